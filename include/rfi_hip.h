@@ -1,0 +1,183 @@
+/* rfi_hip.h -- C ABI of librfi_hip.so, the MI355X (gfx950) implementation of the
+ * rfi_toolbox segmentation hot path.
+ *
+ * The reference (preshanth/rfi_toolbox v0.2.0) is pure Python and has no FFI
+ * layer of its own; its boundary for this path is the torch.nn.Module object
+ * protocol plus two plain functions.  Each group below names the reference
+ * interface it replaces (paths relative to the reference root).  The Python
+ * binding that a maintainer would add is shown in INTEGRATION.md and shipped in
+ * rfi_toolbox_amd/_lib.py (ctypes; the header is also cffi-ABI-mode parsable).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message of
+ *     the last failure on the calling thread is rfi_last_error().
+ *   - plain pointers + sizes only.  `mem` arguments say where a buffer lives:
+ *     RFI_HOST (pageable/pinned host memory) or RFI_DEVICE (HBM on the ctx's GPU).
+ *     Buffers are caller-owned and never retained past the call.
+ *   - images are NHWC float32 (what Preprocessor emits, preprocessor.py:380-404);
+ *     the NCHW entry points exist because UNet.forward takes NCHW (unet.py:60).
+ *   - a handle is bound to one GPU and one HIP stream and is not thread-safe:
+ *     one host thread per handle, one process per GPU.
+ */
+#ifndef RFI_HIP_H
+#define RFI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFI_HIP_ABI_VERSION 1
+
+enum { RFI_HOST = 0, RFI_DEVICE = 1 };
+
+typedef struct rfi_ctx rfi_ctx;
+typedef struct rfi_model rfi_model;
+
+/* ---- library / context ------------------------------------------------------------ */
+int         rfi_abi_version(void);
+const char* rfi_last_error(void);
+int rfi_device_count(int* count);
+int rfi_ctx_create(int device_id, rfi_ctx** out);
+int rfi_ctx_destroy(rfi_ctx* ctx);
+int rfi_ctx_synchronize(rfi_ctx* ctx);
+/* the hipStream_t every kernel of this ctx is launched on (for event timing / interop) */
+int rfi_ctx_stream(rfi_ctx* ctx, void** hip_stream);
+int rfi_ctx_device_name(rfi_ctx* ctx, char* buf, size_t buflen);
+
+/* device memory owned by the ctx (freed at rfi_ctx_destroy if still live) */
+int rfi_malloc(rfi_ctx* ctx, size_t bytes, void** dptr);
+int rfi_free(rfi_ctx* ctx, void* dptr);
+int rfi_memcpy(rfi_ctx* ctx, void* dst, int dst_mem, const void* src, int src_mem, size_t bytes);
+int rfi_memset(rfi_ctx* ctx, void* dptr, int value, size_t bytes);
+
+/* HIP-event stopwatch on the ctx stream: start; ...launches...; stop -> elapsed ms (syncs) */
+int rfi_timer_start(rfi_ctx* ctx);
+int rfi_timer_stop(rfi_ctx* ctx, float* elapsed_ms);
+
+/* per-kernel-family HIP-event profile of everything launched while enabled.
+ * families: see rfi_profile_family_name(); flops/bytes are ALGORITHMIC counts. */
+int rfi_profile_enable(rfi_ctx* ctx, int on);
+int rfi_profile_reset(rfi_ctx* ctx);
+int rfi_profile_family_count(void);
+const char* rfi_profile_family_name(int family);
+int rfi_profile_get(rfi_ctx* ctx, int family, int64_t* launches, double* total_ms,
+                    double* flops, double* bytes);
+
+/* ---- model: replaces rfi_toolbox.models.UNet (models/unet.py:41-77; UNetBigger :79-118
+ *      is depth=5) as constructed by scripts/train_model.py:111, evaluate_model.py:34 ---- */
+int rfi_unet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_features,
+                    int depth, rfi_model** out);
+int rfi_model_destroy(rfi_model* m);
+/* deterministic init with torch's default distributions (kaiming-uniform(a=sqrt5) conv
+ * weights/biases, BN gamma=1 beta=0, running stats 0/1) from a 64-bit seed */
+int rfi_model_init(rfi_model* m, uint64_t seed);
+
+/* state_dict surface (train_model.py:179, evaluate_model.py:35): entries are in the
+ * reference's state_dict order with the reference's key names and shapes; float32
+ * except num_batches_tracked (int64).  Values cross the boundary in the reference's
+ * layouts (Conv2d OIHW, ConvTranspose2d IOHW); the library converts. */
+int rfi_model_entry_count(rfi_model* m, int* n);
+int rfi_model_entry_info(rfi_model* m, int index, const char** name, int* ndim,
+                         int64_t dims[4], int* is_int64, int* is_parameter);
+int rfi_model_load_entry(rfi_model* m, const char* name, const void* host, size_t bytes);
+int rfi_model_store_entry(rfi_model* m, const char* name, void* host, size_t bytes);
+int rfi_model_param_count(rfi_model* m, int64_t* n_scalars);   /* == sum(p.numel()) */
+
+/* .train() / .eval()  (train_model.py:136,157) */
+int rfi_model_set_training(rfi_model* m, int training);
+
+/* model(x) -> logits (N,out,H,W)  (unet.py:60-77; train_model.py:145).  In training mode
+ * BatchNorm uses batch statistics and updates the running buffers exactly as the
+ * reference does, including the encoder's double EMA update (unet.py:28). */
+int rfi_model_forward_nhwc(rfi_model* m, const float* x, int x_mem, int n, int h, int w,
+                           float* logits, int logits_mem);
+int rfi_model_forward_nchw(rfi_model* m, const float* x, int x_mem, int n, int h, int w,
+                           float* logits, int logits_mem);
+
+/* ---- optimisation step: replaces the body of the loop in scripts/train_model.py:139-154
+ *      zero_grad -> forward -> BCEWithLogits(mean)+dice (:120-128,146) -> backward ->
+ *      clip_grad_norm_(max_norm) (:149) -> Adam(lr, betas, eps, coupled L2 weight_decay)
+ *      (:130,150).  labels are uint8 (N,H,W), non-zero == RFI.  fp32 throughout (the
+ *      reference's CPU path; autocast/GradScaler are off there, :131,144). ---- */
+typedef struct rfi_hyper {
+    float lr, beta1, beta2, eps, weight_decay, max_grad_norm;
+} rfi_hyper;
+
+int rfi_train_step(rfi_model* m, const float* x_nhwc, int x_mem, const uint8_t* labels,
+                   int labels_mem, int n, int h, int w, const rfi_hyper* hp, float* loss_out);
+/* same step split in two so a data-parallel caller can all-reduce the gradients in between */
+int rfi_train_forward_backward(rfi_model* m, const float* x_nhwc, int x_mem,
+                               const uint8_t* labels, int labels_mem, int n, int h, int w,
+                               float* loss_out);
+int rfi_train_apply(rfi_model* m, const rfi_hyper* hp, float grad_scale, float* grad_norm_out);
+/* loss only, no update (validation loop, train_model.py:157-167) */
+int rfi_model_loss(rfi_model* m, const float* x_nhwc, int x_mem, const uint8_t* labels,
+                   int labels_mem, int n, int h, int w, float* loss_out);
+/* non-blocking variant used by bench loops: enqueue one full step, no host sync */
+int rfi_train_step_async(rfi_model* m, const float* x_dev, const uint8_t* labels_dev,
+                         int n, int h, int w, const rfi_hyper* hp);
+int rfi_model_last_loss(rfi_model* m, float* loss_out, float* grad_norm_out);   /* syncs */
+
+/* flat gradient / parameter buffers (device pointers, library layout) + gradient access
+ * by reference name in reference layout (what p.grad would hold after backward) */
+int rfi_model_grad_buffer(rfi_model* m, float** dptr, int64_t* n_floats);
+int rfi_model_param_buffer(rfi_model* m, float** dptr, int64_t* n_floats);
+int rfi_model_store_grad(rfi_model* m, const char* name, void* host, size_t bytes);
+int rfi_model_store_adam(rfi_model* m, const char* name, void* host_m, void* host_v, size_t bytes,
+                         int64_t* step);
+int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, double* step);
+
+/* ---- data-parallel gradient exchange (new; the reference has no multi-GPU path) -------
+ * RCCL over xGMI: ncclAllReduce(sum) of the flat gradient buffer on the ctx stream.
+ * librccl.so is dlopen()ed on first use.  id_buf: 128 bytes (ncclUniqueId). */
+int rfi_comm_unique_id(void* id_buf128);
+int rfi_comm_init(rfi_ctx* ctx, const void* id_buf128, int rank, int world_size);
+int rfi_comm_destroy(rfi_ctx* ctx);
+int rfi_comm_allreduce_sum_f32(rfi_ctx* ctx, float* dptr, int64_t count);
+int rfi_model_allreduce_grads(rfi_model* m);   /* all-reduce(sum) of the grad buffer */
+
+/* ---- preprocessing: replaces the per-patch hot loop of Preprocessor.create_dataset
+ *      (preprocessing/preprocessor.py:366-384: _extract_channels_from_complex :562-606 /
+ *      _from_real :608-644, then _apply_sam2_normalization :765-783) for a stack of
+ *      patches already tiled/rotated by the host.  in: (n,ps_h,ps_w) complex128/complex64
+ *      (interleaved re,im) or float64/float32 real; out: NHWC float32 (n,ps_h,ps_w,3). ---- */
+enum { RFI_C128 = 0, RFI_C64 = 1, RFI_F64 = 2, RFI_F32 = 3 };
+int rfi_preprocess_patches(rfi_ctx* ctx, const void* patches, int patches_mem, int dtype,
+                           int n, int ps_h, int ps_w, float* out_nhwc, int out_mem);
+
+/* ---- metrics: replaces the reductions of evaluation/metrics.py:25-172.  pred/true are
+ *      uint8 or float32 arrays of `count` elements, non-zero == positive (:36-37). ---- */
+enum { RFI_U8 = 0, RFI_FLOAT32 = 1 };
+int rfi_confusion_counts(rfi_ctx* ctx, const void* pred, int pred_dtype, int pred_mem,
+                         const void* truth, int truth_dtype, int truth_mem, int64_t count,
+                         int64_t* tp, int64_t* fp, int64_t* fn);
+/* sigmoid(logit) > threshold on device (evaluate_model.py:44-47), u8 out */
+int rfi_threshold_logits(rfi_ctx* ctx, const float* logits_dev, int64_t count, float threshold,
+                         uint8_t* mask_dev);
+
+/* ---- kernel-level entry points (device pointers only).  Used by the parity tests to
+ *      check each HIP kernel against the oracle in isolation.  impl: 0 auto, 1 direct VALU,
+ *      2 MFMA implicit GEMM. ---- */
+int rfi_op_conv3x3(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
+                   const float* w_oihw, const float* bias, int cout,
+                   const float* in_scale, const float* in_shift, int in_relu, float* y);
+int rfi_op_conv3x3_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h, int w, int cout,
+                         const float* w_oihw, int cin, float* dx);
+int rfi_op_conv3x3_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy, int n, int h,
+                         int w, int cin, int cout, const float* in_scale, const float* in_shift,
+                         int in_relu, float* dw_oihw);
+int rfi_op_convt2x2(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
+                    const float* w_iohw, const float* bias, int cout, float* y);
+int rfi_op_convt2x2_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h, int w, int cout,
+                          const float* w_iohw, int cin, float* dx);
+int rfi_op_convt2x2_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy, int n, int h,
+                          int w, int cin, int cout, float* dw_iohw);
+int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean, float* var_biased);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFI_HIP_H */

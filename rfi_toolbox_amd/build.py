@@ -1,0 +1,72 @@
+"""Build librfi_hip.so (gfx950) in-tree with hipcc.
+
+    python -m rfi_toolbox_amd.build            # incremental
+    python -m rfi_toolbox_amd.build --force
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects go to build/obj, the shared library to
+rfi_toolbox_amd/librfi_hip.so (git-ignored; it travels to the GPU box with the tree).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(ROOT, "build", "obj")
+LIB = os.path.join(PKG, "librfi_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+SOURCES = ["api.cpp", "model.cpp", "elem_kernels.hip", "conv_direct.hip", "conv_mfma.hip",
+           "wgrad_mfma.hip", "preprocess.hip"]
+HEADERS = ["common.hpp", "kernels.hpp", "model.hpp", os.path.join(ROOT, "include", "rfi_hip.h")]
+
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-ffp-contract=off"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, force, extra):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src.replace(".", "_") + ".o")
+    deps = [path] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _newer(obj, deps):
+        return obj, None
+    cmd = [HIPCC, *COMMON, *extra, "-x", "hip", "-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return obj, r.stderr
+
+
+def build(force=False, verbose=False, extra=()):
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, list(extra)), SOURCES))
+    objs = [o for o, _ in results]
+    if verbose:
+        for (_, log), s in zip(results, SOURCES):
+            if log:
+                print(f"--- {s}\n{log}")
+    if force or _newer(LIB, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB, "-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    lib = build(force="--force" in sys.argv, verbose="-v" in sys.argv,
+                extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
+    print(lib)

@@ -1,0 +1,948 @@
+// extern "C" surface of librfi_hip.so (declared in include/rfi_hip.h).
+#include <dlfcn.h>
+
+#include <cmath>
+#include <random>
+
+#include "model.hpp"
+
+using namespace rfi;
+
+// ------------------------------------------------------------------------------------ errors
+namespace rfi {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace rfi
+
+// ------------------------------------------------------------------------------------ ctx
+void rfi_ctx::activate() const { RFI_CHECK_HIP(hipSetDevice(device)); }
+
+void* rfi_ctx::alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    RFI_CHECK_HIP(hipMalloc(&p, bytes));
+    allocs[p] = bytes;
+    return p;
+}
+void rfi_ctx::release(void* p) {
+    if (!p) return;
+    auto it = allocs.find(p);
+    RFI_REQUIRE(it != allocs.end(), "rfi_free: pointer was not allocated by this context");
+    allocs.erase(it);
+    RFI_CHECK_HIP(hipFree(p));
+}
+hipEvent_t rfi_ctx::get_event() {
+    if (!event_pool.empty()) {
+        hipEvent_t e = event_pool.back();
+        event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    RFI_CHECK_HIP(hipEventCreate(&e));
+    return e;
+}
+void rfi_ctx::drain_profile() {
+    for (auto& pe : pending) {
+        RFI_CHECK_HIP(hipEventSynchronize(pe.b));
+        float ms = 0;
+        RFI_CHECK_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
+        fam[pe.family].ms += ms;
+        event_pool.push_back(pe.a);
+        event_pool.push_back(pe.b);
+    }
+    pending.clear();
+}
+
+static const char* kFamilyNames[FAM_COUNT] = {"conv_igemm_mfma", "wgrad_igemm_mfma", "conv_direct_valu",
+                                              "batchnorm", "elementwise", "slab_reduce", "optimizer",
+                                              "preprocess", "metrics", "comm"};
+
+extern "C" {
+
+int rfi_abi_version(void) { return RFI_HIP_ABI_VERSION; }
+const char* rfi_last_error(void) { return g_last_error.c_str(); }
+
+int rfi_device_count(int* count) {
+    return guarded([&] {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) n = 0;
+        *count = n;
+    });
+}
+
+int rfi_ctx_create(int device_id, rfi_ctx** out) {
+    return guarded([&] {
+        RFI_REQUIRE(out, "rfi_ctx_create: null out pointer");
+        int n = 0;
+        RFI_CHECK_HIP(hipGetDeviceCount(&n));
+        RFI_REQUIRE(device_id >= 0 && device_id < n, "rfi_ctx_create: no such GPU (device " +
+                                                         std::to_string(device_id) + " of " + std::to_string(n) + ")");
+        auto* c = new rfi_ctx();
+        c->device = device_id;
+        c->activate();
+        RFI_CHECK_HIP(hipGetDeviceProperties(&c->prop, device_id));
+        RFI_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        RFI_CHECK_HIP(hipEventCreate(&c->t0));
+        RFI_CHECK_HIP(hipEventCreate(&c->t1));
+        RFI_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 4096, hipHostMallocDefault));
+        *out = c;
+    });
+}
+
+int rfi_ctx_destroy(rfi_ctx* ctx) {
+    return guarded([&] {
+        if (!ctx) return;
+        ctx->activate();
+        hipStreamSynchronize(ctx->stream);
+        for (auto& pe : ctx->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
+        for (auto e : ctx->event_pool) hipEventDestroy(e);
+        for (auto& kv : ctx->allocs) hipFree(kv.first);
+        if (ctx->pinned) hipHostFree(ctx->pinned);
+        hipEventDestroy(ctx->t0);
+        hipEventDestroy(ctx->t1);
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+    });
+}
+
+int rfi_ctx_synchronize(rfi_ctx* ctx) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+int rfi_ctx_stream(rfi_ctx* ctx, void** s) {
+    return guarded([&] { *s = reinterpret_cast<void*>(ctx->stream); });
+}
+int rfi_ctx_device_name(rfi_ctx* ctx, char* buf, size_t buflen) {
+    return guarded([&] {
+        std::string s = std::string(ctx->prop.name) + " " + ctx->prop.gcnArchName + " CUs=" +
+                        std::to_string(ctx->prop.multiProcessorCount);
+        std::snprintf(buf, buflen, "%s", s.c_str());
+    });
+}
+
+int rfi_malloc(rfi_ctx* ctx, size_t bytes, void** dptr) {
+    return guarded([&] {
+        ctx->activate();
+        *dptr = ctx->alloc(bytes);
+    });
+}
+int rfi_free(rfi_ctx* ctx, void* dptr) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->release(dptr);
+    });
+}
+int rfi_memcpy(rfi_ctx* ctx, void* dst, int dst_mem, const void* src, int src_mem, size_t bytes) {
+    return guarded([&] {
+        ctx->activate();
+        hipMemcpyKind k = (dst_mem == RFI_DEVICE)
+                              ? (src_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice)
+                              : (src_mem == RFI_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+        RFI_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+int rfi_memset(rfi_ctx* ctx, void* dptr, int value, size_t bytes) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_CHECK_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    });
+}
+
+int rfi_timer_start(rfi_ctx* ctx) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_CHECK_HIP(hipEventRecord(ctx->t0, ctx->stream));
+    });
+}
+int rfi_timer_stop(rfi_ctx* ctx, float* elapsed_ms) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_CHECK_HIP(hipEventRecord(ctx->t1, ctx->stream));
+        RFI_CHECK_HIP(hipEventSynchronize(ctx->t1));
+        RFI_CHECK_HIP(hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+    });
+}
+
+int rfi_profile_enable(rfi_ctx* ctx, int on) {
+    return guarded([&] {
+        ctx->activate();
+        if (!on) ctx->drain_profile();
+        ctx->profiling = on != 0;
+    });
+}
+int rfi_profile_reset(rfi_ctx* ctx) {
+    return guarded([&] {
+        ctx->activate();
+        ctx->drain_profile();
+        for (auto& f : ctx->fam) f = FamilyStat();
+    });
+}
+int rfi_profile_family_count(void) { return FAM_COUNT; }
+const char* rfi_profile_family_name(int family) {
+    return (family >= 0 && family < FAM_COUNT) ? kFamilyNames[family] : "";
+}
+int rfi_profile_get(rfi_ctx* ctx, int family, int64_t* launches, double* total_ms, double* flops,
+                    double* bytes) {
+    return guarded([&] {
+        RFI_REQUIRE(family >= 0 && family < FAM_COUNT, "rfi_profile_get: bad family");
+        ctx->activate();
+        ctx->drain_profile();
+        const FamilyStat& f = ctx->fam[family];
+        if (launches) *launches = f.launches;
+        if (total_ms) *total_ms = f.ms;
+        if (flops) *flops = f.flops;
+        if (bytes) *bytes = f.bytes;
+    });
+}
+
+// ------------------------------------------------------------------------------------ model
+int rfi_unet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_features, int depth,
+                    rfi_model** out) {
+    return guarded([&] {
+        RFI_REQUIRE(ctx && out, "rfi_unet_create: null argument");
+        auto* m = new rfi_model();
+        m->ctx = ctx;
+        m->in_ch = in_channels;
+        m->out_ch = out_channels;
+        m->feat = init_features;
+        m->depth = depth;
+        try {
+            m->build();
+        } catch (...) {
+            m->ctx = nullptr;   // nothing to free through the dtor path that is not tracked by ctx
+            delete m;
+            throw;
+        }
+        *out = m;
+    });
+}
+int rfi_model_destroy(rfi_model* m) {
+    return guarded([&] {
+        if (!m) return;
+        m->ctx->activate();
+        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        delete m;
+    });
+}
+
+namespace {
+
+// reference layout <-> library layout for one entry; host staging vectors
+void to_lib_conv(const float* oihw, int cout, int cin, int R, std::vector<float>& out) {
+    out.resize((size_t)R * R * cout * cin);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < R * R; ++t)
+                out[((size_t)t * cout + co) * cin + ci] = oihw[((size_t)co * cin + ci) * R * R + t];
+}
+void from_lib_conv(const float* lib, int cout, int cin, int R, float* oihw) {
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < R * R; ++t)
+                oihw[((size_t)co * cin + ci) * R * R + t] = lib[((size_t)t * cout + co) * cin + ci];
+}
+// ConvTranspose2d weight is [cin][cout][2][2]
+void to_lib_convt(const float* iohw, int cin, int cout, std::vector<float>& out) {
+    out.resize((size_t)4 * cout * cin);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int t = 0; t < 4; ++t)
+                out[((size_t)t * cout + co) * cin + ci] = iohw[((size_t)ci * cout + co) * 4 + t];
+}
+void from_lib_convt(const float* lib, int cin, int cout, float* iohw) {
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int t = 0; t < 4; ++t)
+                iohw[((size_t)ci * cout + co) * 4 + t] = lib[((size_t)t * cout + co) * cin + ci];
+}
+
+// where a float entry lives inside a flat buffer (params / grads / adam m / adam v)
+size_t flat_offset(const rfi_model* m, const Entry& e) {
+    switch (e.kind) {
+        case 0: return m->convs[e.layer].w_off;
+        case 1: return m->ups[e.layer].w_off;
+        case 6: return m->head_w_off;
+        case 2:
+            switch (e.which) {
+                case 0: return m->convs[e.layer].b_off;
+                case 1: return m->convs[e.layer].g_off;
+                case 2: return m->convs[e.layer].be_off;
+                case 3: return m->ups[e.layer].b_off;
+                default: return m->head_b_off;
+            }
+        default: throw Error("entry " + e.name + " is not a parameter");
+    }
+}
+
+void upload(rfi_model* m, float* dst, const float* src, size_t n) {
+    RFI_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+    RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+}
+void download(rfi_model* m, float* dst, const float* src, size_t n) {
+    RFI_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+    RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+}
+
+const Entry& find_entry(rfi_model* m, const char* name) {
+    RFI_REQUIRE(name, "null entry name");
+    auto it = m->entry_index.find(name);
+    RFI_REQUIRE(it != m->entry_index.end(), std::string("unexpected key in state_dict: ") + name);
+    return m->entries[it->second];
+}
+
+void store_from_flat(rfi_model* m, const float* flat, const Entry& e, void* host, size_t bytes) {
+    RFI_REQUIRE(bytes == (size_t)e.numel() * sizeof(float),
+                "size mismatch for " + e.name + ": expected " + std::to_string(e.numel() * 4) + " bytes, got " +
+                    std::to_string(bytes));
+    const size_t off = flat_offset(m, e);
+    std::vector<float> tmp((size_t)e.numel());
+    download(m, tmp.data(), flat + off, tmp.size());
+    float* out = static_cast<float*>(host);
+    if (e.kind == 0) from_lib_conv(tmp.data(), (int)e.dims[0], (int)e.dims[1], 3, out);
+    else if (e.kind == 1) from_lib_convt(tmp.data(), (int)e.dims[0], (int)e.dims[1], out);
+    else std::memcpy(out, tmp.data(), bytes);
+}
+
+}  // namespace
+
+int rfi_model_init(rfi_model* m, uint64_t seed) {
+    return guarded([&] {
+        m->ctx->activate();
+        std::mt19937_64 rng(seed);
+        std::vector<float> flat(m->n_flat, 0.0f);
+        auto uni = [&](float bound) {
+            return (float)((std::generate_canonical<double, 53>(rng) * 2.0 - 1.0) * bound);
+        };
+        float last_bound = 0;
+        for (const Entry& e : m->entries) {
+            if (e.kind == 0 || e.kind == 1 || e.kind == 6) {
+                // kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)), fan_in = dims[1]*kh*kw
+                const double fan_in = (double)e.dims[1] * e.dims[2] * e.dims[3];
+                last_bound = (float)(1.0 / std::sqrt(fan_in));
+                float* w = flat.data() + flat_offset(m, e);
+                for (int64_t i = 0; i < e.numel(); ++i) w[i] = uni(last_bound);   // layout-agnostic iid
+            } else if (e.kind == 2) {
+                float* v = flat.data() + flat_offset(m, e);
+                for (int64_t i = 0; i < e.numel(); ++i)
+                    v[i] = (e.which == 1) ? 1.0f : (e.which == 2 ? 0.0f : uni(last_bound));
+            }
+        }
+        upload(m, m->params, flat.data(), m->n_flat);
+        for (auto& c : m->convs) {
+            std::vector<float> ch((size_t)8 * c.cout, 0.0f);
+            for (int i = 0; i < c.cout; ++i) ch[c.cout + i] = 1.0f;     // running_var = 1
+            upload(m, c.chan, ch.data(), ch.size());
+            c.nbt = 0;
+        }
+        RFI_CHECK_HIP(hipMemsetAsync(m->adam_m, 0, m->n_flat * sizeof(float), m->ctx->stream));
+        RFI_CHECK_HIP(hipMemsetAsync(m->adam_v, 0, m->n_flat * sizeof(float), m->ctx->stream));
+        m->adam_step = 0;
+        m->wd_dirty = true;
+    });
+}
+
+int rfi_model_entry_count(rfi_model* m, int* n) {
+    return guarded([&] { *n = (int)m->entries.size(); });
+}
+int rfi_model_entry_info(rfi_model* m, int index, const char** name, int* ndim, int64_t dims[4],
+                         int* is_int64, int* is_parameter) {
+    return guarded([&] {
+        RFI_REQUIRE(index >= 0 && index < (int)m->entries.size(), "entry index out of range");
+        const Entry& e = m->entries[index];
+        if (name) *name = e.name.c_str();
+        if (ndim) *ndim = e.ndim;
+        if (dims)
+            for (int i = 0; i < 4; ++i) dims[i] = i < e.ndim ? e.dims[i] : 1;
+        if (is_int64) *is_int64 = e.kind == 5;
+        if (is_parameter) *is_parameter = (e.kind == 0 || e.kind == 1 || e.kind == 2 || e.kind == 6);
+    });
+}
+int rfi_model_param_count(rfi_model* m, int64_t* n) {
+    return guarded([&] { *n = m->n_params; });
+}
+
+int rfi_model_load_entry(rfi_model* m, const char* name, const void* host, size_t bytes) {
+    return guarded([&] {
+        m->ctx->activate();
+        const Entry& e = find_entry(m, name);
+        if (e.kind == 5) {
+            RFI_REQUIRE(bytes == sizeof(int64_t), "size mismatch for " + e.name);
+            m->convs[e.layer].nbt = *static_cast<const int64_t*>(host);
+            return;
+        }
+        RFI_REQUIRE(bytes == (size_t)e.numel() * sizeof(float),
+                    "size mismatch for " + e.name + ": expected " + std::to_string(e.numel() * 4) +
+                        " bytes, got " + std::to_string(bytes));
+        const float* src = static_cast<const float*>(host);
+        if (e.kind == 3 || e.kind == 4) {
+            ConvBN& c = m->convs[e.layer];
+            upload(m, e.kind == 3 ? c.running_mean() : c.running_var(), src, (size_t)c.cout);
+            return;
+        }
+        std::vector<float> tmp;
+        if (e.kind == 0) to_lib_conv(src, (int)e.dims[0], (int)e.dims[1], 3, tmp);
+        else if (e.kind == 1) to_lib_convt(src, (int)e.dims[0], (int)e.dims[1], tmp);
+        else tmp.assign(src, src + e.numel());
+        upload(m, m->params + flat_offset(m, e), tmp.data(), tmp.size());
+        m->wd_dirty = true;
+    });
+}
+
+int rfi_model_store_entry(rfi_model* m, const char* name, void* host, size_t bytes) {
+    return guarded([&] {
+        m->ctx->activate();
+        const Entry& e = find_entry(m, name);
+        if (e.kind == 5) {
+            RFI_REQUIRE(bytes == sizeof(int64_t), "size mismatch for " + e.name);
+            *static_cast<int64_t*>(host) = m->convs[e.layer].nbt;
+            return;
+        }
+        if (e.kind == 3 || e.kind == 4) {
+            RFI_REQUIRE(bytes == (size_t)e.numel() * sizeof(float), "size mismatch for " + e.name);
+            ConvBN& c = m->convs[e.layer];
+            download(m, static_cast<float*>(host), e.kind == 3 ? c.running_mean() : c.running_var(),
+                     (size_t)c.cout);
+            return;
+        }
+        store_from_flat(m, m->params, e, host, bytes);
+    });
+}
+
+int rfi_model_store_grad(rfi_model* m, const char* name, void* host, size_t bytes) {
+    return guarded([&] {
+        m->ctx->activate();
+        store_from_flat(m, m->grads, find_entry(m, name), host, bytes);
+    });
+}
+int rfi_model_store_adam(rfi_model* m, const char* name, void* host_m, void* host_v, size_t bytes,
+                         int64_t* step) {
+    return guarded([&] {
+        m->ctx->activate();
+        const Entry& e = find_entry(m, name);
+        if (host_m) store_from_flat(m, m->adam_m, e, host_m, bytes);
+        if (host_v) store_from_flat(m, m->adam_v, e, host_v, bytes);
+        if (step) *step = m->adam_step;
+    });
+}
+
+int rfi_model_set_training(rfi_model* m, int training) {
+    return guarded([&] { m->training = training != 0; });
+}
+
+namespace {
+
+const float* stage_input(rfi_model* m, const float* x, int x_mem, int n, int h, int w, bool nchw) {
+    const size_t cnt = (size_t)n * h * w * m->in_ch;
+    const float* dev = x;
+    if (x_mem == RFI_HOST) {
+        float* st = m->buf(nchw ? m->x_stage2 : m->x_stage);
+        RFI_CHECK_HIP(hipMemcpyAsync(st, x, cnt * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+        dev = st;
+    }
+    if (nchw) {
+        launch_nchw_to_nhwc(m->ctx, dev, n, m->in_ch, h, w, m->buf(m->x_stage));
+        dev = m->buf(m->x_stage);
+    }
+    return dev;
+}
+const uint8_t* stage_labels(rfi_model* m, const uint8_t* y, int y_mem, int n, int h, int w) {
+    if (y_mem == RFI_DEVICE) return y;
+    uint8_t* st = reinterpret_cast<uint8_t*>(m->buf(m->lab_stage));
+    RFI_CHECK_HIP(hipMemcpyAsync(st, y, (size_t)n * h * w, hipMemcpyHostToDevice, m->ctx->stream));
+    return st;
+}
+void emit_logits(rfi_model* m, float* out, int out_mem, int n, int h, int w, bool nchw) {
+    const size_t cnt = (size_t)n * h * w * m->out_ch;
+    const float* src = m->buf(m->logits);
+    if (nchw && m->out_ch > 1) {
+        launch_nhwc_to_nchw(m->ctx, src, n, m->out_ch, h, w, m->buf(m->out_stage));
+        src = m->buf(m->out_stage);
+    }
+    RFI_CHECK_HIP(hipMemcpyAsync(out, src, cnt * sizeof(float),
+                                 out_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                 m->ctx->stream));
+    RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+}
+float read_scalar(rfi_model* m, const float* dev) {
+    RFI_CHECK_HIP(hipMemcpyAsync(m->ctx->pinned, dev, sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+    RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    return m->ctx->pinned[0];
+}
+void check_hyper(const rfi_hyper* hp) {
+    RFI_REQUIRE(hp, "null hyper-parameters");
+    RFI_REQUIRE(hp->lr >= 0 && hp->eps >= 0 && hp->weight_decay >= 0, "Adam: lr, eps, weight_decay must be >= 0");
+    RFI_REQUIRE(hp->beta1 >= 0 && hp->beta1 < 1 && hp->beta2 >= 0 && hp->beta2 < 1, "Adam: betas must be in [0,1)");
+}
+
+}  // namespace
+
+int rfi_model_forward_nhwc(rfi_model* m, const float* x, int x_mem, int n, int h, int w, float* logits,
+                           int logits_mem) {
+    return guarded([&] {
+        m->ctx->activate();
+        m->prepare(n, h, w);
+        const float* xd = stage_input(m, x, x_mem, n, h, w, false);
+        m->forward(xd, n, h, w, m->training);
+        emit_logits(m, logits, logits_mem, n, h, w, false);
+    });
+}
+int rfi_model_forward_nchw(rfi_model* m, const float* x, int x_mem, int n, int h, int w, float* logits,
+                           int logits_mem) {
+    return guarded([&] {
+        m->ctx->activate();
+        m->prepare(n, h, w);
+        const float* xd = stage_input(m, x, x_mem, n, h, w, true);
+        m->forward(xd, n, h, w, m->training);
+        emit_logits(m, logits, logits_mem, n, h, w, true);
+    });
+}
+
+int rfi_train_forward_backward(rfi_model* m, const float* x, int x_mem, const uint8_t* labels,
+                               int labels_mem, int n, int h, int w, float* loss_out) {
+    return guarded([&] {
+        m->ctx->activate();
+        m->prepare(n, h, w);
+        const float* xd = stage_input(m, x, x_mem, n, h, w, false);
+        const uint8_t* yd = stage_labels(m, labels, labels_mem, n, h, w);
+        m->forward(xd, n, h, w, true);
+        m->loss_forward(yd, n, h, w);
+        m->backward(xd, yd, n, h, w);
+        if (loss_out) *loss_out = m->last_loss = read_scalar(m, m->d_scalars);
+    });
+}
+int rfi_train_apply(rfi_model* m, const rfi_hyper* hp, float grad_scale, float* grad_norm_out) {
+    return guarded([&] {
+        check_hyper(hp);
+        m->ctx->activate();
+        RFI_REQUIRE(m->pN > 0, "rfi_train_apply: no gradients (call rfi_train_forward_backward first)");
+        m->apply(*hp, grad_scale);
+        if (grad_norm_out) *grad_norm_out = m->last_norm = read_scalar(m, m->d_scalars + 1);
+    });
+}
+int rfi_train_step(rfi_model* m, const float* x, int x_mem, const uint8_t* labels, int labels_mem,
+                   int n, int h, int w, const rfi_hyper* hp, float* loss_out) {
+    return guarded([&] {
+        check_hyper(hp);
+        m->ctx->activate();
+        m->prepare(n, h, w);
+        const float* xd = stage_input(m, x, x_mem, n, h, w, false);
+        const uint8_t* yd = stage_labels(m, labels, labels_mem, n, h, w);
+        m->forward(xd, n, h, w, true);
+        m->loss_forward(yd, n, h, w);
+        m->backward(xd, yd, n, h, w);
+        m->apply(*hp, 1.0f);
+        RFI_CHECK_HIP(hipMemcpyAsync(m->ctx->pinned, m->d_scalars, 2 * sizeof(float), hipMemcpyDeviceToHost,
+                                     m->ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        m->last_loss = m->ctx->pinned[0];
+        m->last_norm = m->ctx->pinned[1];
+        if (loss_out) *loss_out = m->last_loss;
+    });
+}
+int rfi_train_step_async(rfi_model* m, const float* x_dev, const uint8_t* labels_dev, int n, int h,
+                         int w, const rfi_hyper* hp) {
+    return guarded([&] {
+        check_hyper(hp);
+        m->ctx->activate();
+        m->prepare(n, h, w);
+        m->forward(x_dev, n, h, w, true);
+        m->loss_forward(labels_dev, n, h, w);
+        m->backward(x_dev, labels_dev, n, h, w);
+        if (m->ctx->nccl_comm && m->ctx->world > 1) {
+            RFI_REQUIRE(rfi_comm_allreduce_sum_f32(m->ctx, m->grads, (int64_t)m->n_flat) == 0, rfi_last_error());
+            m->apply(*hp, 1.0f / (float)m->ctx->world);
+        } else {
+            m->apply(*hp, 1.0f);
+        }
+    });
+}
+int rfi_model_last_loss(rfi_model* m, float* loss_out, float* grad_norm_out) {
+    return guarded([&] {
+        m->ctx->activate();
+        RFI_CHECK_HIP(hipMemcpyAsync(m->ctx->pinned, m->d_scalars, 2 * sizeof(float), hipMemcpyDeviceToHost,
+                                     m->ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        if (loss_out) *loss_out = m->ctx->pinned[0];
+        if (grad_norm_out) *grad_norm_out = m->ctx->pinned[1];
+    });
+}
+int rfi_model_loss(rfi_model* m, const float* x, int x_mem, const uint8_t* labels, int labels_mem, int n,
+                   int h, int w, float* loss_out) {
+    return guarded([&] {
+        m->ctx->activate();
+        m->prepare(n, h, w);
+        const float* xd = stage_input(m, x, x_mem, n, h, w, false);
+        const uint8_t* yd = stage_labels(m, labels, labels_mem, n, h, w);
+        m->forward(xd, n, h, w, m->training);
+        m->loss_forward(yd, n, h, w);
+        if (loss_out) *loss_out = read_scalar(m, m->d_scalars);
+    });
+}
+
+int rfi_model_grad_buffer(rfi_model* m, float** dptr, int64_t* n_floats) {
+    return guarded([&] {
+        *dptr = m->grads;
+        *n_floats = (int64_t)m->n_flat;
+    });
+}
+int rfi_model_param_buffer(rfi_model* m, float** dptr, int64_t* n_floats) {
+    return guarded([&] {
+        *dptr = m->params;
+        *n_floats = (int64_t)m->n_flat;
+    });
+}
+
+int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, double* step) {
+    return guarded([&] {
+        // 2*M*K*N over every conv / convT / head, each layer evaluated once
+        double f = 0, stem = 0;
+        const int D = m->depth;
+        for (size_t ci = 0; ci < m->convs.size(); ++ci) {
+            int lvl;
+            if ((int)ci < 2 * D) lvl = (int)ci / 2 + 1;
+            else if ((int)ci < 2 * D + 2) lvl = D + 1;
+            else lvl = D - ((int)ci - (2 * D + 2)) / 2;
+            const double M = (double)n * (h >> (lvl - 1)) * (w >> (lvl - 1));
+            const double fl = 2.0 * M * 9.0 * m->convs[ci].cin * m->convs[ci].cout;
+            f += fl;
+            if (ci == 0) stem = fl;
+        }
+        for (int k = 0; k < D; ++k) {
+            const int l = D - k;
+            const double M = (double)n * (h >> l) * (w >> l);
+            f += 2.0 * M * 4.0 * m->ups[k].cin * m->ups[k].cout;
+        }
+        f += 2.0 * n * h * w * (double)m->feat * m->out_ch;
+        if (fwd) *fwd = f;
+        if (step) *step = 3.0 * f - stem;     // fwd + dgrad + wgrad, no dgrad for the first layer
+    });
+}
+
+// ------------------------------------------------------------------------------------ RCCL
+struct Id128 { char bytes[128]; };   // ncclUniqueId is passed BY VALUE to ncclCommInitRank
+namespace {
+
+struct NcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+NcclApi g_nccl;
+
+void load_nccl() {
+    if (g_nccl.lib) return;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names) {
+        g_nccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (g_nccl.lib) break;
+    }
+    RFI_REQUIRE(g_nccl.lib, std::string("cannot dlopen librccl.so: ") + dlerror());
+    auto sym = [&](const char* s) {
+        void* p = dlsym(g_nccl.lib, s);
+        RFI_REQUIRE(p, std::string("librccl.so lacks symbol ") + s);
+        return p;
+    };
+    g_nccl.GetUniqueId = reinterpret_cast<decltype(g_nccl.GetUniqueId)>(sym("ncclGetUniqueId"));
+    g_nccl.CommInitRank = reinterpret_cast<decltype(g_nccl.CommInitRank)>(sym("ncclCommInitRank"));
+    g_nccl.AllReduce = reinterpret_cast<decltype(g_nccl.AllReduce)>(sym("ncclAllReduce"));
+    g_nccl.CommDestroy = reinterpret_cast<decltype(g_nccl.CommDestroy)>(sym("ncclCommDestroy"));
+    g_nccl.GetErrorString = reinterpret_cast<decltype(g_nccl.GetErrorString)>(sym("ncclGetErrorString"));
+}
+void nccl_check(int rc, const char* what) {
+    if (rc != 0) throw Error(std::string(what) + " failed: " + g_nccl.GetErrorString(rc));
+}
+}  // namespace
+
+int rfi_comm_unique_id(void* id_buf128) {
+    return guarded([&] {
+        load_nccl();
+        nccl_check(g_nccl.GetUniqueId(id_buf128), "ncclGetUniqueId");
+    });
+}
+int rfi_comm_init(rfi_ctx* ctx, const void* id_buf128, int rank, int world_size) {
+    return guarded([&] {
+        RFI_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "rfi_comm_init: bad rank/world");
+        load_nccl();
+        ctx->activate();
+        Id128 id;
+        std::memcpy(id.bytes, id_buf128, 128);
+        void* comm = nullptr;
+        nccl_check(g_nccl.CommInitRank(&comm, world_size, id, rank), "ncclCommInitRank");
+        ctx->nccl_comm = comm;
+        ctx->rank = rank;
+        ctx->world = world_size;
+    });
+}
+int rfi_comm_destroy(rfi_ctx* ctx) {
+    return guarded([&] {
+        if (ctx->nccl_comm) {
+            ctx->activate();
+            hipStreamSynchronize(ctx->stream);
+            nccl_check(g_nccl.CommDestroy(ctx->nccl_comm), "ncclCommDestroy");
+            ctx->nccl_comm = nullptr;
+            ctx->world = 1;
+        }
+    });
+}
+int rfi_comm_allreduce_sum_f32(rfi_ctx* ctx, float* dptr, int64_t count) {
+    return guarded([&] {
+        RFI_REQUIRE(ctx->nccl_comm, "rfi_comm_allreduce: communicator not initialised");
+        ctx->activate();
+        ProfScope ps(ctx, FAM_COMM, 0, (double)count * 4);
+        // ncclFloat32 = 7, ncclSum = 0
+        nccl_check(g_nccl.AllReduce(dptr, dptr, (size_t)count, 7, 0, ctx->nccl_comm, ctx->stream), "ncclAllReduce");
+    });
+}
+int rfi_model_allreduce_grads(rfi_model* m) {
+    return rfi_comm_allreduce_sum_f32(m->ctx, m->grads, (int64_t)m->n_flat);
+}
+
+// ------------------------------------------------------------------------------------ preprocessing / metrics
+int rfi_preprocess_patches(rfi_ctx* ctx, const void* patches, int patches_mem, int dtype, int n,
+                           int ps_h, int ps_w, float* out_nhwc, int out_mem) {
+    return guarded([&] {
+        RFI_REQUIRE(n >= 0 && ps_h > 0 && ps_w > 0, "preprocess: bad shape");
+        if (n == 0) return;
+        ctx->activate();
+        const size_t px = (size_t)n * ps_h * ps_w;
+        const size_t esz = dtype == RFI_C128 ? 16 : (dtype == RFI_F32 ? 4 : 8);
+        void* din = const_cast<void*>(patches);
+        float* dout = out_nhwc;
+        void *tmp_in = nullptr, *tmp_out = nullptr;
+        if (patches_mem == RFI_HOST) {
+            tmp_in = ctx->alloc(px * esz);
+            RFI_CHECK_HIP(hipMemcpyAsync(tmp_in, patches, px * esz, hipMemcpyHostToDevice, ctx->stream));
+            din = tmp_in;
+        }
+        if (out_mem == RFI_HOST) {
+            tmp_out = ctx->alloc(px * 3 * sizeof(float));
+            dout = static_cast<float*>(tmp_out);
+        }
+        void* mm = ctx->alloc((size_t)n * 4 * sizeof(unsigned long long));
+        launch_preprocess(ctx, din, dtype, n, ps_h, ps_w, static_cast<float*>(mm), dout);
+        if (out_mem == RFI_HOST)
+            RFI_CHECK_HIP(hipMemcpyAsync(out_nhwc, dout, px * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->release(mm);
+        if (tmp_in) ctx->release(tmp_in);
+        if (tmp_out) ctx->release(tmp_out);
+    });
+}
+
+int rfi_confusion_counts(rfi_ctx* ctx, const void* pred, int pred_dtype, int pred_mem, const void* truth,
+                         int truth_dtype, int truth_mem, int64_t count, int64_t* tp, int64_t* fp,
+                         int64_t* fn) {
+    return guarded([&] {
+        RFI_REQUIRE(count >= 0, "confusion: negative count");
+        RFI_REQUIRE((pred_dtype == RFI_U8 || pred_dtype == RFI_FLOAT32) &&
+                        (truth_dtype == RFI_U8 || truth_dtype == RFI_FLOAT32), "confusion: dtype must be u8 or f32");
+        ctx->activate();
+        const void *dp = pred, *dt = truth;
+        void *tp_ = nullptr, *tt_ = nullptr;
+        if (pred_mem == RFI_HOST && count) {
+            const size_t b = (size_t)count * (pred_dtype ? 4 : 1);
+            tp_ = ctx->alloc(b);
+            RFI_CHECK_HIP(hipMemcpyAsync(tp_, pred, b, hipMemcpyHostToDevice, ctx->stream));
+            dp = tp_;
+        }
+        if (truth_mem == RFI_HOST && count) {
+            const size_t b = (size_t)count * (truth_dtype ? 4 : 1);
+            tt_ = ctx->alloc(b);
+            RFI_CHECK_HIP(hipMemcpyAsync(tt_, truth, b, hipMemcpyHostToDevice, ctx->stream));
+            dt = tt_;
+        }
+        auto* d3 = static_cast<unsigned long long*>(ctx->alloc(3 * sizeof(unsigned long long)));
+        launch_confusion(ctx, dp, pred_dtype, dt, truth_dtype, count, d3);
+        unsigned long long h3[3];
+        RFI_CHECK_HIP(hipMemcpyAsync(h3, d3, sizeof(h3), hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        *tp = (int64_t)h3[0]; *fp = (int64_t)h3[1]; *fn = (int64_t)h3[2];
+        ctx->release(d3);
+        if (tp_) ctx->release(tp_);
+        if (tt_) ctx->release(tt_);
+    });
+}
+int rfi_threshold_logits(rfi_ctx* ctx, const float* logits_dev, int64_t count, float threshold,
+                         uint8_t* mask_dev) {
+    return guarded([&] {
+        ctx->activate();
+        launch_threshold(ctx, logits_dev, count, threshold, mask_dev);
+    });
+}
+
+// ------------------------------------------------------------------------------------ kernel-level ops
+namespace {
+struct Scratch {
+    rfi_ctx* c;
+    std::vector<void*> v;
+    explicit Scratch(rfi_ctx* ctx) : c(ctx) {}
+    float* get(size_t floats) {
+        void* p = c->alloc(floats * sizeof(float));
+        v.push_back(p);
+        return static_cast<float*>(p);
+    }
+    ~Scratch() {
+        hipStreamSynchronize(c->stream);
+        for (void* p : v) c->release(p);
+    }
+};
+float* upload_lib_weight(rfi_ctx* ctx, Scratch& s, const float* dev_ref, size_t numel, bool convt,
+                         int d0, int d1, int R) {
+    // dev_ref holds the reference layout ON DEVICE; bounce through the host to convert
+    std::vector<float> h(numel), lib;
+    RFI_CHECK_HIP(hipMemcpyAsync(h.data(), dev_ref, numel * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (convt) to_lib_convt(h.data(), d0, d1, lib);
+    else to_lib_conv(h.data(), d0, d1, R, lib);
+    float* d = s.get(numel);
+    RFI_CHECK_HIP(hipMemcpyAsync(d, lib.data(), numel * 4, hipMemcpyHostToDevice, ctx->stream));
+    RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return d;
+}
+}  // namespace
+
+int rfi_op_conv3x3(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
+                   const float* w_oihw, const float* bias, int cout, const float* in_scale,
+                   const float* in_shift, int in_relu, float* y) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        ConvArgs a;
+        a.x = View{x, cin};
+        a.N = n; a.H = h; a.W = w; a.Hin = h; a.Win = w; a.Cin = cin; a.Cout = cout;
+        a.w = upload_lib_weight(ctx, s, w_oihw, (size_t)9 * cin * cout, false, cout, cin, 3);
+        a.bias = bias;
+        a.y = MutView{y, cout};
+        a.Hout = h; a.Wout = w;
+        a.xf = InXform{in_scale, in_shift, in_relu};
+        launch_conv(ctx, a, impl);
+    });
+}
+int rfi_op_conv3x3_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h, int w, int cout,
+                         const float* w_oihw, int cin, float* dx) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        float* wf = upload_lib_weight(ctx, s, w_oihw, (size_t)9 * cin * cout, false, cout, cin, 3);
+        float* wd = s.get((size_t)9 * cin * cout);
+        launch_weight_to_dgrad(ctx, wf, 9, cout, cin, 1, wd);
+        ConvArgs a;
+        a.x = View{dy, cout};
+        a.N = n; a.H = h; a.W = w; a.Hin = h; a.Win = w; a.Cin = cout; a.Cout = cin;
+        a.w = wd;
+        a.y = MutView{dx, cin};
+        a.Hout = h; a.Wout = w;
+        launch_conv(ctx, a, impl);
+    });
+}
+int rfi_op_conv3x3_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy, int n, int h, int w,
+                         int cin, int cout, const float* in_scale, const float* in_shift, int in_relu,
+                         float* dw_oihw) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        WgradArgs a;
+        a.xop = View{x, cin};
+        a.yop = View{dy, cout};
+        a.xf_x = InXform{in_scale, in_shift, in_relu};
+        a.N = n; a.H = h; a.W = w; a.Hx = h; a.Wx = w; a.Cx = cin; a.Cy = cout;
+        a.tap_stride = (int64_t)cin * cout;
+        a.sy = cin; a.sx = 1;
+        const size_t numel = (size_t)9 * cin * cout;
+        a.dw = s.get(numel);
+        a.slab_floats = wgrad_slab_floats(a, impl);
+        a.slab = s.get(a.slab_floats);
+        launch_wgrad(ctx, a, impl);
+        std::vector<float> lib(numel), ref(numel);
+        RFI_CHECK_HIP(hipMemcpyAsync(lib.data(), a.dw, numel * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        from_lib_conv(lib.data(), cout, cin, 3, ref.data());
+        RFI_CHECK_HIP(hipMemcpyAsync(dw_oihw, ref.data(), numel * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+int rfi_op_convt2x2(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
+                    const float* w_iohw, const float* bias, int cout, float* y) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        ConvArgs a;
+        a.x = View{x, cin};
+        a.N = n; a.H = h; a.W = w; a.Hin = h; a.Win = w; a.Cin = cin; a.Cout = cout;
+        a.w = upload_lib_weight(ctx, s, w_iohw, (size_t)4 * cin * cout, true, cin, cout, 2);
+        a.bias = bias;
+        a.y = MutView{y, cout};
+        a.Hout = 2 * h; a.Wout = 2 * w;
+        a.osy = 2; a.osx = 2;
+        a.R = 1; a.S = 1; a.pad = 0; a.zgroups = 4;
+        launch_conv(ctx, a, impl);
+    });
+}
+int rfi_op_convt2x2_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h, int w, int cout,
+                          const float* w_iohw, int cin, float* dx) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        float* wf = upload_lib_weight(ctx, s, w_iohw, (size_t)4 * cin * cout, true, cin, cout, 2);
+        float* wd = s.get((size_t)4 * cin * cout);
+        launch_weight_to_dgrad(ctx, wf, 4, cout, cin, 0, wd);
+        ConvArgs a;               // (n,h,w) is the INPUT grid of the convT, dy is (n,2h,2w,cout)
+        a.x = View{dy, cout};
+        a.N = n; a.H = h; a.W = w; a.Hin = 2 * h; a.Win = 2 * w; a.Cin = cout; a.Cout = cin;
+        a.w = wd;
+        a.y = MutView{dx, cin};
+        a.Hout = h; a.Wout = w;
+        a.R = 2; a.S = 2; a.pad = 0;
+        launch_conv(ctx, a, impl);
+    });
+}
+int rfi_op_convt2x2_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy, int n, int h, int w,
+                          int cin, int cout, float* dw_iohw) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        WgradArgs a;
+        a.xop = View{dy, cout};
+        a.yop = View{x, cin};
+        a.N = n; a.H = h; a.W = w; a.Hx = 2 * h; a.Wx = 2 * w; a.Cx = cout; a.Cy = cin;
+        a.R = 2; a.S = 2; a.pad = 0;
+        a.tap_stride = (int64_t)cin * cout;
+        a.sy = 1; a.sx = cin;
+        const size_t numel = (size_t)4 * cin * cout;
+        a.dw = s.get(numel);
+        a.slab_floats = wgrad_slab_floats(a, impl);
+        a.slab = s.get(a.slab_floats);
+        launch_wgrad(ctx, a, impl);
+        std::vector<float> lib(numel), ref(numel);
+        RFI_CHECK_HIP(hipMemcpyAsync(lib.data(), a.dw, numel * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        from_lib_convt(lib.data(), cin, cout, ref.data());
+        RFI_CHECK_HIP(hipMemcpyAsync(dw_iohw, ref.data(), numel * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean, float* var_biased) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        float* ws = s.get(bn_stats_ws_floats(c));
+        float* tmp = s.get((size_t)6 * c);
+        std::vector<float> ones((size_t)c, 1.0f), zeros((size_t)c, 0.0f);
+        RFI_CHECK_HIP(hipMemcpyAsync(tmp, ones.data(), c * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFI_CHECK_HIP(hipMemcpyAsync(tmp + c, zeros.data(), c * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        launch_bn_stats(ctx, y, m, c, ws);
+        launch_bn_finalize(ctx, ws, m, c, tmp, tmp + c, nullptr, nullptr, 0, mean, tmp + 2 * c, tmp + 3 * c,
+                           tmp + 4 * c, var_biased);
+    });
+}
+
+}  // extern "C"

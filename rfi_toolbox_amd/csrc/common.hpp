@@ -1,0 +1,136 @@
+// Shared host-side declarations for librfi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rfi_hip.h"
+
+namespace rfi {
+
+// ---------------------------------------------------------------- errors
+void set_last_error(const std::string& msg);
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define RFI_CHECK_HIP(expr)                                                                 \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            throw ::rfi::Error(std::string(#expr) + " failed: " + hipGetErrorString(_e) +   \
+                               " (" __FILE__ ":" + std::to_string(__LINE__) + ")");         \
+    } while (0)
+
+#define RFI_REQUIRE(cond, msg)                                                              \
+    do {                                                                                    \
+        if (!(cond)) throw ::rfi::Error(std::string(msg));                                  \
+    } while (0)
+
+// run `body`, translate exceptions into the C-ABI int + rfi_last_error()
+template <typename F>
+static inline int guarded(F&& body) {
+    try {
+        body();
+        return 0;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return 1;
+    } catch (...) {
+        set_last_error("unknown C++ exception");
+        return 1;
+    }
+}
+
+// ---------------------------------------------------------------- profiling families
+enum Family : int {
+    FAM_CONV_MFMA = 0,    // implicit-GEMM conv fwd / dgrad / convT (MFMA)
+    FAM_WGRAD_MFMA,       // implicit-GEMM weight gradient (MFMA)
+    FAM_CONV_DIRECT,      // VALU direct conv (stem, odd shapes)
+    FAM_BN,               // batch-norm statistics / finalize / backward
+    FAM_ELEMWISE,         // pool, head, loss, relayout, copies
+    FAM_REDUCE,           // partial-slab reductions
+    FAM_OPTIM,            // grad-norm, clip, Adam
+    FAM_PREPROCESS,
+    FAM_METRICS,
+    FAM_COMM,
+    FAM_COUNT
+};
+
+struct FamilyStat {
+    int64_t launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+
+struct PendingEvent {
+    hipEvent_t a, b;
+    int family;
+};
+
+}  // namespace rfi
+
+// ---------------------------------------------------------------- context
+struct rfi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    std::unordered_map<void*, size_t> allocs;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // profiling
+    bool profiling = false;
+    rfi::FamilyStat fam[rfi::FAM_COUNT];
+    std::vector<rfi::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    // pinned scratch for small D2H readbacks
+    float* pinned = nullptr;
+    // RCCL
+    void* nccl_comm = nullptr;
+    int rank = 0, world = 1;
+
+    void* alloc(size_t bytes);
+    void release(void* p);
+    void activate() const;   // hipSetDevice
+    hipEvent_t get_event();
+    void drain_profile();
+};
+
+namespace rfi {
+
+// RAII: brackets one kernel launch with events when profiling is on
+struct ProfScope {
+    rfi_ctx* c;
+    int fam;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(rfi_ctx* ctx, int family, double flops = 0, double bytes = 0) : c(ctx), fam(family) {
+        if (c->profiling) {
+            a = c->get_event();
+            b = c->get_event();
+            hipEventRecord(a, c->stream);
+            c->fam[fam].flops += flops;
+            c->fam[fam].bytes += bytes;
+        }
+    }
+    ~ProfScope() {
+        if (c->profiling) {
+            hipEventRecord(b, c->stream);
+            c->fam[fam].launches += 1;
+            c->pending.push_back({a, b, fam});
+        }
+    }
+};
+
+static inline void check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(std::string("launch of ") + what + " failed: " + hipGetErrorString(e));
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace rfi

@@ -1,0 +1,940 @@
+// HBM-bound kernels of the U-Net step: batch-norm statistics / backward, pool, head, loss,
+// optimiser, layout changes.  gfx950 (wave64).  Reductions over pixels accumulate in fp64 per
+// thread (what torch's CPU BatchNorm does, acc_type<float> == double) and are two-stage
+// (per-block partials + a finishing launch) so every result is bitwise run-to-run reproducible.
+#include "kernels.hpp"
+
+namespace rfi {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// channel-lane geometry shared by the per-channel reductions over a [M][C] tensor:
+// a block = CL channel lanes x RL row lanes (CL*RL == 256), grid = (row blocks, channel blocks)
+struct ChanGeom {
+    int CL, RL, cblocks;
+    int64_t rows_per_block;
+    int rblocks;
+};
+
+static ChanGeom chan_geom(int64_t M, int C, int max_rblocks) {
+    ChanGeom g;
+    int cl = 4;
+    while (cl < C && cl < 64) cl <<= 1;
+    g.CL = cl;
+    g.RL = kBlock / cl;
+    g.cblocks = (int)cdiv(C, cl);
+    int64_t rpb = cdiv(M, max_rblocks);
+    int64_t min_rows = (int64_t)g.RL * 8;
+    if (rpb < min_rows) rpb = min_rows;
+    rpb = cdiv(rpb, g.RL) * g.RL;
+    g.rows_per_block = rpb;
+    g.rblocks = (int)cdiv(M, rpb);
+    return g;
+}
+
+// ------------------------------------------------------------------ batch-norm statistics
+// partial[(rb*C + c)*2 + {0,1}] = sum x, sum x^2 over the block's rows (double)
+__global__ void bn_stats_kernel(const float* __restrict__ y, int64_t M, int C, int CL,
+                                int64_t rows_per_block, double* __restrict__ partial) {
+    __shared__ double red[2 * kBlock];
+    const int RL = kBlock / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = blockIdx.y * CL + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    double s1 = 0, s2 = 0;
+    if (c < C) {
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            double v = (double)y[r * C + c];
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    red[threadIdx.x] = s1;
+    red[kBlock + threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < RL; ++k) {
+            s1 += red[k * CL + cl];
+            s2 += red[kBlock + k * CL + cl];
+        }
+        partial[((int64_t)blockIdx.x * C + c) * 2 + 0] = s1;
+        partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = s2;
+    }
+}
+
+// one block per 8 channels, 32 record lanes
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int records, int C,
+                                   double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, int ema_repeats,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ var_out) {
+    __shared__ double red[2 * kBlock];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double s1 = 0, s2 = 0;
+    if (c < C) {
+        for (int r = rl; r < records; r += 32) {
+            s1 += partial[((int64_t)r * C + c) * 2 + 0];
+            s2 += partial[((int64_t)r * C + c) * 2 + 1];
+        }
+    }
+    red[threadIdx.x] = s1;
+    red[kBlock + threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < 32; ++k) {
+            s1 += red[k * 8 + cl];
+            s2 += red[kBlock + k * 8 + cl];
+        }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0) var = 0;
+        const double invstd = 1.0 / sqrt(var + 1e-5);
+        const float meanf = (float)mean, invf = (float)invstd;
+        mean_out[c] = meanf;
+        invstd_out[c] = invf;
+        if (var_out) var_out[c] = (float)var;
+        const float sc = gamma[c] * invf;
+        scale[c] = sc;
+        shift[c] = beta[c] - meanf * sc;
+        if (running_mean) {
+            const double var_u = count > 1 ? var * (count / (count - 1.0)) : var;
+            float rm = running_mean[c], rv = running_var[c];
+            const float vuf = (float)var_u;
+            for (int k = 0; k < ema_repeats; ++k) {
+                rm = (1.0f - 0.1f) * rm + 0.1f * meanf;
+                rv = (1.0f - 0.1f) * rv + 0.1f * vuf;
+            }
+            running_mean[c] = rm;
+            running_var[c] = rv;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float inv = (float)(1.0 / sqrt((double)rv[c] + 1e-5));
+        float sc = gamma[c] * inv;
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+// ------------------------------------------------------------------ batch-norm backward
+// partial[(rb*C+c)*2 + {0,1}] = sum dz, sum dz*xhat;  dz = da * (y*scale+shift > 0)
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ y,
+                                     int64_t M, int C, int CL, int64_t rows_per_block,
+                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     double* __restrict__ partial) {
+    __shared__ double red[2 * kBlock];
+    const int RL = kBlock / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = blockIdx.y * CL + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    double s1 = 0, s2 = 0;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            const float yv = y[r * C + c];
+            const float dz = (yv * sc + sh > 0.0f) ? da[r * C + c] : 0.0f;
+            const float xh = (yv - mu) * is;
+            s1 += (double)dz;
+            s2 += (double)dz * (double)xh;
+        }
+    }
+    red[threadIdx.x] = s1;
+    red[kBlock + threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < RL; ++k) {
+            s1 += red[k * CL + cl];
+            s2 += red[kBlock + k * CL + cl];
+        }
+        partial[((int64_t)blockIdx.x * C + c) * 2 + 0] = s1;
+        partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = s2;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int records, int C,
+                                       double count, float* c1, float* c2, float* dgamma,
+                                       float* dbeta) {
+    __shared__ double red[2 * kBlock];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double s1 = 0, s2 = 0;
+    if (c < C) {
+        for (int r = rl; r < records; r += 32) {
+            s1 += partial[((int64_t)r * C + c) * 2 + 0];
+            s2 += partial[((int64_t)r * C + c) * 2 + 1];
+        }
+    }
+    red[threadIdx.x] = s1;
+    red[kBlock + threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < 32; ++k) {
+            s1 += red[k * 8 + cl];
+            s2 += red[kBlock + k * 8 + cl];
+        }
+        c1[c] = (float)(s1 / count);
+        c2[c] = (float)(s2 / count);
+        dgamma[c] = (float)s2;
+        dbeta[c] = (float)s1;
+    }
+}
+
+// in place: da <- dy;  partial[rb*C+c] = sum dy (double)
+__global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restrict__ y, int64_t M,
+                                    int C, int CL, int64_t rows_per_block,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ c1,
+                                    const float* __restrict__ c2, double* __restrict__ partial) {
+    __shared__ double red[kBlock];
+    const int RL = kBlock / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = blockIdx.y * CL + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    double s = 0;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        const float g = gamma[c] * is, k1 = c1[c], k2 = c2[c];
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            const float yv = y[r * C + c];
+            const float dz = (yv * sc + sh > 0.0f) ? da[r * C + c] : 0.0f;
+            const float xh = (yv - mu) * is;
+            const float dy = g * (dz - k1 - xh * k2);
+            da[r * C + c] = dy;
+            s += (double)dy;
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < RL; ++k) s += red[k * CL + cl];
+        partial[(int64_t)blockIdx.x * C + c] = s;
+    }
+}
+
+// out[c] = sum_r partial[r*stride + c] for c < count (double -> float)
+__global__ void finish_channel_sum_kernel(const double* __restrict__ partial, int records,
+                                          int64_t stride, int count, float* __restrict__ out) {
+    __shared__ double red[kBlock];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    const int C = count;
+    double s = 0;
+    if (c < C)
+        for (int r = rl; r < records; r += 32) s += partial[(int64_t)r * stride + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < 32; ++k) s += red[k * 8 + cl];
+        out[c] = (float)s;
+    }
+}
+
+__global__ void channel_sum_kernel(const float* __restrict__ v, int pstride, int64_t M, int C, int CL,
+                                   int64_t rows_per_block, double* __restrict__ partial) {
+    __shared__ double red[kBlock];
+    const int RL = kBlock / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = blockIdx.y * CL + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    double s = 0;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r1; r += RL) s += (double)v[r * pstride + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < RL; ++k) s += red[k * CL + cl];
+        partial[(int64_t)blockIdx.x * C + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------ pool
+__global__ void bn_relu_pool_kernel(const float* __restrict__ y, int N, int H, int W, int C,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    float* __restrict__ skip, int skip_ps, float* __restrict__ pooled) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int64_t total = (int64_t)N * Hp * Wp * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int px = (int)(t % Wp);
+        t /= Wp;
+        const int py = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        const float sc = scale[c], sh = shift[c];
+        float best = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t pix = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
+            float a = y[pix * C + c] * sc + sh;
+            a = a > 0.0f ? a : 0.0f;
+            skip[pix * skip_ps + c] = a;
+            best = (k == 0 || a > best) ? a : best;
+        }
+        pooled[i] = best;
+    }
+}
+
+// rows/cols of an odd-sized map that the floor-mode pool does not cover still need their skip
+__global__ void bn_relu_edge_kernel(const float* __restrict__ y, int N, int H, int W, int C,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    float* __restrict__ skip, int skip_ps) {
+    const int64_t total = (int64_t)N * H * W * C;
+    const int He = H & ~1, We = W & ~1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int x = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        if (yy >= He || x >= We) {
+            float a = y[pix * C + c] * scale[c] + shift[c];
+            skip[pix * skip_ps + c] = a > 0.0f ? a : 0.0f;
+        }
+    }
+}
+
+__global__ void pool_bwd_merge_kernel(const float* __restrict__ y, int N, int H, int W, int C,
+                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                      const float* __restrict__ dskip, int dskip_ps,
+                                      const float* __restrict__ dpool, float* __restrict__ da) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int64_t total = (int64_t)N * Hp * Wp * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int px = (int)(t % Wp);
+        t /= Wp;
+        const int py = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        const float sc = scale[c], sh = shift[c];
+        float best = 0.0f;
+        int arg = 0;
+        int64_t pixk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pixk[k] = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
+            float a = y[pixk[k] * C + c] * sc + sh;
+            a = a > 0.0f ? a : 0.0f;
+            if (k == 0 || a > best) {
+                best = a;
+                arg = k;
+            }
+        }
+        const float g = dpool[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            da[pixk[k] * C + c] = dskip[pixk[k] * dskip_ps + c] + (k == arg ? g : 0.0f);
+    }
+}
+
+__global__ void copy_edge_kernel(int N, int H, int W, int C, const float* __restrict__ dskip,
+                                 int dskip_ps, float* __restrict__ da) {
+    const int64_t total = (int64_t)N * H * W * C;
+    const int He = H & ~1, We = W & ~1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int x = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        if (yy >= He || x >= We) da[pix * C + c] = dskip[pix * dskip_ps + c];
+    }
+}
+
+// ------------------------------------------------------------------ head (1x1 conv) + loss
+__global__ void head_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
+                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                const float* __restrict__ w, const float* __restrict__ b, int Cout,
+                                float* __restrict__ logits) {
+    // one wave-quarter (16 lanes) per pixel: lanes stride over channels, shuffle-reduce
+    const int lane16 = threadIdx.x & 15;
+    const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (m >= M) return;   // whole 16-lane group leaves together
+    for (int o = 0; o < Cout; ++o) {
+        float acc = 0.0f;
+        for (int c = lane16; c < C; c += 16) {
+            float a = y[m * C + c] * scale[c] + shift[c];
+            a = a > 0.0f ? a : 0.0f;
+            acc += a * w[o * C + c];
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 16);
+        if (lane16 == 0) logits[m * Cout + o] = acc + b[o];
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void loss_reduce_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                                   int64_t count, double* __restrict__ partial) {
+    __shared__ double red[4][kBlock / 64];
+    double s[4] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = logits[i];
+        const float t = labels[i] ? 1.0f : 0.0f;
+        const float bce = fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x)));
+        const float p = sigmoidf_(x);
+        s[0] += (double)bce;
+        s[1] += (double)(p * t);
+        s[2] += (double)p;
+        s[3] += (double)t;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double v = wave_sum(s[k]);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double v = 0;
+        for (int wv = 0; wv < kBlock / 64; ++wv) v += red[threadIdx.x][wv];
+        partial[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
+    }
+}
+
+__global__ void loss_finish_kernel(const double* __restrict__ partial, int blocks, double count,
+                                   double* __restrict__ sums4, float* __restrict__ loss_out) {
+    __shared__ double red[4][kBlock / 64];
+    double s[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < blocks; b += blockDim.x)
+        for (int k = 0; k < 4; ++k) s[k] += partial[(int64_t)b * 4 + k];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double v = wave_sum(s[k]);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4];
+        for (int k = 0; k < 4; ++k) {
+            t[k] = 0;
+            for (int wv = 0; wv < kBlock / 64; ++wv) t[k] += red[k][wv];
+            sums4[k] = t[k];
+        }
+        // float32 arithmetic for the final combination, as the reference's fp32 tensors do
+        const float bce = (float)(t[0] / count);
+        const float inter = (float)t[1], sp = (float)t[2], st = (float)t[3];
+        const float dice = 1.0f - (2.0f * inter + 1.0f) / (sp + st + 1.0f);
+        loss_out[0] = bce + dice;
+    }
+}
+
+__global__ void loss_bwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                                int64_t count, const double* __restrict__ sums4,
+                                float* __restrict__ dlogits) {
+    const float inter = (float)sums4[1], sp = (float)sums4[2], st = (float)sums4[3];
+    const float D = sp + st + 1.0f;
+    const float num = 2.0f * inter + 1.0f;
+    const float invD2 = 1.0f / (D * D);
+    const float invN = (float)(1.0 / (double)count);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = logits[i];
+        const float t = labels[i] ? 1.0f : 0.0f;
+        const float p = sigmoidf_(x);
+        // d dice / d p_i = -(2 t D - num) / D^2
+        const float ddice = -(2.0f * t * D - num) * invD2;
+        dlogits[i] = (p - t) * invN + ddice * p * (1.0f - p);
+    }
+}
+
+// da[m][c] = sum_o dl[m][o] * w[o][c];  partial dw/db per block (double)
+__global__ void head_bwd_kernel(const float* __restrict__ y, int64_t M, int C, int CL,
+                                int64_t rows_per_block, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const float* __restrict__ w, int Cout,
+                                const float* __restrict__ dl, float* __restrict__ da,
+                                double* __restrict__ partial) {
+    // partial layout per row block: [Cout][C] dw then [Cout] db  (stride Cout*C + Cout)
+    __shared__ double red[kBlock];
+    const int RL = kBlock / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = blockIdx.y * CL + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const int64_t pstride = (int64_t)Cout * C + Cout;
+    for (int o = 0; o < Cout; ++o) {
+        double sw = 0, sb = 0;
+        if (c < C) {
+            const float sc = scale[c], sh = shift[c], wv = w[o * C + c];
+            for (int64_t r = r0 + rl; r < r1; r += RL) {
+                const float d = dl[r * Cout + o];
+                float a = y[r * C + c] * sc + sh;
+                a = a > 0.0f ? a : 0.0f;
+                sw += (double)d * (double)a;
+                sb += (double)d;
+                if (o == 0) da[r * C + c] = d * wv;
+                else da[r * C + c] += d * wv;
+            }
+        }
+        red[threadIdx.x] = sw;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            for (int k = 1; k < RL; ++k) sw += red[k * CL + cl];
+            partial[(int64_t)blockIdx.x * pstride + (int64_t)o * C + c] = sw;
+        }
+        __syncthreads();
+        if (blockIdx.y == 0 && cl == 0) {   // db: channel lane 0 of the first channel block
+            red[rl] = sb;
+        }
+        __syncthreads();
+        if (blockIdx.y == 0 && threadIdx.x == 0) {
+            double t = 0;
+            for (int k = 0; k < RL; ++k) t += red[k];
+            partial[(int64_t)blockIdx.x * pstride + (int64_t)Cout * C + o] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ layouts
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int N, int C, int H, int W,
+                                    float* __restrict__ dst) {
+    const int64_t total = (int64_t)N * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int x = (int)(t % W);
+        t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        dst[i] = src[(((int64_t)n * C + c) * H + yy) * W + x];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int N, int C, int H, int W,
+                                    float* __restrict__ dst) {
+    const int64_t total = (int64_t)N * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        int64_t t = i / W;
+        const int yy = (int)(t % H);
+        t /= H;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        dst[i] = src[(((int64_t)n * H + yy) * W + x) * C + c];
+    }
+}
+__global__ void weight_to_dgrad_kernel(const float* __restrict__ wf, int taps, int Cout, int Cin,
+                                       int flip, float* __restrict__ wd) {
+    const int64_t total = (int64_t)taps * Cout * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        int64_t t = i / Cout;
+        const int ci = (int)(t % Cin);
+        const int tp = (int)(t / Cin);
+        const int ts = flip ? (taps - 1 - tp) : tp;
+        wd[i] = wf[((int64_t)ts * Cout + co) * Cin + ci];
+    }
+}
+__global__ void u8_to_f32_kernel(const uint8_t* __restrict__ s, int64_t n, float* __restrict__ d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = (float)s[i];
+}
+
+// ------------------------------------------------------------------ optimiser
+__global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+    __shared__ double red[kBlock / 64];
+    double s = 0;
+    const int64_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = g[(n4 << 2) + threadIdx.x];
+        s += (double)v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < kBlock / 64; ++k) t += red[k];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ void sumsq_finish_kernel(const double* __restrict__ partial, int blocks,
+                                    double* __restrict__ out) {
+    __shared__ double red[kBlock / 64];
+    double s = 0;
+    for (int b = threadIdx.x; b < blocks; b += blockDim.x) s += partial[b];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < kBlock / 64; ++k) t += red[k];
+        out[0] = t;
+    }
+}
+
+__global__ void adam_kernel(AdamArgs a) {
+    const float norm = (float)sqrt(a.sumsq[0]) * a.grad_scale;
+    float coef = a.max_norm / (norm + 1e-6f);
+    coef = coef > 1.0f ? 1.0f : coef;
+    if (a.max_norm <= 0.0f) coef = 1.0f;   // clipping disabled
+    const float gs = a.grad_scale;
+    const float step = a.lr / a.bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = a.p[i];
+        float g = (a.g[i] * gs) * coef;
+        g = g + a.wd * p;
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        a.p[i] = p - step * (m / denom);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) a.norm_out[0] = norm;
+}
+
+// out[i] = sum_{k<count} slabs[(base + k*kstride) * n + i]; grid.y selects the group:
+// base = blockIdx.y * group, out row = blockIdx.y * out_rowstride (in units of n)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, int group, int kstride,
+                                    int64_t n, float* __restrict__ out, int64_t out_rowstride) {
+    const int base = blockIdx.y * group;
+    int cnt = nslabs - base;
+    if (cnt > group) cnt = group;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int k = 0; k < cnt; ++k) s += slabs[((int64_t)base + (int64_t)k) * kstride * n + i];
+        out[(int64_t)blockIdx.y * out_rowstride * n + i] = s;
+    }
+}
+
+static int grid_for(int64_t total, int cap = 256 * 16) {
+    int64_t b = cdiv(total, kBlock);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+constexpr int kMaxRowBlocks = 1024;
+
+}  // namespace
+
+// ====================================================================== launch wrappers
+size_t bn_stats_ws_floats(int C) { return (size_t)kMaxRowBlocks * C * 2 * 2; }
+
+// records actually used for (M, C)
+static ChanGeom geom_rows(int64_t M, int C) { return chan_geom(M, C, kMaxRowBlocks); }
+
+void launch_bn_stats(rfi_ctx* ctx, const float* y, int64_t M, int C, float* partial_ws) {
+    ChanGeom g = geom_rows(M, C);
+    ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 4);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y, M,
+                       C, g.CL, g.rows_per_block, reinterpret_cast<double*>(partial_ws));
+    check_launch("bn_stats");
+}
+
+void launch_bn_finalize(rfi_ctx* ctx, const float* partial, int64_t M, int C, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var,
+                          int ema_repeats, float* mean, float* invstd, float* scale, float* shift,
+                          float* var_out) {
+    ChanGeom g = geom_rows(M, C);
+    ProfScope ps(ctx, FAM_BN);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<const double*>(partial), g.rblocks, C, (double)M, gamma, beta,
+                       running_mean, running_var, ema_repeats, mean, invstd, scale, shift, var_out);
+    check_launch("bn_finalize");
+}
+
+void launch_bn_eval_coeffs(rfi_ctx* ctx, int C, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, float* scale,
+                           float* shift) {
+    ProfScope ps(ctx, FAM_BN);
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((int)cdiv(C, 256)), dim3(256), 0, ctx->stream, C,
+                       gamma, beta, running_mean, running_var, scale, shift);
+    check_launch("bn_eval_coeffs");
+}
+
+size_t bn_bwd_ws_floats(int64_t M, int C) {
+    (void)M;
+    return (size_t)kMaxRowBlocks * C * 2 * 2;   // doubles counted as 2 floats
+}
+
+void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t M, int C,
+                          const float* scale, const float* shift, const float* mean,
+                          const float* invstd, float* partial_ws, float* c1, float* c2,
+                          float* dgamma, float* dbeta) {
+    ChanGeom g = geom_rows(M, C);
+    {
+        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 8);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
+                           ctx->stream, da, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
+                           reinterpret_cast<double*>(partial_ws));
+        check_launch("bn_bwd_reduce");
+    }
+    {
+        ProfScope ps(ctx, FAM_BN);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, ctx->stream,
+                           reinterpret_cast<const double*>(partial_ws), g.rblocks, C, (double)M, c1, c2,
+                           dgamma, dbeta);
+        check_launch("bn_bwd_finalize");
+    }
+}
+
+void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t M, int C,
+                         const float* scale, const float* shift, const float* mean,
+                         const float* invstd, const float* gamma, const float* c1, const float* c2,
+                         float* partial_ws, float* dbias) {
+    ChanGeom g = geom_rows(M, C);
+    {
+        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 12);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
+                           da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
+                           c1, c2, reinterpret_cast<double*>(partial_ws));
+        check_launch("bn_bwd_apply");
+    }
+    if (dbias) {
+        ProfScope ps(ctx, FAM_BN);
+        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0,
+                           ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, dbias);
+        check_launch("finish_channel_sum");
+    }
+}
+
+size_t channel_sum_ws_floats(int64_t M, int C) {
+    (void)M;
+    return (size_t)kMaxRowBlocks * C * 2;
+}
+void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out) {
+    ChanGeom g = geom_rows(M, C);
+    {
+        ProfScope ps(ctx, FAM_REDUCE, 0, (double)M * C * 4);
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
+                           v.p, v.pstride, M, C, g.CL, g.rows_per_block,
+                           reinterpret_cast<double*>(partial_ws));
+        check_launch("channel_sum");
+    }
+    {
+        ProfScope ps(ctx, FAM_REDUCE);
+        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0,
+                           ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, out);
+        check_launch("finish_channel_sum");
+    }
+}
+
+void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
+                         const float* scale, const float* shift, MutView skip, float* pooled) {
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    {
+        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 8 + (double)total * 4);
+        hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
+                           N, H, W, C, scale, shift, skip.p, skip.pstride, pooled);
+        check_launch("bn_relu_pool");
+    }
+    if ((H & 1) || (W & 1)) {
+        ProfScope ps(ctx, FAM_ELEMWISE);
+        hipLaunchKernelGGL(bn_relu_edge_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(kBlock), 0,
+                           ctx->stream, y, N, H, W, C, scale, shift, skip.p, skip.pstride);
+        check_launch("bn_relu_edge");
+    }
+}
+
+void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
+                           const float* scale, const float* shift, View dskip, const float* dpool,
+                           float* da) {
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    {
+        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 12 + (double)total * 4);
+        hipLaunchKernelGGL(pool_bwd_merge_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
+                           N, H, W, C, scale, shift, dskip.p, dskip.pstride, dpool, da);
+        check_launch("pool_bwd_merge");
+    }
+    if ((H & 1) || (W & 1)) {
+        ProfScope ps(ctx, FAM_ELEMWISE);
+        hipLaunchKernelGGL(copy_edge_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(kBlock), 0,
+                           ctx->stream, N, H, W, C, dskip.p, dskip.pstride, da);
+        check_launch("copy_edge");
+    }
+}
+
+void launch_head_fwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
+                     const float* shift, const float* w, const float* b, int Cout, float* logits) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 2.0 * M * C * Cout, (double)M * C * 4 + (double)M * Cout * 4);
+    const int64_t threads = M * 16;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)cdiv(threads, kBlock)), dim3(kBlock), 0,
+                       ctx->stream, y, M, C, scale, shift, w, b, Cout, logits);
+    check_launch("head_fwd");
+}
+
+size_t loss_ws_doubles(int64_t count) {
+    (void)count;
+    return 4 * 1024 + 8;
+}
+void launch_loss_reduce(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count,
+                        double* partial_ws, double* sums4, float* loss_out) {
+    int blocks = grid_for(count, 1024);
+    {
+        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)count * 5);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, logits, labels,
+                           count, partial_ws);
+        check_launch("loss_reduce");
+    }
+    {
+        ProfScope ps(ctx, FAM_ELEMWISE);
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, partial_ws, blocks,
+                           (double)count, sums4, loss_out);
+        check_launch("loss_finish");
+    }
+}
+void launch_loss_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count,
+                     const double* sums4, float* dlogits) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)count * 9);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, logits,
+                       labels, count, sums4, dlogits);
+    check_launch("loss_bwd");
+}
+
+size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
+    (void)M;
+    return (size_t)kMaxRowBlocks * ((size_t)Cout * C + Cout) * 2;
+}
+void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
+                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
+                     float* partial_ws, float* dw, float* db) {
+    ChanGeom g = geom_rows(M, C);
+    {
+        ProfScope ps(ctx, FAM_ELEMWISE, 4.0 * M * C * Cout, (double)M * C * 8);
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
+                           M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
+                           reinterpret_cast<double*>(partial_ws));
+        check_launch("head_bwd");
+    }
+    {
+        // dw (Cout*C values) followed by db (Cout values) are contiguous in each partial record
+        const int n = Cout * C + Cout;
+        ProfScope ps(ctx, FAM_REDUCE);
+        // dw and db are adjacent in the flat gradient buffer only by construction of the caller;
+        // finish into dw[0..Cout*C) and db[0..Cout) separately
+        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(Cout * C, 8)), dim3(kBlock), 0,
+                           ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)n, Cout * C, dw);
+        check_launch("head_bwd_finish_dw");
+    }
+    {
+        const int n = Cout * C + Cout;
+        ProfScope ps(ctx, FAM_REDUCE);
+        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(Cout, 8)), dim3(kBlock), 0,
+                           ctx->stream, reinterpret_cast<const double*>(partial_ws) + (size_t)Cout * C,
+                           g.rblocks, (int64_t)n, Cout, db);
+        check_launch("head_bwd_finish_db");
+    }
+}
+
+void launch_nchw_to_nhwc(rfi_ctx* ctx, const float* src, int N, int C, int H, int W, float* dst) {
+    const int64_t total = (int64_t)N * C * H * W;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * 8);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, src, N,
+                       C, H, W, dst);
+    check_launch("nchw_to_nhwc");
+}
+void launch_nhwc_to_nchw(rfi_ctx* ctx, const float* src, int N, int C, int H, int W, float* dst) {
+    const int64_t total = (int64_t)N * C * H * W;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * 8);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, src, N,
+                       C, H, W, dst);
+    check_launch("nhwc_to_nchw");
+}
+void launch_weight_to_dgrad(rfi_ctx* ctx, const float* wf, int taps, int Cout, int Cin, int flip,
+                            float* wd) {
+    const int64_t total = (int64_t)taps * Cout * Cin;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * 8);
+    hipLaunchKernelGGL(weight_to_dgrad_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, wf,
+                       taps, Cout, Cin, flip, wd);
+    check_launch("weight_to_dgrad");
+}
+void launch_u8_to_f32(rfi_ctx* ctx, const uint8_t* src, int64_t n, float* dst) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * 5);
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, src, n, dst);
+    check_launch("u8_to_f32");
+}
+
+size_t sumsq_ws_doubles(int64_t n) {
+    (void)n;
+    return 1024 + 8;
+}
+void launch_sumsq(rfi_ctx* ctx, const float* g, int64_t n, double* partial_ws, double* sumsq) {
+    int blocks = grid_for(n / 4 + 1, 1024);
+    {
+        ProfScope ps(ctx, FAM_OPTIM, 0, (double)n * 4);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, g, n, partial_ws);
+        check_launch("sumsq");
+    }
+    {
+        ProfScope ps(ctx, FAM_OPTIM);
+        hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, partial_ws, blocks,
+                           sumsq);
+        check_launch("sumsq_finish");
+    }
+}
+void launch_adam(rfi_ctx* ctx, const AdamArgs& a) {
+    ProfScope ps(ctx, FAM_OPTIM, 0, (double)a.n * 28);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(a.n)), dim3(kBlock), 0, ctx->stream, a);
+    check_launch("adam");
+}
+
+void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n, float* out) {
+    // fold groups of 32 slabs in place (each group's sum lands in the group's first slab) until
+    // at most 32 partial slabs remain, then sum those into `out`.  Fixed order -> reproducible.
+    float* s = const_cast<float*>(slabs);
+    int count = nslabs;      // live partial slabs, `stride` slabs apart
+    int stride = 1;
+    while (count > 32) {
+        const int groups = (int)cdiv(count, 32);
+        ProfScope ps(ctx, FAM_REDUCE, 0, (double)n * 4 * (count + groups));
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n, 1024), groups), dim3(kBlock), 0,
+                           ctx->stream, s, count, 32, stride, n, s, (int64_t)32 * stride);
+        check_launch("reduce_slabs_fold");
+        // group g wrote slab index g*32*stride; element i of it is only touched by the thread
+        // that summed element i of that group, so the in-place fold is race free
+        count = groups;
+        stride *= 32;
+    }
+    ProfScope ps(ctx, FAM_REDUCE, 0, (double)n * 4 * (count + 1));
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n, 1024), 1), dim3(kBlock), 0, ctx->stream, s,
+                       count, 32, stride, n, out, (int64_t)0);
+    check_launch("reduce_slabs");
+}
+
+}  // namespace rfi

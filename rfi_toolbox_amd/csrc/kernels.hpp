@@ -1,0 +1,167 @@
+// Launch wrappers of every HIP kernel in librfi_hip.so.  All pointers are device pointers,
+// all launches go to ctx->stream, nothing here synchronises.
+#pragma once
+#include "common.hpp"
+
+namespace rfi {
+
+// Optional per-channel transform applied when a kernel LOADS an activation:
+//   v = v * scale[c] + shift[c];  if (relu) v = max(v, 0)     (scale == nullptr -> identity)
+// This is how BatchNorm-apply + ReLU of the producing layer is folded into its consumers.
+struct InXform {
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    int relu = 0;
+};
+
+// A [N,H,W,C] activation view: `pstride` floats between consecutive pixels (>= C; a
+// channel slice of a wider concat buffer is a view with pstride = total channels).
+struct View {
+    const float* p = nullptr;
+    int pstride = 0;
+};
+struct MutView {
+    float* p = nullptr;
+    int pstride = 0;
+};
+
+// ---------------------------------------------------------------- generic "conv-like" contraction
+//   y[n, oy, ox, co] (+)= bias[co] + sum_{tap=(r,s), ci} X[n, oy*S + r - pad, ox*S + s - pad, ci] * Wf[tap][co][ci]
+// out-of-range input pixels read as zero (after the load transform).
+// R x R taps, input stride S.  Cases used:
+//   conv3x3 fwd   R=3 S=1 pad=1            Wf = forward layout  [tap][cout][cin]
+//   conv3x3 dgrad R=3 S=1 pad=1            Wf = dgrad layout    [tap'][cin][cout] (taps flipped)
+//   convT   fwd   R=1 S=1 pad=0, 4 launches-in-one (grid z = (a,b)); output scattered to (2y+a, 2x+b)
+//   convT   dgrad R=2 S=2 pad=0            Wf = dgrad layout    [tap][cin][cout]
+struct ConvArgs {
+    View x;
+    int N = 0, H = 0, W = 0;          // output grid ("m" space)
+    int Hin = 0, Win = 0;             // input spatial size
+    int Cin = 0, Cout = 0;
+    const float* w = nullptr;         // [taps][Cout][Cin]
+    const float* bias = nullptr;      // [Cout] or null
+    MutView y;
+    int Hout = 0, Wout = 0;           // spatial size of the tensor y points into
+    int osy = 1, osx = 1;             // output pixel = (oy*osy + ooy, ox*osx + oox)
+    int ooy = 0, oox = 0;
+    int R = 3, S = 1, pad = 1;
+    int zgroups = 1;                  // convT fwd: 4 (a,b) groups: w += z*Cout*Cin, (ooy,oox) = (z/2, z%2)
+    InXform xf;
+};
+
+enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2 };
+
+bool conv_mfma_eligible(const ConvArgs& a);
+void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl = IMPL_AUTO);
+
+// ---------------------------------------------------------------- weight gradient
+//   dW[tap][cy][cx] = sum_{n,y,x} Yop[n,y,x,cy] * Xop[n, y*S + r - pad, x*S + s - pad, cx]
+// written at dw[tap*tap_stride + cy*sy + cx*sx].
+//   conv3x3 wgrad: Xop = layer input (cx = cin), Yop = dY (cy = cout), out [tap][cout][cin]: sy=Cin, sx=1
+//   convT   wgrad: Xop = dUp (cx = cout, R=2,S=2), Yop = layer input (cy = cin), out [tap][cout][cin]: sy=1, sx=Cin
+struct WgradArgs {
+    View xop, yop;
+    InXform xf_x, xf_y;
+    int N = 0, H = 0, W = 0;          // grid of the Yop pixels
+    int Hx = 0, Wx = 0;               // spatial size of Xop
+    int Cx = 0, Cy = 0;
+    int R = 3, S = 1, pad = 1;
+    float* dw = nullptr;
+    int64_t tap_stride = 0;
+    int sy = 0, sx = 0;
+    float* slab = nullptr;            // workspace for split partials
+    size_t slab_floats = 0;
+};
+size_t wgrad_slab_floats(const WgradArgs& a, int impl);
+void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);
+
+// ---------------------------------------------------------------- batch norm
+// two-stage statistics of a [M][C] tensor: launch_bn_stats writes fp64 (sum, sumsq) partials
+// into partial_ws (bn_stats_ws_floats(C) floats); launch_bn_finalize merges them -> mean,
+// biased var, invstd, and scale/shift for the consumers' load transform, and updates the
+// running stats `ema_repeats` times (momentum 0.1, unbiased var) when running_mean != null.
+size_t bn_stats_ws_floats(int C);
+void launch_bn_stats(rfi_ctx* ctx, const float* y, int64_t M, int C, float* partial_ws);
+void launch_bn_finalize(rfi_ctx* ctx, const float* partial_ws, int64_t M, int C, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var,
+                        int ema_repeats, float* mean, float* invstd, float* scale, float* shift,
+                        float* var_out);
+// eval mode: scale/shift from running statistics
+void launch_bn_eval_coeffs(rfi_ctx* ctx, int C, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, float* scale,
+                           float* shift);
+// backward, pass 1: per-channel sum(dz), sum(dz * xhat) with dz = da * (act > 0)
+//   -> c1 = mean(dz), c2 = mean(dz*xhat), dgamma, dbeta   (two launches: partial + finalize)
+void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t M, int C,
+                          const float* scale, const float* shift, const float* mean,
+                          const float* invstd, float* partial_ws, float* c1, float* c2,
+                          float* dgamma, float* dbeta);
+size_t bn_bwd_ws_floats(int64_t M, int C);
+// backward, pass 2 (in place on da): dy = gamma*invstd * (dz - c1 - xhat*c2); also per-channel
+// sum(dy) -> dbias_conv (partials in ws, finished by the same launch pair)
+void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t M, int C,
+                         const float* scale, const float* shift, const float* mean,
+                         const float* invstd, const float* gamma, const float* c1, const float* c2,
+                         float* partial_ws, float* dbias);
+
+// ---------------------------------------------------------------- pool / head / loss
+// a = relu(y*scale+shift) -> skip view (full res) and 2x2 max-pooled p
+void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
+                         const float* scale, const float* shift, MutView skip, float* pooled);
+// da[n,y,x,c] = dskip[n,y,x,c] + (argmax of the 2x2 window of a == (y,x) ? dpool : 0)
+void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
+                           const float* scale, const float* shift, View dskip, const float* dpool,
+                           float* da);
+// logits[m,o] = b[o] + sum_c relu(y*scale+shift)[m,c] * w[o][c]
+void launch_head_fwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
+                     const float* shift, const float* w, const float* b, int Cout, float* logits);
+// loss sums over all logits: [0]=sum bce, [1]=sum sig*y, [2]=sum sig, [3]=sum y  (double)
+void launch_loss_reduce(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count,
+                        double* partial_ws, double* sums4, float* loss_out);
+size_t loss_ws_doubles(int64_t count);
+// dlogits from logits + the 4 sums (BCE mean + dice), in place into dlogits
+void launch_loss_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count,
+                     const double* sums4, float* dlogits);
+// head backward: da[m,c] = sum_o dlogits[m,o]*w[o][c] (NOT yet relu-masked: bn_bwd does that);
+// dw[o][c] = sum_m dlogits[m,o]*act[m,c]; db[o] = sum_m dlogits[m,o]
+void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
+                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
+                     float* partial_ws, float* dw, float* db);
+size_t head_bwd_ws_floats(int64_t M, int C, int Cout);
+// per-channel sum over pixels of a view (convT bias grad)
+void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out);
+size_t channel_sum_ws_floats(int64_t M, int C);
+
+// ---------------------------------------------------------------- layouts
+void launch_nchw_to_nhwc(rfi_ctx* ctx, const float* src, int N, int C, int H, int W, float* dst);
+void launch_nhwc_to_nchw(rfi_ctx* ctx, const float* src, int N, int C, int H, int W, float* dst);
+// forward layout [tap][co][ci] -> dgrad layout [tap'][ci][co]; flip: tap' = taps-1-tap
+void launch_weight_to_dgrad(rfi_ctx* ctx, const float* wf, int taps, int Cout, int Cin, int flip,
+                            float* wd);
+void launch_u8_to_f32(rfi_ctx* ctx, const uint8_t* src, int64_t n, float* dst);
+
+// ---------------------------------------------------------------- optimiser
+// sum of squares of g[0..n) -> *sumsq (double), deterministic two-stage
+void launch_sumsq(rfi_ctx* ctx, const float* g, int64_t n, double* partial_ws, double* sumsq);
+size_t sumsq_ws_doubles(int64_t n);
+struct AdamArgs {
+    float* p; float* g; float* m; float* v; int64_t n;
+    float lr, beta1, beta2, eps, wd, max_norm, grad_scale;
+    float bc1, bc2_sqrt;            // 1-beta1^t, sqrt(1-beta2^t)
+    const double* sumsq;            // device scalar: ||g||^2 BEFORE grad_scale
+    float* norm_out;                // device scalar out: ||g*grad_scale||
+};
+void launch_adam(rfi_ctx* ctx, const AdamArgs& a);
+
+// ---------------------------------------------------------------- preprocessing / metrics
+void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int ph, int pw,
+                       float* minmax_ws, float* out_nhwc);
+void launch_confusion(rfi_ctx* ctx, const void* pred, int pred_dtype, const void* truth,
+                      int truth_dtype, int64_t count, unsigned long long* counts3);
+void launch_threshold(rfi_ctx* ctx, const float* logits, int64_t count, float threshold,
+                      uint8_t* mask);
+
+// generic: out[i] = sum_s slabs[s*n + i]
+void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n, float* out);
+
+}  // namespace rfi

@@ -1,0 +1,517 @@
+// U-Net graph (rfi_toolbox/models/unet.py:41-118) and the optimisation step
+// (rfi_toolbox/scripts/train_model.py:139-154) orchestrated over the HIP kernels.
+//
+// Data layout in HBM
+//   activations  NHWC fp32.  Per 3x3 conv only the RAW conv output Y (pre-BatchNorm) is kept;
+//                consumers apply scale/shift/ReLU when they load it (InXform), so the activated
+//                tensor is never written except where two consumers need it materialised:
+//                the encoder output goes once, activated, into channels [C,2C) of the decoder's
+//                concat buffer (the skip) and, pooled, into the next level's input.  ConvTranspose
+//                writes channels [0,C) of the same concat buffer: torch.cat never happens.
+//   parameters   one flat fp32 buffer (+ identical flat grad / Adam m / Adam v buffers) in forward
+//                layer order, every tensor 16-byte aligned: conv weights [tap][cout][cin],
+//                convT weights [a*2+b][cout][cin]; a second "dgrad layout" copy [tap'][cin][cout]
+//                is rebuilt after each optimiser step.
+//   Encoder blocks are evaluated ONCE; the reference evaluates them twice (unet.py:28), which
+//   only shows in the BatchNorm running statistics (EMA applied twice, num_batches_tracked += 2).
+#include "model.hpp"
+
+#include <cmath>
+#include <random>
+
+using namespace rfi;
+
+namespace rfi {
+
+void DevBuf::ensure(rfi_ctx* c, size_t floats) {
+    if (floats <= n && p) return;
+    if (p) c->release(p);
+    ctx = c;
+    p = static_cast<float*>(c->alloc(floats * sizeof(float)));
+    n = floats;
+}
+void DevBuf::free() {
+    if (p && ctx) ctx->release(p);
+    p = nullptr;
+    n = 0;
+}
+
+}  // namespace rfi
+
+static size_t align4(size_t v) { return (v + 3) & ~size_t(3); }
+
+rfi_model::~rfi_model() {
+    if (!ctx) return;
+    ctx->activate();
+    for (auto& b : bufs) b.free();
+    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool})
+        if (p) ctx->release(p);
+    if (d_sums) ctx->release(d_sums);
+    if (d_scalars) ctx->release(d_scalars);
+}
+
+// ------------------------------------------------------------------------------------ build
+void rfi_model::build() {
+    RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
+    RFI_REQUIRE(depth >= 1 && depth <= 6, "UNet: depth must be in [1,6]");
+    const int D = depth;
+    convs.clear();
+    ups.clear();
+    size_t off = 0, chan_floats = 0, wd_floats = 0;
+    auto add_conv = [&](const std::string& prefix, int conv_idx, int bn_idx, int cin, int cout, int ema) {
+        ConvBN c;
+        c.conv_name = prefix + "." + std::to_string(conv_idx);
+        c.bn_name = prefix + "." + std::to_string(bn_idx);
+        c.cin = cin;
+        c.cout = cout;
+        c.ema_repeats = ema;
+        c.w_off = off; off = align4(off + (size_t)9 * cin * cout);
+        c.b_off = off; off = align4(off + cout);
+        c.g_off = off; off = align4(off + cout);
+        c.be_off = off; off = align4(off + cout);
+        chan_floats += align4((size_t)8 * cout);
+        wd_floats += align4((size_t)9 * cin * cout);
+        convs.push_back(c);
+    };
+    int cin = in_ch;
+    for (int l = 1; l <= D; ++l) {
+        const int cout = feat << (l - 1);
+        const std::string p = "encoder" + std::to_string(l) + ".conv.conv";
+        add_conv(p, 0, 1, cin, cout, 2);
+        add_conv(p, 3, 4, cout, cout, 2);
+        cin = cout;
+    }
+    add_conv("bottleneck.conv", 0, 1, cin, cin * 2, 1);
+    add_conv("bottleneck.conv", 3, 4, cin * 2, cin * 2, 1);
+    cin *= 2;
+    // decoder parameters come in forward order: up, conv1, conv2 per level; to keep `convs`
+    // contiguous the up-convs get their offsets here and the convs right after
+    for (int l = D; l >= 1; --l) {
+        const int cout = feat << (l - 1);
+        UpConv u;
+        u.name = "decoder" + std::to_string(l) + ".up";
+        u.cin = cin;
+        u.cout = cout;
+        u.w_off = off; off = align4(off + (size_t)4 * cin * cout);
+        u.b_off = off; off = align4(off + cout);
+        wd_floats += align4((size_t)4 * cin * cout);
+        ups.push_back(u);
+        const std::string p = "decoder" + std::to_string(l) + ".conv.conv";
+        add_conv(p, 0, 1, cin, cout, 1);
+        add_conv(p, 3, 4, cout, cout, 1);
+        cin = cout;
+    }
+    head_w_off = off; off = align4(off + (size_t)out_ch * feat);
+    head_b_off = off; off = align4(off + out_ch);
+    n_flat = off;
+
+    // ---- state_dict entry table in the reference's order
+    entries.clear();
+    entry_index.clear();
+    n_params = 0;
+    auto push = [&](Entry e) {
+        entry_index[e.name] = (int)entries.size();
+        if (e.kind == 0 || e.kind == 1 || e.kind == 2 || e.kind == 6) n_params += e.numel();
+        entries.push_back(e);
+    };
+    auto push_conv_entries = [&](int ci) {
+        const ConvBN& c = convs[ci];
+        Entry e;
+        e.layer = ci;
+        e.name = c.conv_name + ".weight"; e.ndim = 4; e.dims[0] = c.cout; e.dims[1] = c.cin; e.dims[2] = 3; e.dims[3] = 3; e.kind = 0; push(e);
+        e = Entry(); e.layer = ci;
+        e.name = c.conv_name + ".bias"; e.ndim = 1; e.dims[0] = c.cout; e.kind = 2; e.which = 0; push(e);
+        e.name = c.bn_name + ".weight"; e.which = 1; push(e);
+        e.name = c.bn_name + ".bias"; e.which = 2; push(e);
+        e.name = c.bn_name + ".running_mean"; e.kind = 3; push(e);
+        e.name = c.bn_name + ".running_var"; e.kind = 4; push(e);
+        e.name = c.bn_name + ".num_batches_tracked"; e.kind = 5; e.ndim = 0; e.dims[0] = 0; push(e);
+    };
+    for (int l = 1; l <= D; ++l) {
+        push_conv_entries(2 * (l - 1));
+        push_conv_entries(2 * (l - 1) + 1);
+    }
+    push_conv_entries(2 * D);
+    push_conv_entries(2 * D + 1);
+    for (int l = D; l >= 1; --l) {
+        const int k = D - l;
+        const UpConv& u = ups[k];
+        Entry e;
+        e.layer = k;
+        e.name = u.name + ".weight"; e.ndim = 4; e.dims[0] = u.cin; e.dims[1] = u.cout; e.dims[2] = 2; e.dims[3] = 2; e.kind = 1; push(e);
+        e = Entry(); e.layer = k;
+        e.name = u.name + ".bias"; e.ndim = 1; e.dims[0] = u.cout; e.kind = 2; e.which = 3; push(e);
+        push_conv_entries(2 * D + 2 + 2 * k);
+        push_conv_entries(2 * D + 2 + 2 * k + 1);
+    }
+    {
+        Entry e;
+        e.name = "final_conv.weight"; e.ndim = 4; e.dims[0] = out_ch; e.dims[1] = feat; e.dims[2] = 1; e.dims[3] = 1; e.kind = 6; push(e);
+        e = Entry();
+        e.name = "final_conv.bias"; e.ndim = 1; e.dims[0] = out_ch; e.kind = 2; e.which = 4; push(e);
+    }
+
+    // ---- device state
+    ctx->activate();
+    const size_t bytes = n_flat * sizeof(float);
+    params = static_cast<float*>(ctx->alloc(bytes));
+    grads = static_cast<float*>(ctx->alloc(bytes));
+    adam_m = static_cast<float*>(ctx->alloc(bytes));
+    adam_v = static_cast<float*>(ctx->alloc(bytes));
+    chan_pool = static_cast<float*>(ctx->alloc(chan_floats * sizeof(float)));
+    wd_pool = static_cast<float*>(ctx->alloc(wd_floats * sizeof(float)));
+    d_sums = static_cast<double*>(ctx->alloc(8 * sizeof(double)));
+    d_scalars = static_cast<float*>(ctx->alloc(8 * sizeof(float)));
+    for (float* p : {params, grads, adam_m, adam_v}) RFI_CHECK_HIP(hipMemsetAsync(p, 0, bytes, ctx->stream));
+    RFI_CHECK_HIP(hipMemsetAsync(chan_pool, 0, chan_floats * sizeof(float), ctx->stream));
+    RFI_CHECK_HIP(hipMemsetAsync(d_sums, 0, 8 * sizeof(double), ctx->stream));
+    RFI_CHECK_HIP(hipMemsetAsync(d_scalars, 0, 8 * sizeof(float), ctx->stream));
+    size_t co = 0, wo = 0;
+    size_t conv_i = 0;
+    // wd_pool sub-allocation must follow the same order as the sizing above
+    for (int l = 1; l <= 2 * D + 2; ++l) {   // encoder + bottleneck convs
+        ConvBN& c = convs[conv_i++];
+        c.chan = chan_pool + co; co += align4((size_t)8 * c.cout);
+        c.wd = wd_pool + wo; wo += align4((size_t)9 * c.cin * c.cout);
+    }
+    for (int k = 0; k < D; ++k) {
+        ups[k].wd = wd_pool + wo; wo += align4((size_t)4 * ups[k].cin * ups[k].cout);
+        for (int j = 0; j < 2; ++j) {
+            ConvBN& c = convs[conv_i++];
+            c.chan = chan_pool + co; co += align4((size_t)8 * c.cout);
+            c.wd = wd_pool + wo; wo += align4((size_t)9 * c.cin * c.cout);
+        }
+    }
+    adam_step = 0;
+    wd_dirty = true;
+}
+
+// ------------------------------------------------------------------------------------ prepare
+void rfi_model::prepare(int n, int h, int w) {
+    RFI_REQUIRE(n > 0 && h > 0 && w > 0, "forward: empty batch or image");
+    const int div = 1 << depth;
+    RFI_REQUIRE(h % div == 0 && w % div == 0,
+                "forward: H and W must be multiples of 2^depth (" + std::to_string(div) +
+                    "), as the reference's pool/up-conv/cat chain requires; got " +
+                    std::to_string(h) + "x" + std::to_string(w));
+    if (n == pN && h == pH && w == pW && !bufs.empty()) return;
+    ctx->activate();
+    const int D = depth;
+    if (bufs.empty()) {
+        auto mk = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) v[l] = new_buf(); };
+        mk(encY1); mk(encY2); mk(concat); mk(pool); mk(decY1); mk(decY2);
+        mk(gA); mk(gB); mk(dconcat); mk(dpool);
+        bottY1 = new_buf(); bottY2 = new_buf(); gBottA = new_buf(); gBottB = new_buf();
+        logits = new_buf(); dlogits = new_buf();
+        x_stage = new_buf(); x_stage2 = new_buf(); out_stage = new_buf();
+        ws_red = new_buf(); ws_slab = new_buf(); lab_stage = new_buf();
+    }
+    size_t slab_need = 0, red_need = 0;
+    auto upd_red = [&](size_t f) { if (f > red_need) red_need = f; };
+    for (int l = 1; l <= D; ++l) {
+        const size_t M = (size_t)n * (h >> (l - 1)) * (w >> (l - 1));
+        const size_t C = (size_t)feat << (l - 1);
+        for (int i : {encY1[l], encY2[l], decY1[l], decY2[l], gA[l], gB[l]}) bufs[i].ensure(ctx, M * C);
+        bufs[concat[l]].ensure(ctx, M * 2 * C);
+        bufs[dconcat[l]].ensure(ctx, M * 2 * C);
+        bufs[pool[l]].ensure(ctx, M / 4 * C);
+        bufs[dpool[l]].ensure(ctx, M / 4 * C);
+    }
+    {
+        const size_t M = (size_t)n * (h >> D) * (w >> D);
+        const size_t C = (size_t)feat << D;
+        for (int i : {bottY1, bottY2, gBottA, gBottB}) bufs[i].ensure(ctx, M * C);
+    }
+    const size_t M1 = (size_t)n * h * w;
+    bufs[logits].ensure(ctx, M1 * out_ch);
+    bufs[dlogits].ensure(ctx, M1 * out_ch);
+    bufs[x_stage].ensure(ctx, M1 * in_ch);
+    bufs[x_stage2].ensure(ctx, M1 * in_ch);
+    bufs[out_stage].ensure(ctx, M1 * out_ch);
+    bufs[lab_stage].ensure(ctx, (M1 + 3) / 4 + 4);
+    // workspaces
+    size_t cmax = (size_t)feat << depth;
+    upd_red(bn_stats_ws_floats((int)cmax));
+    upd_red(bn_bwd_ws_floats(M1, (int)cmax));
+    upd_red(head_bwd_ws_floats(M1, feat, out_ch));
+    upd_red(channel_sum_ws_floats(M1, (int)cmax));
+    upd_red(loss_ws_doubles(M1) * 2);
+    upd_red(sumsq_ws_doubles(n_flat) * 2);
+    bufs[ws_red].ensure(ctx, red_need + 16);
+    // wgrad slabs: the largest need over all layers
+    auto conv_geom = [&](int ci, int& H, int& W) {
+        // spatial size of conv ci's output
+        int lvl;
+        if (ci < 2 * D) lvl = ci / 2 + 1;
+        else if (ci < 2 * D + 2) lvl = D + 1;
+        else lvl = D - (ci - (2 * D + 2)) / 2;
+        H = h >> (lvl - 1);
+        W = w >> (lvl - 1);
+    };
+    for (size_t ci = 0; ci < convs.size(); ++ci) {
+        int H, W;
+        conv_geom((int)ci, H, W);
+        WgradArgs a;
+        a.N = n; a.H = H; a.W = W; a.Hx = H; a.Wx = W;
+        a.Cx = convs[ci].cin; a.Cy = convs[ci].cout;
+        a.xop.pstride = a.Cx; a.yop.pstride = a.Cy;
+        a.R = 3; a.S = 1; a.pad = 1;
+        a.tap_stride = (int64_t)a.Cx * a.Cy;
+        slab_need = std::max(slab_need, wgrad_slab_floats(a, IMPL_AUTO));
+    }
+    for (int k = 0; k < D; ++k) {
+        const int l = D - k;                       // decoder level; input at level l+1 resolution
+        WgradArgs a;
+        a.N = n; a.H = h >> l; a.W = w >> l; a.Hx = a.H * 2; a.Wx = a.W * 2;
+        a.Cx = ups[k].cout; a.Cy = ups[k].cin;
+        a.xop.pstride = 2 * ups[k].cout; a.yop.pstride = a.Cy;
+        a.R = 2; a.S = 2; a.pad = 0;
+        a.tap_stride = (int64_t)a.Cx * a.Cy;
+        slab_need = std::max(slab_need, wgrad_slab_floats(a, IMPL_AUTO));
+    }
+    bufs[ws_slab].ensure(ctx, slab_need + 16);
+    pN = n; pH = h; pW = w;
+}
+
+void rfi_model::refresh_dgrad_weights() {
+    if (!wd_dirty) return;
+    for (auto& c : convs) launch_weight_to_dgrad(ctx, params + c.w_off, 9, c.cout, c.cin, 1, c.wd);
+    for (auto& u : ups) launch_weight_to_dgrad(ctx, params + u.w_off, 4, u.cout, u.cin, 0, u.wd);
+    wd_dirty = false;
+}
+
+// ------------------------------------------------------------------------------------ forward
+namespace {
+
+struct Shape { int N, H, W; };
+
+void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y, bool train) {
+    ConvArgs a;
+    a.x = in;
+    a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
+    a.Cin = c.cin; a.Cout = c.cout;
+    a.w = m->params + c.w_off;
+    a.bias = m->params + c.b_off;
+    a.y = MutView{Y, c.cout};
+    a.Hout = s.H; a.Wout = s.W;
+    a.R = 3; a.S = 1; a.pad = 1;
+    a.xf = xf;
+    launch_conv(m->ctx, a);
+    const int64_t M = (int64_t)s.N * s.H * s.W;
+    if (train) {
+        float* ws = m->buf(m->ws_red);
+        launch_bn_stats(m->ctx, Y, M, c.cout, ws);
+        launch_bn_finalize(m->ctx, ws, M, c.cout, m->params + c.g_off, m->params + c.be_off,
+                           c.running_mean(), c.running_var(), c.ema_repeats, c.mean(), c.invstd(),
+                           c.scale(), c.shift(), nullptr);
+        c.nbt += c.ema_repeats;
+    } else {
+        launch_bn_eval_coeffs(m->ctx, c.cout, m->params + c.g_off, m->params + c.be_off, c.running_mean(),
+                              c.running_var(), c.scale(), c.shift());
+    }
+}
+
+InXform bn_xf(const ConvBN& c) { return InXform{c.scale(), c.shift(), 1}; }
+
+}  // namespace
+
+void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode) {
+    prepare(n, h, w);
+    const int D = depth;
+    View cur{x_dev, in_ch};
+    for (int l = 1; l <= D; ++l) {
+        Shape s{n, h >> (l - 1), w >> (l - 1)};
+        ConvBN& c1 = convs[2 * (l - 1)];
+        ConvBN& c2 = convs[2 * (l - 1) + 1];
+        run_conv_bn(this, c1, cur, InXform{}, s, buf(encY1[l]), train_mode);
+        run_conv_bn(this, c2, View{buf(encY1[l]), c1.cout}, bn_xf(c1), s, buf(encY2[l]), train_mode);
+        launch_bn_relu_pool(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
+                            MutView{buf(concat[l]) + c2.cout, 2 * c2.cout}, buf(pool[l]));
+        cur = View{buf(pool[l]), c2.cout};
+    }
+    {
+        Shape s{n, h >> D, w >> D};
+        ConvBN& c1 = convs[2 * D];
+        ConvBN& c2 = convs[2 * D + 1];
+        run_conv_bn(this, c1, cur, InXform{}, s, buf(bottY1), train_mode);
+        run_conv_bn(this, c2, View{buf(bottY1), c1.cout}, bn_xf(c1), s, buf(bottY2), train_mode);
+    }
+    const float* prevY = buf(bottY2);
+    ConvBN* prevBN = &convs[2 * D + 1];
+    for (int l = D; l >= 1; --l) {
+        const int k = D - l;
+        UpConv& u = ups[k];
+        Shape sin{n, h >> l, w >> l};
+        Shape s{n, h >> (l - 1), w >> (l - 1)};
+        ConvArgs a;
+        a.x = View{prevY, u.cin};
+        a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = sin.H; a.Win = sin.W;
+        a.Cin = u.cin; a.Cout = u.cout;
+        a.w = params + u.w_off;
+        a.bias = params + u.b_off;
+        a.y = MutView{buf(concat[l]), 2 * u.cout};
+        a.Hout = s.H; a.Wout = s.W;
+        a.osy = 2; a.osx = 2;
+        a.R = 1; a.S = 1; a.pad = 0;
+        a.zgroups = 4;
+        a.xf = bn_xf(*prevBN);
+        launch_conv(ctx, a);
+        ConvBN& c1 = convs[2 * D + 2 + 2 * k];
+        ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
+        run_conv_bn(this, c1, View{buf(concat[l]), 2 * u.cout}, InXform{}, s, buf(decY1[l]), train_mode);
+        run_conv_bn(this, c2, View{buf(decY1[l]), c1.cout}, bn_xf(c1), s, buf(decY2[l]), train_mode);
+        prevY = buf(decY2[l]);
+        prevBN = &c2;
+    }
+    const int64_t M1 = (int64_t)n * h * w;
+    launch_head_fwd(ctx, prevY, M1, feat, prevBN->scale(), prevBN->shift(), params + head_w_off,
+                    params + head_b_off, out_ch, buf(logits));
+}
+
+void rfi_model::loss_forward(const uint8_t* labels_dev, int n, int h, int w) {
+    RFI_REQUIRE(out_ch == 1, "loss: the reference's BCE+dice step is defined for out_channels == 1");
+    const int64_t cnt = (int64_t)n * h * w;
+    launch_loss_reduce(ctx, buf(logits), labels_dev, cnt, reinterpret_cast<double*>(buf(ws_red)), d_sums,
+                       d_scalars);
+}
+
+// ------------------------------------------------------------------------------------ backward
+namespace {
+
+// given dA (grad w.r.t. the ACTIVATED output of conv c, overwritten with dY), produce dW/db/dgamma/
+// dbeta into the grad buffer and, if dx != null, the gradient w.r.t. the conv's (activated) input
+void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in, InXform in_xf,
+                      Shape s, float* dx, int dx_pstride_unused) {
+    (void)dx_pstride_unused;
+    rfi_ctx* ctx = m->ctx;
+    const int64_t M = (int64_t)s.N * s.H * s.W;
+    float* ws = m->buf(m->ws_red);
+    launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(),
+                         c.c2(), m->grads + c.g_off, m->grads + c.be_off);
+    launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
+                        m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off);
+    WgradArgs wa;
+    wa.xop = in;
+    wa.yop = View{dA, c.cout};
+    wa.xf_x = in_xf;
+    wa.N = s.N; wa.H = s.H; wa.W = s.W; wa.Hx = s.H; wa.Wx = s.W;
+    wa.Cx = c.cin; wa.Cy = c.cout;
+    wa.R = 3; wa.S = 1; wa.pad = 1;
+    wa.dw = m->grads + c.w_off;
+    wa.tap_stride = (int64_t)c.cin * c.cout;
+    wa.sy = c.cin; wa.sx = 1;
+    wa.slab = m->buf(m->ws_slab);
+    wa.slab_floats = m->bufs[m->ws_slab].n;
+    launch_wgrad(ctx, wa);
+    if (dx) {
+        ConvArgs a;
+        a.x = View{dA, c.cout};
+        a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
+        a.Cin = c.cout; a.Cout = c.cin;
+        a.w = c.wd;
+        a.bias = nullptr;
+        a.y = MutView{dx, c.cin};
+        a.Hout = s.H; a.Wout = s.W;
+        a.R = 3; a.S = 1; a.pad = 1;
+        launch_conv(ctx, a);
+    }
+}
+
+}  // namespace
+
+void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
+    const int D = depth;
+    const int64_t M1 = (int64_t)n * h * w;
+    refresh_dgrad_weights();
+    // loss -> dlogits -> head
+    launch_loss_bwd(ctx, buf(logits), labels_dev, M1, d_sums, buf(dlogits));
+    {
+        ConvBN& last = convs[2 * D + 2 + 2 * (D - 1) + 1];
+        launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off,
+                        out_ch, buf(dlogits), buf(gA[1]), buf(ws_red), grads + head_w_off,
+                        grads + head_b_off);
+    }
+    // decoders, shallow to deep
+    for (int l = 1; l <= D; ++l) {
+        const int k = D - l;
+        Shape s{n, h >> (l - 1), w >> (l - 1)};
+        Shape sin{n, h >> l, w >> l};
+        ConvBN& c1 = convs[2 * D + 2 + 2 * k];
+        ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
+        UpConv& u = ups[k];
+        // conv2: input = act(decY1) ; conv1: input = concat (materialised)
+        backward_conv_bn(this, c2, buf(gA[l]), buf(decY2[l]), View{buf(decY1[l]), c1.cout}, bn_xf(c1), s,
+                         buf(gB[l]), 0);
+        backward_conv_bn(this, c1, buf(gB[l]), buf(decY1[l]), View{buf(concat[l]), 2 * u.cout}, InXform{}, s,
+                         buf(dconcat[l]), 0);
+        // up-conv: dUp = dconcat[..., 0:C]
+        const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
+        ConvBN& prevBN = (l == D) ? convs[2 * D + 1] : convs[2 * D + 2 + 2 * (k - 1) + 1];
+        View dUp{buf(dconcat[l]), 2 * u.cout};
+        launch_channel_sum(ctx, dUp, (int64_t)s.N * s.H * s.W, u.cout, buf(ws_red), grads + u.b_off);
+        WgradArgs wa;
+        wa.xop = dUp;
+        wa.yop = View{prevY, u.cin};
+        wa.xf_y = bn_xf(prevBN);
+        wa.N = sin.N; wa.H = sin.H; wa.W = sin.W; wa.Hx = s.H; wa.Wx = s.W;
+        wa.Cx = u.cout; wa.Cy = u.cin;
+        wa.R = 2; wa.S = 2; wa.pad = 0;
+        wa.dw = grads + u.w_off;
+        wa.tap_stride = (int64_t)u.cin * u.cout;
+        wa.sy = 1; wa.sx = u.cin;          // -> [tap][cout][cin]
+        wa.slab = buf(ws_slab);
+        wa.slab_floats = bufs[ws_slab].n;
+        launch_wgrad(ctx, wa);
+        ConvArgs a;
+        a.x = dUp;
+        a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = s.H; a.Win = s.W;
+        a.Cin = u.cout; a.Cout = u.cin;
+        a.w = u.wd;
+        a.bias = nullptr;
+        float* dprev = (l == D) ? buf(gBottA) : buf(gA[l + 1]);
+        a.y = MutView{dprev, u.cin};
+        a.Hout = sin.H; a.Wout = sin.W;
+        a.R = 2; a.S = 2; a.pad = 0;
+        launch_conv(ctx, a);
+    }
+    // bottleneck
+    {
+        Shape s{n, h >> D, w >> D};
+        ConvBN& c1 = convs[2 * D];
+        ConvBN& c2 = convs[2 * D + 1];
+        backward_conv_bn(this, c2, buf(gBottA), buf(bottY2), View{buf(bottY1), c1.cout}, bn_xf(c1), s,
+                         buf(gBottB), 0);
+        backward_conv_bn(this, c1, buf(gBottB), buf(bottY1), View{buf(pool[D]), c1.cin}, InXform{}, s,
+                         buf(dpool[D]), 0);
+    }
+    // encoders, deep to shallow
+    for (int l = D; l >= 1; --l) {
+        Shape s{n, h >> (l - 1), w >> (l - 1)};
+        ConvBN& c1 = convs[2 * (l - 1)];
+        ConvBN& c2 = convs[2 * (l - 1) + 1];
+        launch_pool_bwd_merge(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
+                              View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]));
+        backward_conv_bn(this, c2, buf(gA[l]), buf(encY2[l]), View{buf(encY1[l]), c1.cout}, bn_xf(c1), s,
+                         buf(gB[l]), 0);
+        View in = (l == 1) ? View{x_dev, in_ch} : View{buf(pool[l - 1]), c1.cin};
+        backward_conv_bn(this, c1, buf(gB[l]), buf(encY1[l]), in, InXform{}, s,
+                         (l == 1) ? nullptr : buf(dpool[l - 1]), 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------ optimiser
+void rfi_model::apply(const rfi_hyper& hp, float grad_scale) {
+    double* ws = reinterpret_cast<double*>(buf(ws_red));
+    launch_sumsq(ctx, grads, (int64_t)n_flat, ws, d_sums + 4);
+    adam_step += 1;
+    AdamArgs a;
+    a.p = params; a.g = grads; a.m = adam_m; a.v = adam_v; a.n = (int64_t)n_flat;
+    a.lr = hp.lr; a.beta1 = hp.beta1; a.beta2 = hp.beta2; a.eps = hp.eps; a.wd = hp.weight_decay;
+    a.max_norm = hp.max_grad_norm; a.grad_scale = grad_scale;
+    a.bc1 = (float)(1.0 - std::pow((double)hp.beta1, (double)adam_step));
+    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)hp.beta2, (double)adam_step));
+    a.sumsq = d_sums + 4;
+    a.norm_out = d_scalars + 1;
+    launch_adam(ctx, a);
+    wd_dirty = true;
+}

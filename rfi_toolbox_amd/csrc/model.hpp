@@ -1,0 +1,101 @@
+// U-Net graph of rfi_toolbox/models/unet.py on top of the HIP kernels (host orchestration).
+#pragma once
+#include "kernels.hpp"
+
+namespace rfi {
+
+struct DevBuf {
+    rfi_ctx* ctx = nullptr;
+    float* p = nullptr;
+    size_t n = 0;
+    void ensure(rfi_ctx* c, size_t floats);
+    void free();
+};
+
+// Conv3x3(pad 1)+bias -> BatchNorm2d -> ReLU
+struct ConvBN {
+    std::string conv_name, bn_name;     // e.g. "encoder1.conv.conv.0", "encoder1.conv.conv.1"
+    int cin = 0, cout = 0;
+    size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;   // offsets into the flat param/grad buffers
+    int ema_repeats = 1;
+    int64_t nbt = 0;                    // num_batches_tracked (host side)
+    // device per-channel state: [running_mean | running_var | mean | invstd | scale | shift | c1 | c2]
+    float* chan = nullptr;
+    float* running_mean() const { return chan; }
+    float* running_var() const { return chan + cout; }
+    float* mean() const { return chan + 2 * cout; }
+    float* invstd() const { return chan + 3 * cout; }
+    float* scale() const { return chan + 4 * cout; }
+    float* shift() const { return chan + 5 * cout; }
+    float* c1() const { return chan + 6 * cout; }
+    float* c2() const { return chan + 7 * cout; }
+    float* wd = nullptr;                // dgrad-layout copy of the weight [9][cin][cout]
+};
+
+// ConvTranspose2d(k2,s2)+bias
+struct UpConv {
+    std::string name;                   // "decoder4.up"
+    int cin = 0, cout = 0;
+    size_t w_off = 0, b_off = 0;        // forward layout [4][cout][cin]
+    float* wd = nullptr;                // dgrad layout [4][cin][cout]
+};
+
+struct Entry {
+    std::string name;
+    int ndim = 0;
+    int64_t dims[4] = {0, 0, 0, 0};
+    int kind = 0;        // 0 conv weight (OIHW), 1 convT weight (IOHW), 2 vector param, 3 running_mean,
+                         // 4 running_var, 5 num_batches_tracked, 6 final weight
+    int layer = -1;      // index into convs / ups; -1 for the head
+    int which = 0;       // vector param: 0 conv bias, 1 bn gamma, 2 bn beta, 3 up bias, 4 head bias
+    int64_t numel() const {
+        int64_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= dims[i];
+        return n;
+    }
+};
+
+}  // namespace rfi
+
+struct rfi_model {
+    rfi_ctx* ctx = nullptr;
+    int in_ch = 0, out_ch = 0, feat = 0, depth = 0;
+    bool training = true;
+
+    std::vector<rfi::ConvBN> convs;   // enc1.c1, enc1.c2, ..., encD.c2, bott.c1, bott.c2, decD.c1, decD.c2, ..., dec1.c2
+    std::vector<rfi::UpConv> ups;     // decD.up ... dec1.up   (index 0 = deepest)
+    size_t head_w_off = 0, head_b_off = 0;
+    std::vector<rfi::Entry> entries;
+    std::unordered_map<std::string, int> entry_index;
+
+    size_t n_flat = 0;                // floats in each flat buffer (padded)
+    int64_t n_params = 0;             // true scalar parameter count
+    float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    float* chan_pool = nullptr;
+    float* wd_pool = nullptr;
+    int64_t adam_step = 0;
+    bool wd_dirty = true;
+
+    // activations / workspaces for the prepared shape
+    int pN = 0, pH = 0, pW = 0;
+    std::vector<rfi::DevBuf> bufs;
+    // indices into bufs
+    std::vector<int> encY1, encY2, concat, pool, decY1, decY2, gA, gB, dconcat, dpool;
+    int bottY1 = -1, bottY2 = -1, gBottA = -1, gBottB = -1, logits = -1, dlogits = -1;
+    int x_stage = -1, x_stage2 = -1, out_stage = -1, ws_red = -1, ws_slab = -1, lab_stage = -1;
+    double* d_sums = nullptr;         // [0..3] loss sums, [4] grad sumsq
+    float* d_scalars = nullptr;       // [0] loss, [1] grad norm
+    float last_loss = 0, last_norm = 0;
+
+    void build();
+    void prepare(int n, int h, int w);
+    float* buf(int i) { return bufs[i].p; }
+    int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
+
+    void refresh_dgrad_weights();
+    void forward(const float* x_dev, int n, int h, int w, bool train_mode);
+    void loss_forward(const uint8_t* labels_dev, int n, int h, int w);
+    void backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w);
+    void apply(const rfi_hyper& hp, float grad_scale);
+    ~rfi_model();
+};

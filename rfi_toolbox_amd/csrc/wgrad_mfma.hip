@@ -1,0 +1,321 @@
+// Weight gradient of the conv-like contraction on the gfx950 matrix cores (fp32 MFMA 32x32x2).
+//
+//   dW[tap][cy][cx] = sum_{n,y,x} T(Yop)[n,y,x,cy] * T(Xop)[n, y*S+r-pad, x*S+s-pad, cx]
+//
+// GEMM view: the reduction runs over PIXELS (K = N*H*W, up to 10^6) and the output is tiny
+// (taps*Cy*Cx), so the work is split over pixels: a workgroup is persistent over a strided set of
+// TH x TW spatial tiles, keeps its taps x 32 x 32 accumulators in registers for its whole life and
+// writes ONE partial slab at the end; a second launch sums the slabs in fixed order (bitwise
+// reproducible, no float atomics).  Per tile the Yop tile and the Xop HALO tile are staged through
+// registers into LDS as [pixel][channel] rows; MFMA operands are ds_read_b32 (lane = channel,
+// k = pixel), so one A read feeds all taps.  Waves of a workgroup split either the (cy,cx) 32x32
+// blocks of a BY x BX channel tile or, when that tile is a single block, the tile's pixels.
+#include "kernels.hpp"
+
+namespace rfi {
+
+void launch_wgrad_direct(rfi_ctx* ctx, const WgradArgs& a);
+size_t wgrad_direct_slab_floats(const WgradArgs& a);
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int R, int S, int BY, int BX, int TH, int TW>
+struct WCfg {
+    static constexpr int BM = TH * TW;
+    static constexpr int HH = TH * S + R - S;
+    static constexpr int HW = TW * S + R - S;
+    static constexpr int HP = HH * HW;
+    static constexpr int NTAP = R * R;
+    static constexpr int BYP = BY + 4, BXP = BX + 4;
+    static constexpr int BLOCKS = (BY / 32) * (BX / 32);   // 32x32 channel blocks per workgroup
+    static constexpr int WP = 4 / BLOCKS;                   // waves splitting the tile's pixels
+    static constexpr int KSTEPS = BM / 2 / WP;              // k-steps (2 pixels each) per wave per tile
+    static constexpr int Y_ITEMS = (BM * (BY / 4) + 255) / 256;
+    static constexpr int X_ITEMS = (HP * (BX / 4) + 255) / 256;
+    static constexpr int LDS_FLOATS = BM * BYP + HP * BXP + 2 * BY + 2 * BX;
+    static_assert(BLOCKS == 1 || BLOCKS == 2 || BLOCKS == 4, "1, 2 or 4 channel blocks");
+    static_assert((BM / 2) % WP == 0, "pixels must split evenly over waves");
+};
+
+struct WgradDev {
+    WgradArgs a;
+    int nsplit;          // workgroups along the pixel split
+    int64_t slab_stride; // floats per slab
+};
+
+template <int R, int S, int BY, int BX, int TH, int TW>
+__global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
+    using C = WCfg<R, S, BY, BX, TH, TW>;
+    const WgradArgs& a = d.a;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_y = smem;
+    float* s_x = s_y + C::BM * C::BYP;
+    float* s_cy = s_x + C::HP * C::BXP;      // [scale BY][shift BY]
+    float* s_cx = s_cy + 2 * BY;             // [scale BX][shift BX]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int blk = wave % C::BLOCKS, ps = wave / C::BLOCKS;
+    const int by = blk / (BX / 32), bx = blk % (BX / 32);
+    const int cy0 = blockIdx.y * BY, cx0 = blockIdx.z * BX;
+    const int split = blockIdx.x;
+
+    // per-channel load transforms of this workgroup's channel tiles -> LDS (identity if absent)
+    for (int i = tid; i < BY; i += 256) {
+        const bool ok = a.xf_y.scale && (cy0 + i) < a.Cy;
+        s_cy[i] = ok ? a.xf_y.scale[cy0 + i] : 1.0f;
+        s_cy[BY + i] = ok ? a.xf_y.shift[cy0 + i] : 0.0f;
+    }
+    for (int i = tid; i < BX; i += 256) {
+        const bool ok = a.xf_x.scale && (cx0 + i) < a.Cx;
+        s_cx[i] = ok ? a.xf_x.scale[cx0 + i] : 1.0f;
+        s_cx[BX + i] = ok ? a.xf_x.shift[cx0 + i] : 0.0f;
+    }
+
+    // per-thread staging descriptors (tile-independent parts)
+    int y_pix[C::Y_ITEMS], y_q[C::Y_ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::Y_ITEMS; ++it) {
+        const int idx = tid + it * 256;
+        y_pix[it] = idx / (BY / 4);
+        y_q[it] = idx % (BY / 4);
+        if (idx >= C::BM * (BY / 4)) y_pix[it] = -1;
+    }
+    int x_pix[C::X_ITEMS], x_q[C::X_ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::X_ITEMS; ++it) {
+        const int idx = tid + it * 256;
+        x_pix[it] = idx / (BX / 4);
+        x_q[it] = idx % (BX / 4);
+        if (idx >= C::HP * (BX / 4)) x_pix[it] = -1;
+    }
+
+    f32x4 yreg[C::Y_ITEMS], xreg[C::X_ITEMS];
+    unsigned yvalid = 0, xvalid = 0;
+
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int ntiles = a.N * tiles_y * tiles_x;
+
+    auto load_tile = [&](int tile) {
+        const int tx_i = tile % tiles_x;
+        const int ty_i = (tile / tiles_x) % tiles_y;
+        const int n = tile / (tiles_x * tiles_y);
+        const int oy0 = ty_i * TH, ox0 = tx_i * TW;
+        yvalid = 0;
+        xvalid = 0;
+#pragma unroll
+        for (int it = 0; it < C::Y_ITEMS; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y_pix[it] >= 0) {
+                const int oy = oy0 + y_pix[it] / TW, ox = ox0 + y_pix[it] % TW;
+                const int c = cy0 + y_q[it] * 4;
+                if (oy < a.H && ox < a.W && c < a.Cy) {
+                    v = *reinterpret_cast<const f32x4*>(
+                        a.yop.p + (((long)n * a.H + oy) * a.W + ox) * a.yop.pstride + c);
+                    yvalid |= 1u << it;
+                }
+            }
+            yreg[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < C::X_ITEMS; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (x_pix[it] >= 0) {
+                const int iy = oy0 * S - a.pad + x_pix[it] / C::HW, ix = ox0 * S - a.pad + x_pix[it] % C::HW;
+                const int c = cx0 + x_q[it] * 4;
+                if (iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < a.Cx) {
+                    v = *reinterpret_cast<const f32x4*>(
+                        a.xop.p + (((long)n * a.Hx + iy) * a.Wx + ix) * a.xop.pstride + c);
+                    xvalid |= 1u << it;
+                }
+            }
+            xreg[it] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::Y_ITEMS; ++it) {
+            if (y_pix[it] < 0) continue;
+            f32x4 v = yreg[it];
+            if (a.xf_y.scale && (yvalid >> it & 1u)) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(s_cy + y_q[it] * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(s_cy + BY + y_q[it] * 4);
+                v = v * sc + sh;
+                if (a.xf_y.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            *reinterpret_cast<f32x4*>(s_y + y_pix[it] * C::BYP + y_q[it] * 4) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < C::X_ITEMS; ++it) {
+            if (x_pix[it] < 0) continue;
+            f32x4 v = xreg[it];
+            if (a.xf_x.scale && (xvalid >> it & 1u)) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(s_cx + x_q[it] * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(s_cx + BX + x_q[it] * 4);
+                v = v * sc + sh;
+                if (a.xf_x.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            *reinterpret_cast<f32x4*>(s_x + x_pix[it] * C::BXP + x_q[it] * 4) = v;
+        }
+    };
+
+    f32x16 acc[C::NTAP];
+#pragma unroll
+    for (int t = 0; t < C::NTAP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    __syncthreads();                       // s_cy / s_cx visible
+    int tile = split;
+    if (tile < ntiles) {
+        load_tile(tile);
+        store_tile();
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += d.nsplit) {
+        const int next = tile + d.nsplit;
+        if (next < ntiles) load_tile(next);
+        // ---- MFMA over this wave's share of the tile's pixels
+        const int a_col = by * 32 + li, b_col = bx * 32 + li;
+#pragma unroll 4
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            const int p = (ps * C::KSTEPS + ks) * 2 + lh;          // pixel within the tile
+            const int ty = p / TW, tx = p % TW;
+            const float av = s_y[p * C::BYP + a_col];
+            const float* xb = s_x + ((ty * S) * C::HW + tx * S) * C::BXP + b_col;
+#pragma unroll
+            for (int tap = 0; tap < C::NTAP; ++tap) {
+                const float bv = xb[((tap / R) * C::HW + (tap % R)) * C::BXP];
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (next < ntiles) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- write this wave's partial: rows (reg) = cy, cols (lane&31) = cx
+    float* slab = a.slab + (size_t)(split * C::WP + ps) * d.slab_stride;
+    const int cx = cx0 + bx * 32 + li;
+#pragma unroll
+    for (int tap = 0; tap < C::NTAP; ++tap) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cy = cy0 + by * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (cy < a.Cy && cx < a.Cx)
+                slab[(int64_t)tap * a.tap_stride + (int64_t)cy * a.sy + (int64_t)cx * a.sx] = acc[tap][r];
+        }
+    }
+}
+
+struct Plan {
+    int nsplit, wp;
+    int64_t slab_stride;
+};
+
+template <int R, int S, int BY, int BX, int TH, int TW>
+Plan plan_cfg(const WgradArgs& a, int cus) {
+    using C = WCfg<R, S, BY, BX, TH, TW>;
+    const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
+    const int chunks = (int)cdiv(a.Cy, BY) * (int)cdiv(a.Cx, BX);
+    int nsplit = (int)cdiv((int64_t)cus * 2, chunks);      // ~2 workgroups per CU in total
+    if (nsplit > ntiles) nsplit = ntiles;
+    if (nsplit < 1) nsplit = 1;
+    Plan p;
+    p.nsplit = nsplit;
+    p.wp = C::WP;
+    p.slab_stride = (int64_t)C::NTAP * a.tap_stride;
+    return p;
+}
+
+template <int R, int S, int BY, int BX, int TH, int TW>
+void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
+    using C = WCfg<R, S, BY, BX, TH, TW>;
+    const Plan p = plan_cfg<R, S, BY, BX, TH, TW>(a, 256);
+    const int nslabs = p.nsplit * p.wp;
+    RFI_REQUIRE(a.slab && a.slab_floats >= (size_t)nslabs * p.slab_stride, "wgrad: slab workspace too small");
+    WgradDev d{a, p.nsplit, p.slab_stride};
+    dim3 grid(p.nsplit, (unsigned)cdiv(a.Cy, BY), (unsigned)cdiv(a.Cx, BX));
+    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RFI_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&wgrad_igemm_kernel<R, S, BY, BX, TH, TW>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    {
+        const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cy * a.Cx * R * R;
+        ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0);
+        hipLaunchKernelGGL((wgrad_igemm_kernel<R, S, BY, BX, TH, TW>), grid, dim3(256), lds, ctx->stream, d);
+        check_launch("wgrad_igemm");
+    }
+    launch_reduce_slabs(ctx, a.slab, nslabs, p.slab_stride, a.dw);
+}
+
+enum { SEL_PLAN = 0, SEL_LAUNCH = 1 };
+
+template <int R, int S, int TH, int TW>
+Plan select(rfi_ctx* ctx, const WgradArgs& a, int what, int cus) {
+    // channel tile: 64 where the dimension has more than 32 channels, else 32
+    const bool y64 = a.Cy > 32, x64 = a.Cx > 32;
+#define RFI_WG(BY_, BX_)                                                        \
+    do {                                                                        \
+        if (what == SEL_LAUNCH) launch_cfg<R, S, BY_, BX_, TH, TW>(ctx, a);     \
+        return plan_cfg<R, S, BY_, BX_, TH, TW>(a, cus);                        \
+    } while (0)
+    if (y64 && x64) RFI_WG(64, 64);
+    if (y64) RFI_WG(64, 32);
+    if (x64) RFI_WG(32, 64);
+    RFI_WG(32, 32);
+#undef RFI_WG
+}
+
+bool wgrad_mfma_eligible(const WgradArgs& a) {
+    if (a.Cx % 4 || a.Cy % 4 || a.xop.pstride % 4 || a.yop.pstride % 4) return false;
+    if ((reinterpret_cast<uintptr_t>(a.xop.p) & 15) || (reinterpret_cast<uintptr_t>(a.yop.p) & 15)) return false;
+    return (a.R == 3 && a.S == 1 && a.pad == 1) || (a.R == 2 && a.S == 2 && a.pad == 0);
+}
+
+Plan dispatch(rfi_ctx* ctx, const WgradArgs& a, int what, int cus) {
+    if (a.R == 3) return select<3, 1, 8, 8>(ctx, a, what, cus);
+    return select<2, 2, 4, 8>(ctx, a, what, cus);
+}
+
+}  // namespace
+
+size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
+    size_t need = wgrad_direct_slab_floats(a);
+    if (impl != IMPL_DIRECT && wgrad_mfma_eligible(a)) {
+        const Plan p = dispatch(nullptr, a, SEL_PLAN, 256);
+        // plan with the largest CU count we may meet so the workspace always suffices
+        const size_t m = (size_t)p.nsplit * p.wp * p.slab_stride;
+        if (m > need) need = m;
+    }
+    return need;
+}
+
+void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl) {
+    RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cx > 0 && a.Cy > 0, "wgrad: empty shape");
+    const bool ok = wgrad_mfma_eligible(a);
+    if (impl == IMPL_MFMA) RFI_REQUIRE(ok, "wgrad: shape/alignment not eligible for the MFMA kernel");
+    if (impl == IMPL_DIRECT || !ok) {
+        launch_wgrad_direct(ctx, a);
+        return;
+    }
+    dispatch(ctx, a, SEL_LAUNCH, 256);   // MI355X: 256 CUs (the plan fixes the slab workspace size)
+}
+
+}  // namespace rfi

@@ -1,0 +1,5 @@
+"""Drop-in for ``rfi_toolbox.models`` (reference: rfi_toolbox/models/__init__.py:12-14 exports
+``UNet``; ``UNetBigger`` is models/unet.py:79-118) running on MI355X through librfi_hip.so."""
+from .unet import UNet, UNetBigger, default_init_state, unet_entries
+
+__all__ = ["UNet", "UNetBigger", "default_init_state", "unet_entries"]

@@ -1,0 +1,338 @@
+"""``UNet`` with the reference's object protocol, executed by HIP kernels on MI355X.
+
+Mirrors how the reference's callers use ``rfi_toolbox.models.UNet`` (models/unet.py:41-77):
+
+    model = UNet(in_channels=3, out_channels=1, init_features=32).to("cuda")   # train_model.py:111
+    model.train(); logits = model(x)            # x (N,C,H,W) float32 -> (N,1,H,W)   :136,145
+    model.eval();  logits = model(x)                                                  # :157
+    sd = model.state_dict(); model.load_state_dict(sd)       # :179, evaluate_model.py:35
+
+``state_dict`` keys, shapes, dtypes and tensor layouts are the reference's, so checkpoints move
+both ways.  Under ``torch.manual_seed(s)`` the constructor draws the initial weights with the same
+torch initialisers in the same order as the reference's ``__init__`` and therefore produces
+bit-identical initial weights.
+
+What cannot be mirrored is ``loss.backward()``: there is no autograd here.  The loop body of
+scripts/train_model.py:139-154 is one call, ``model.train_step(data, mask, lr=..., ...)``.
+There is no CPU fallback: constructing a model without an MI355X raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _lib
+from .._lib import DEVICE, HOST, Hyper, check, lib
+from ..runtime import Context, as_pointer, is_torch, torch
+
+
+# ------------------------------------------------------------------ host-side parameter table
+def _double_conv_entries(prefix, cin, cout):
+    out = []
+    for conv_i, bn_i, ci in ((0, 1, cin), (3, 4, cout)):
+        out += [(f"{prefix}.{conv_i}.weight", (cout, ci, 3, 3), "conv_w"),
+                (f"{prefix}.{conv_i}.bias", (cout,), "conv_b"),
+                (f"{prefix}.{bn_i}.weight", (cout,), "bn_g"),
+                (f"{prefix}.{bn_i}.bias", (cout,), "bn_b"),
+                (f"{prefix}.{bn_i}.running_mean", (cout,), "bn_rm"),
+                (f"{prefix}.{bn_i}.running_var", (cout,), "bn_rv"),
+                (f"{prefix}.{bn_i}.num_batches_tracked", (), "bn_nbt")]
+    return out
+
+
+def unet_entries(in_channels, out_channels, init_features, depth=4):
+    """(name, shape, kind) in the reference's ``state_dict`` order (unet.py:41-58, :79-98)."""
+    f, ent, cin = init_features, [], in_channels
+    for lvl in range(1, depth + 1):
+        cout = f << (lvl - 1)
+        ent += _double_conv_entries(f"encoder{lvl}.conv.conv", cin, cout)
+        cin = cout
+    ent += _double_conv_entries("bottleneck.conv", cin, 2 * cin)
+    cin *= 2
+    for lvl in range(depth, 0, -1):
+        cout = f << (lvl - 1)
+        ent += [(f"decoder{lvl}.up.weight", (cin, cout, 2, 2), "conv_w"),
+                (f"decoder{lvl}.up.bias", (cout,), "conv_b")]
+        ent += _double_conv_entries(f"decoder{lvl}.conv.conv", cin, cout)
+        cin = cout
+    ent += [("final_conv.weight", (out_channels, f, 1, 1), "conv_w"), ("final_conv.bias", (out_channels,), "conv_b")]
+    return ent
+
+
+def default_init_state(in_channels, out_channels, init_features, depth=4):
+    """torch's default Conv2d/ConvTranspose2d/BatchNorm2d initialisation, drawn from the global
+    torch RNG in module-construction order == the reference's ``UNet.__init__`` draw order."""
+    if torch is None:
+        raise RuntimeError("torch is required for the default initialisation")
+    sd = OrderedDict()
+    bound = 0.0
+    for name, shape, kind in unet_entries(in_channels, out_channels, init_features, depth):
+        if kind == "conv_w":
+            w = torch.empty(shape)
+            torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+            fan_in = shape[1] * shape[2] * shape[3]
+            bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+            sd[name] = w
+        elif kind == "conv_b":
+            b = torch.empty(shape)
+            torch.nn.init.uniform_(b, -bound, bound)
+            sd[name] = b
+        elif kind in ("bn_g", "bn_rv"):
+            sd[name] = torch.ones(shape)
+        elif kind in ("bn_b", "bn_rm"):
+            sd[name] = torch.zeros(shape)
+        else:
+            sd[name] = torch.tensor(0, dtype=torch.long)
+    return sd
+
+
+# ------------------------------------------------------------------ the model
+class UNet:
+    """MI355X-native U-Net; same constructor signature as the reference (unet.py:42)."""
+
+    _DEPTH = 4
+
+    def __init__(self, in_channels=1, out_channels=1, init_features=32, *, device=None, depth=None):
+        for v, nm in ((in_channels, "in_channels"), (out_channels, "out_channels"), (init_features, "init_features")):
+            if not isinstance(v, (int, np.integer)) or v <= 0:
+                raise ValueError(f"{nm} must be a positive integer, got {v!r}")
+        self.in_channels, self.out_channels, self.init_features = int(in_channels), int(out_channels), int(init_features)
+        self.depth = int(depth if depth is not None else self._DEPTH)
+        self.training = True
+        self._entries = unet_entries(self.in_channels, self.out_channels, self.init_features, self.depth)
+        self._init = default_init_state(self.in_channels, self.out_channels, self.init_features, self.depth)
+        self._h = None
+        self.ctx = None
+        self._bind(device)
+
+    # ---- device binding
+    def _bind(self, device):
+        ctx = Context.get(device)
+        h = C.c_void_p()
+        check(lib.rfi_unet_create(ctx.handle, self.in_channels, self.out_channels, self.init_features,
+                                  self.depth, C.byref(h)))
+        old_state = self.state_dict() if self._h is not None else self._init
+        self._release()
+        self.ctx, self._h = ctx, h
+        self._check_table()
+        self.load_state_dict(old_state)
+        self._init = None
+        check(lib.rfi_model_set_training(self._h, 1 if self.training else 0))
+
+    def _release(self):
+        if self._h is not None:
+            lib.rfi_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _check_table(self):
+        n = C.c_int()
+        check(lib.rfi_model_entry_count(self._h, C.byref(n)))
+        if n.value != len(self._entries):
+            raise RuntimeError("library/host parameter tables disagree")
+        name, ndim, dims = C.c_char_p(), C.c_int(), (C.c_int64 * 4)()
+        for i, (nm, shape, _) in enumerate(self._entries):
+            check(lib.rfi_model_entry_info(self._h, i, C.byref(name), C.byref(ndim), dims, None, None))
+            got = tuple(dims[k] for k in range(ndim.value))
+            if name.value.decode() != nm or got != tuple(shape):
+                raise RuntimeError(f"parameter table mismatch at {i}: {name.value!r}{got} vs {nm}{shape}")
+
+    def to(self, device):
+        """``.to("cuda")`` / ``.to("cuda:1")`` / ``.to(torch.device)``; 'cpu' raises (no CPU path)."""
+        from ..runtime import _parse_device
+        if _parse_device(device) != self.ctx.device_index:
+            self._bind(device)
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else f"cuda:{device}")
+
+    # ---- mode
+    def train(self, mode=True):
+        self.training = bool(mode)
+        check(lib.rfi_model_set_training(self._h, 1 if self.training else 0))
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ---- state
+    def state_dict(self):
+        sd = OrderedDict()
+        for name, shape, kind in self._entries:
+            if kind == "bn_nbt":
+                v = np.zeros((), dtype=np.int64)
+            else:
+                v = np.empty(shape, dtype=np.float32)
+            check(lib.rfi_model_store_entry(self._h, name.encode(), v.ctypes.data_as(C.c_void_p), v.nbytes))
+            sd[name] = torch.from_numpy(v) if torch is not None else v
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        # accept the wrapped checkpoint train_model.py:177-183 writes as well as a bare state_dict
+        if "model_state_dict" in state_dict and "encoder1.conv.conv.0.weight" not in state_dict:
+            state_dict = state_dict["model_state_dict"]
+        names = [e[0] for e in self._entries]
+        missing = [n for n in names if n not in state_dict]
+        unexpected = [k for k in state_dict if k not in set(names)]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for UNet: Missing key(s): {missing}; "
+                               f"Unexpected key(s): {unexpected}")
+        for name, shape, kind in self._entries:
+            if name not in state_dict:
+                continue
+            v = state_dict[name]
+            v = v.detach().cpu().numpy() if is_torch(v) else np.asarray(v)
+            if tuple(v.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {name}: copying a param with shape {tuple(v.shape)} "
+                                   f"from checkpoint, the shape in current model is {tuple(shape)}")
+            v = np.ascontiguousarray(v, dtype=np.int64 if kind == "bn_nbt" else np.float32)
+            check(lib.rfi_model_load_entry(self._h, name.encode(), v.ctypes.data_as(C.c_void_p), v.nbytes))
+        return self
+
+    def named_parameters(self):
+        sd = self.state_dict()
+        for name, _, kind in self._entries:
+            if kind in ("conv_w", "conv_b", "bn_g", "bn_b"):
+                yield name, sd[name]
+
+    def parameters(self):
+        """Host snapshots of the parameters (copies: updates happen on the GPU in train_step)."""
+        for _, p in self.named_parameters():
+            yield p
+
+    def num_parameters(self) -> int:
+        n = C.c_int64()
+        check(lib.rfi_model_param_count(self._h, C.byref(n)))
+        return n.value
+
+    # ---- forward
+    def _forward(self, x, nchw):
+        shape = tuple(x.shape)
+        if len(shape) != 4:
+            raise ValueError(f"expected a 4-D input, got shape {shape}")
+        n, c, h, w = (shape if nchw else (shape[0], shape[3], shape[1], shape[2]))
+        if c != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {c}")
+        ptr, mem, keep = as_pointer(x, np.float32, self.ctx)
+        out = np.empty((n, self.out_channels, h, w) if nchw else (n, h, w, self.out_channels), dtype=np.float32)
+        fn = lib.rfi_model_forward_nchw if nchw else lib.rfi_model_forward_nhwc
+        check(fn(self._h, C.c_void_p(ptr), mem, n, h, w, out.ctypes.data_as(C.c_void_p), HOST))
+        del keep
+        if is_torch(x):
+            t = torch.from_numpy(out)
+            return t.to(x.device) if x.is_cuda else t
+        return out
+
+    def forward(self, x):
+        """x (N,C,H,W) float32 -> logits (N,out,H,W)  (unet.py:60-77)."""
+        return self._forward(x, nchw=True)
+
+    __call__ = forward
+
+    def forward_nhwc(self, x):
+        """x (N,H,W,C) as ``Preprocessor`` emits it -> logits (N,H,W,out); no transposes anywhere."""
+        return self._forward(x, nchw=False)
+
+    # ---- the optimisation step of scripts/train_model.py:139-154
+    @staticmethod
+    def _hyper(lr, betas, eps, weight_decay, max_grad_norm):
+        return Hyper(float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                     float(max_grad_norm))
+
+    def _xy(self, data, mask, nhwc):
+        shape = tuple(data.shape)
+        if len(shape) != 4:
+            raise ValueError(f"expected 4-D data, got shape {shape}")
+        if not nhwc:
+            raise ValueError("train_step takes NHWC data (N,H,W,C) as Preprocessor emits it")
+        n, h, w, c = shape
+        if c != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {c}")
+        mshape = tuple(mask.shape)
+        if mshape not in ((n, h, w), (n, 1, h, w), (n, h, w, 1)):
+            raise ValueError(f"mask shape {mshape} does not match data {shape}")
+        xp, xm, k1 = as_pointer(data, np.float32, self.ctx)
+        yp, ym, k2 = as_pointer(mask, np.uint8, self.ctx)
+        return n, h, w, xp, xm, yp, ym, (k1, k2)
+
+    def train_step(self, data, mask, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5,
+                   max_grad_norm=1.0):
+        """zero_grad, forward, BCEWithLogits+dice, backward, clip_grad_norm_, Adam step; returns the loss.
+        Defaults are the reference script's (train_model.py:89,95,130,149).  data: NHWC float32,
+        mask: (N,H,W) uint8/bool, non-zero == RFI."""
+        n, h, w, xp, xm, yp, ym, keep = self._xy(data, mask, True)
+        hp = self._hyper(lr, betas, eps, weight_decay, max_grad_norm)
+        loss = C.c_float()
+        check(lib.rfi_train_step(self._h, C.c_void_p(xp), xm, C.c_void_p(yp), ym, n, h, w, C.byref(hp),
+                                 C.byref(loss)))
+        del keep
+        return loss.value
+
+    def loss(self, data, mask):
+        """BCE+dice of the current mode's forward, no update (validation loop, train_model.py:157-167)."""
+        n, h, w, xp, xm, yp, ym, keep = self._xy(data, mask, True)
+        loss = C.c_float()
+        check(lib.rfi_model_loss(self._h, C.c_void_p(xp), xm, C.c_void_p(yp), ym, n, h, w, C.byref(loss)))
+        del keep
+        return loss.value
+
+    def forward_backward(self, data, mask):
+        n, h, w, xp, xm, yp, ym, keep = self._xy(data, mask, True)
+        loss = C.c_float()
+        check(lib.rfi_train_forward_backward(self._h, C.c_void_p(xp), xm, C.c_void_p(yp), ym, n, h, w,
+                                             C.byref(loss)))
+        del keep
+        return loss.value
+
+    def apply_gradients(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, max_grad_norm=1.0,
+                        grad_scale=1.0):
+        hp = self._hyper(lr, betas, eps, weight_decay, max_grad_norm)
+        norm = C.c_float()
+        check(lib.rfi_train_apply(self._h, C.byref(hp), float(grad_scale), C.byref(norm)))
+        return norm.value
+
+    def allreduce_gradients(self):
+        check(lib.rfi_model_allreduce_grads(self._h))
+
+    def train_step_async(self, data_dev, mask_dev, n, h, w, hyper: Hyper):
+        """Enqueue one full step on device-resident inputs without any host sync (bench loops)."""
+        check(lib.rfi_train_step_async(self._h, C.c_void_p(data_dev), C.c_void_p(mask_dev), n, h, w,
+                                       C.byref(hyper)))
+
+    def last_loss(self):
+        a, b = C.c_float(), C.c_float()
+        check(lib.rfi_model_last_loss(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def grad(self, name) -> np.ndarray:
+        """Gradient of parameter ``name`` after forward_backward, in the reference's layout."""
+        shape = dict((e[0], e[1]) for e in self._entries)[name]
+        g = np.empty(shape, dtype=np.float32)
+        check(lib.rfi_model_store_grad(self._h, name.encode(), g.ctypes.data_as(C.c_void_p), g.nbytes))
+        return g
+
+    def adam_state(self, name):
+        shape = dict((e[0], e[1]) for e in self._entries)[name]
+        m, v, step = np.empty(shape, np.float32), np.empty(shape, np.float32), C.c_int64()
+        check(lib.rfi_model_store_adam(self._h, name.encode(), m.ctypes.data_as(C.c_void_p),
+                                       v.ctypes.data_as(C.c_void_p), m.nbytes, C.byref(step)))
+        return m, v, step.value
+
+    def algorithmic_flops(self, n, h, w):
+        f, s = C.c_double(), C.c_double()
+        check(lib.rfi_model_algorithmic_flops(self._h, n, h, w, C.byref(f), C.byref(s)))
+        return f.value, s.value
+
+
+class UNetBigger(UNet):
+    """5-level variant (reference models/unet.py:79-118)."""
+    _DEPTH = 5

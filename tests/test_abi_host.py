@@ -1,0 +1,76 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/rfi_hip.h declares, and the
+host-side logic (parameter table, default init, argument validation, error strings) behaves.
+No compute entry point is called here (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "rfi_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rfi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rfi_toolbox_amd import _lib
+    names = _header_functions()
+    assert len(names) >= 50
+    for n in names:
+        assert hasattr(_lib.lib, n), f"librfi_hip.so lacks {n}"
+    assert sorted(_lib.EXPORTED) == names, set(_lib.EXPORTED) ^ set(names)
+    assert _lib.lib.rfi_abi_version() == 1
+
+
+def test_host_only_entry_points():
+    from rfi_toolbox_amd import _lib
+    assert _lib.lib.rfi_profile_family_count() == 10
+    fams = [_lib.lib.rfi_profile_family_name(i).decode() for i in range(10)]
+    assert fams[0] == "conv_igemm_mfma" and "wgrad_igemm_mfma" in fams
+    assert _lib.device_count() >= 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    from rfi_toolbox_amd import _lib
+    from rfi_toolbox_amd.models import UNet
+    h = C.c_void_p()
+    assert _lib.lib.rfi_ctx_create(0, C.byref(h)) != 0
+    assert len(_lib.lib.rfi_last_error()) > 0
+    with pytest.raises(RuntimeError):
+        UNet(3, 1, 4)
+    with pytest.raises(RuntimeError):
+        UNet(3, 1, 4, device="cpu")
+
+
+def test_parameter_table_and_default_init_match_reference(golden_dir):
+    from rfi_toolbox_amd.models import default_init_state, unet_entries
+    g = np.load(os.path.join(golden_dir, "unet_f8_b4_s64.npz"))
+    ent = unet_entries(3, 1, 8)
+    assert [(n, tuple(s)) for n, s, _ in ent] == [(n, tuple(s)) for n, s, _ in unet_ref.unet_entries(3, 1, 8)]
+    torch.manual_seed(1234)                      # the seed the golden run used before UNet(3,1,8)
+    sd = default_init_state(3, 1, 8)
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), g[f"state0/{k}"]), k      # bit-identical initial weights
+    assert len(unet_entries(3, 1, 4, depth=5)) == len(unet_ref.unet_entries(3, 1, 4, depth=5))
+
+
+def test_python_argument_validation_without_gpu():
+    from rfi_toolbox_amd.models import UNet
+    from rfi_toolbox_amd.preprocessing import Preprocessor, patchify
+    with pytest.raises(ValueError):
+        UNet(0, 1, 4)
+    with pytest.raises(ValueError):
+        UNet(3, 1, -2)
+    with pytest.raises(ValueError):
+        Preprocessor(np.zeros((4, 4)))
+    p = patchify(np.arange(16).reshape(4, 4), (2, 2), 2)
+    assert p[0, 0].tolist() == [[0, 1], [4, 5]] and p[1, 1].tolist() == [[10, 11], [14, 15]]
