@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training patches/sec of the U-Net step on 128x128x3 patches.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + BCE/dice loss + backward + (RCCL gradient all-reduce when N > 1) + global-norm
+clip + Adam on one batch of 64 synthetic patches per GPU that is already resident in HBM.
+Prints ONE JSON line on rank 0.  fp32 compute (the reference's CPU path is fp32).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def usable_cpus():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(features, size, seconds_cap=25.0):
+    """The oracle (torch-CPU fp32 restatement of the reference step) timed on this host: batch 4
+    (BASELINE config 0), all host threads.  A reported baseline, not the target."""
+    from collections import OrderedDict
+
+    import torch
+
+    from oracle import unet_ref
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    st = unet_ref.init_state(3, 1, features, seed=0)
+    adam = unet_ref.new_adam_state(st)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 3, size, size, generator=g)
+    y = (torch.rand(4, 1, size, size, generator=g) > 0.8).float()
+    t_all0 = time.perf_counter()
+    times = []
+    for i in range(2 + 10):
+        t0 = time.perf_counter()
+        unet_ref.train_step(st, adam, x, y, lr=1e-4, weight_decay=1e-5)
+        dt = time.perf_counter() - t0
+        if i >= 2:
+            times.append(dt)
+        if time.perf_counter() - t_all0 > seconds_cap and len(times) >= 2:
+            break
+    med = float(np.median(times))
+    return {"value": round(4 / med, 3), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/unet_ref.train_step, UNet(3,1,{features}) batch 4 x {size}x{size}x3 fp32, "
+                      f"{len(times)} timed steps after 2 warm-up, median {med * 1e3:.1f} ms/step, "
+                      f"torch.set_num_threads({threads})"}
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T0:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="patches per GPU per step")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--features", type=int, default=32)
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from rfi_toolbox_amd import distributed as D
+    from rfi_toolbox_amd._lib import Hyper
+    from rfi_toolbox_amd.data_generation import make_training_patches
+    from rfi_toolbox_amd.models import UNet
+    from rfi_toolbox_amd.runtime import Context
+
+    log("imports done")
+    rank, local_rank, world = D.init_control_plane("gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    ctx = Context.get(local_rank)
+    D.init_gradient_exchange(ctx, rank, world)
+
+    torch.manual_seed(1234)                       # identical replicas on every rank
+    model = UNet(3, 1, args.features, device=local_rank)
+    model.train()
+    log("model built")
+    B, S = args.batch, args.size
+    imgs, labs = make_training_patches(B, S, seed=1234 + rank, device=local_rank)
+    d_x, d_y = ctx.to_device(imgs), ctx.to_device(labs)
+    hp = Hyper(1e-4, 0.9, 0.999, 1e-8, 1e-5, 1.0)   # train_model.py:89,95,130,149 defaults
+    log(f"inputs resident: {imgs.shape} {labs.shape}, label fraction {labs.mean():.3f}")
+
+    for _ in range(args.warmup):
+        model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+    ctx.synchronize()
+    log("warm-up done")
+    D.barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+    ev_ms = ctx.timer_stop()                      # HIP events on the ctx stream; synchronises
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    D.barrier()
+    wall = D.max_over_ranks(wall)
+    log(f"timed region done: {wall * 1e3 / args.steps:.2f} ms/step")
+    loss, gnorm = model.last_loss()
+    if not np.isfinite(loss):
+        raise SystemExit(f"non-finite loss {loss}")
+
+    # ---- per-kernel-family HIP-event profile (separate steps so events do not sit in the timed region)
+    fam = {}
+    if args.profile_steps > 0:
+        ctx.profile_reset()
+        ctx.profile(True)
+        for _ in range(args.profile_steps):
+            model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+        ctx.synchronize()
+        ctx.profile(False)
+        fam = ctx.profile_report()
+    D.barrier()
+
+    if rank != 0:
+        return
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * B * args.steps / wall
+    fwd_flops, step_flops = model.algorithmic_flops(B, S, S)
+    roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
+            "traffic": None}
+    fam_out = {}
+    for name, f in fam.items():
+        per = {"launches_per_step": f["launches"] / args.profile_steps, "ms_per_step": f["ms"] / args.profile_steps}
+        if f["flops"]:
+            per["tflops"] = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] else None
+        if f["bytes"]:
+            per["gbs"] = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else None
+        fam_out[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in per.items()}
+    dom = "conv_igemm_mfma"
+    if dom in fam and fam[dom]["ms"]:
+        ach = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3) / 1e12
+        roof.update(achieved=round(ach, 3), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), kernel=dom,
+                    avg_launch_ms=round(fam[dom]["ms"] / fam[dom]["launches"], 5),
+                    launches_per_step=fam[dom]["launches"] / args.profile_steps,
+                    algorithmic_flops_per_launch=fam[dom]["flops"] / fam[dom]["launches"])
+    step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
+    out = {
+        "metric": "training patches/sec (128x128x3)", "value": round(value, 2), "unit": "patches/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"UNet(3,1,{args.features}) train step (fwd+BCE/dice+bwd+clip+Adam), "
+                               f"batch {B}/GPU x {S}x{S}x3 NHWC fp32, BASELINE configs[1] shape on the "
+                               "reference's U-Net (the '3-layer CNN' of configs[1] is not in the reference)",
+                   "global_batch": B * world, "patch": [S, S, 3], "parallelism": f"dp{world}",
+                   "params": model.num_parameters()},
+        "roofline": roof,
+        "step": {"algorithmic_gflop_per_patch": round(step_flops / B / 1e9, 3),
+                 "tflops_whole_step": round(step_tflops, 3),
+                 "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                 "hip_event_ms_per_step": round(ev_ms / args.steps, 4), "final_loss": round(float(loss), 6)},
+        "families": fam_out,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline ...")
+        out["cpu_baseline"] = cpu_baseline(args.features, S)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,13 @@ int rfi_model_store_grad(rfi_model* m, const char* name, void* host, size_t byte
 int rfi_model_store_adam(rfi_model* m, const char* name, void* host_m, void* host_v, size_t bytes,
                          int64_t* step);
 int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, double* step);
+/* read an internal activation / gradient buffer of the last prepared shape (parity debugging):
+ * "encY1.<l>" "encY2.<l>" "decY1.<l>" "decY2.<l>" "concat.<l>" "pool.<l>" "bottY1" "bottY2" "logits"
+ * "dlogits" "gA.<l>" "gB.<l>" "dconcat.<l>" "dpool.<l>" "gBottA" "gBottB" (raw NHWC fp32), and
+ * "chan.<conv index>" = [running_mean|running_var|mean|invstd|scale|shift|c1|c2] x Cout.
+ * host == NULL only reports the element count. */
+int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t host_floats,
+                           int64_t* n_floats);
 
 /* ---- data-parallel gradient exchange (new; the reference has no multi-GPU path) -------
  * RCCL over xGMI: ncclAllReduce(sum) of the flat gradient buffer on the ctx stream.
@@ -176,6 +183,16 @@ int rfi_op_convt2x2_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h,
 int rfi_op_convt2x2_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy, int n, int h,
                           int w, int cin, int cout, float* dw_iohw);
 int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean, float* var_biased);
+/* a = relu(y*scale+shift): skip (n,h,w,c) and 2x2 max-pooled (n,h/2,w/2,c) */
+int rfi_op_bn_relu_pool(rfi_ctx* ctx, const float* y, int n, int h, int w, int c, const float* scale,
+                        const float* shift, float* skip, float* pooled);
+/* da = dskip + max-pool routing of dpool (first maximum in row-major window order wins) */
+int rfi_op_pool_bwd_merge(rfi_ctx* ctx, const float* y, int n, int h, int w, int c, const float* scale,
+                          const float* shift, const float* dskip, const float* dpool, float* da);
+/* train-mode BatchNorm+ReLU backward of y (m,c) with affine gamma/beta: da (grad w.r.t. the
+ * activated output) is overwritten with dy; dgamma, dbeta, dbias(=sum dy) are written */
+int rfi_op_bn_relu_backward(rfi_ctx* ctx, const float* y, int64_t m, int c, const float* gamma,
+                            const float* beta, float* da_inout, float* dgamma, float* dbeta, float* dbias);
 
 #ifdef __cplusplus
 }

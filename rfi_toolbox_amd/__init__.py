@@ -4,7 +4,9 @@ segmentation metrics, behind the reference's Python surface.  Compute lives in l
 (hand-written HIP, C ABI in include/rfi_hip.h); there is no CPU fallback."""
 __version__ = "0.1.0"
 
-from . import _lib  # noqa: F401  (loads librfi_hip.so; raises ImportError if it was not built)
+# Sub-modules are imported lazily; every one of them imports ``_lib`` first, which loads
+# librfi_hip.so and raises ImportError (with the build command) if it has not been built.
+# ``python -m rfi_toolbox_amd.build`` must stay importable without the library.
 
 
 def __getattr__(name):

@@ -81,6 +81,7 @@ _PROTOS = {
     "rfi_model_store_grad": (_i, [_vp, _cp, _vp, _sz]),
     "rfi_model_store_adam": (_i, [_vp, _cp, _vp, _vp, _sz, _pi64]),
     "rfi_model_algorithmic_flops": (_i, [_vp, _i, _i, _i, _pd, _pd]),
+    "rfi_model_debug_tensor": (_i, [_vp, _cp, _vp, _sz, _pi64]),
     "rfi_comm_unique_id": (_i, [_vp]),
     "rfi_comm_init": (_i, [_vp, _vp, _i, _i]),
     "rfi_comm_destroy": (_i, [_vp]),
@@ -96,6 +97,9 @@ _PROTOS = {
     "rfi_op_convt2x2_dgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "rfi_op_convt2x2_wgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rfi_op_bn_stats": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "rfi_op_bn_relu_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rfi_op_pool_bwd_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rfi_op_bn_relu_backward": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 for _name, (_res, _args) in _PROTOS.items():

@@ -597,6 +597,60 @@ int rfi_model_param_buffer(rfi_model* m, float** dptr, int64_t* n_floats) {
     });
 }
 
+int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t host_floats,
+                           int64_t* n_floats) {
+    return guarded([&] {
+        m->ctx->activate();
+        RFI_REQUIRE(name && m->pN > 0, "debug_tensor: no prepared shape");
+        std::string s(name), base = s;
+        int idx = -1;
+        auto dot = s.find('.');
+        if (dot != std::string::npos) {
+            base = s.substr(0, dot);
+            idx = std::stoi(s.substr(dot + 1));
+        }
+        const float* src = nullptr;
+        size_t n = 0;
+        const int D = m->depth;
+        auto level = [&](const std::vector<int>& v, size_t chmul) {
+            RFI_REQUIRE(idx >= 1 && idx <= D, "debug_tensor: level out of range");
+            const size_t M = (size_t)m->pN * (m->pH >> (idx - 1)) * (m->pW >> (idx - 1));
+            src = m->buf(v[idx]);
+            n = M * ((size_t)m->feat << (idx - 1)) * chmul;
+        };
+        const size_t Mb = (size_t)m->pN * (m->pH >> D) * (m->pW >> D), Cb = (size_t)m->feat << D;
+        const size_t M1 = (size_t)m->pN * m->pH * m->pW;
+        if (base == "encY1") level(m->encY1, 1);
+        else if (base == "encY2") level(m->encY2, 1);
+        else if (base == "decY1") level(m->decY1, 1);
+        else if (base == "decY2") level(m->decY2, 1);
+        else if (base == "gA") level(m->gA, 1);
+        else if (base == "gB") level(m->gB, 1);
+        else if (base == "concat") level(m->concat, 2);
+        else if (base == "dconcat") level(m->dconcat, 2);
+        else if (base == "pool") { level(m->pool, 1); n /= 4; }
+        else if (base == "dpool") { level(m->dpool, 1); n /= 4; }
+        else if (base == "bottY1") { src = m->buf(m->bottY1); n = Mb * Cb; }
+        else if (base == "bottY2") { src = m->buf(m->bottY2); n = Mb * Cb; }
+        else if (base == "gBottA") { src = m->buf(m->gBottA); n = Mb * Cb; }
+        else if (base == "gBottB") { src = m->buf(m->gBottB); n = Mb * Cb; }
+        else if (base == "logits") { src = m->buf(m->logits); n = M1 * m->out_ch; }
+        else if (base == "dlogits") { src = m->buf(m->dlogits); n = M1 * m->out_ch; }
+        else if (base == "chan") {
+            RFI_REQUIRE(idx >= 0 && idx < (int)m->convs.size(), "debug_tensor: conv index out of range");
+            src = m->convs[idx].chan;
+            n = (size_t)8 * m->convs[idx].cout;
+        } else {
+            throw Error("debug_tensor: unknown tensor " + s);
+        }
+        if (n_floats) *n_floats = (int64_t)n;
+        if (host) {
+            RFI_REQUIRE(host_floats >= n, "debug_tensor: host buffer too small");
+            download(m, host, src, n);
+        }
+    });
+}
+
 int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, double* step) {
     return guarded([&] {
         // 2*M*K*N over every conv / convT / head, each layer evaluated once
@@ -942,6 +996,39 @@ int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean,
         launch_bn_stats(ctx, y, m, c, ws);
         launch_bn_finalize(ctx, ws, m, c, tmp, tmp + c, nullptr, nullptr, 0, mean, tmp + 2 * c, tmp + 3 * c,
                            tmp + 4 * c, var_biased);
+    });
+}
+
+int rfi_op_bn_relu_pool(rfi_ctx* ctx, const float* y, int n, int h, int w, int c, const float* scale,
+                        const float* shift, float* skip, float* pooled) {
+    return guarded([&] {
+        ctx->activate();
+        launch_bn_relu_pool(ctx, y, n, h, w, c, scale, shift, MutView{skip, c}, pooled);
+    });
+}
+int rfi_op_pool_bwd_merge(rfi_ctx* ctx, const float* y, int n, int h, int w, int c, const float* scale,
+                          const float* shift, const float* dskip, const float* dpool, float* da) {
+    return guarded([&] {
+        ctx->activate();
+        launch_pool_bwd_merge(ctx, y, n, h, w, c, scale, shift, View{dskip, c}, dpool, da);
+    });
+}
+int rfi_op_bn_relu_backward(rfi_ctx* ctx, const float* y, int64_t m, int c, const float* gamma,
+                            const float* beta, float* da_inout, float* dgamma, float* dbeta, float* dbias) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        size_t wsf = bn_stats_ws_floats(c);
+        if (bn_bwd_ws_floats(m, c) > wsf) wsf = bn_bwd_ws_floats(m, c);
+        float* ws = s.get(wsf);
+        float* t = s.get((size_t)6 * c);     // mean | invstd | scale | shift | c1 | c2
+        launch_bn_stats(ctx, y, m, c, ws);
+        launch_bn_finalize(ctx, ws, m, c, gamma, beta, nullptr, nullptr, 0, t, t + c, t + 2 * c, t + 3 * c,
+                           nullptr);
+        launch_bn_bwd_reduce(ctx, da_inout, y, m, c, t + 2 * c, t + 3 * c, t, t + c, ws, t + 4 * c, t + 5 * c,
+                             dgamma, dbeta);
+        launch_bn_bwd_apply(ctx, da_inout, y, m, c, t + 2 * c, t + 3 * c, t, t + c, gamma, t + 4 * c, t + 5 * c,
+                            ws, dbias);
     });
 }
 

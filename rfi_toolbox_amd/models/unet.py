@@ -327,6 +327,15 @@ class UNet:
                                        v.ctypes.data_as(C.c_void_p), m.nbytes, C.byref(step)))
         return m, v, step.value
 
+    def debug_tensor(self, name) -> np.ndarray:
+        """Flat copy of an internal activation/gradient buffer (see rfi_model_debug_tensor)."""
+        n = C.c_int64()
+        check(lib.rfi_model_debug_tensor(self._h, name.encode(), None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        check(lib.rfi_model_debug_tensor(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size,
+                                         C.byref(n)))
+        return out
+
     def algorithmic_flops(self, n, h, w):
         f, s = C.c_double(), C.c_double()
         check(lib.rfi_model_algorithmic_flops(self._h, n, h, w, C.byref(f), C.byref(s)))

@@ -74,10 +74,11 @@ def test_conv3x3_wgrad_with_load_transform():
     dy = torch.randn(n, cout, h, w, generator=g)
     F.conv2d(a, wt, None, padding=1).backward(dy)
     c = ctx()
+    dx, ddy, dsc, dsh = (c.to_device(nhwc(x)), c.to_device(nhwc(dy)), c.to_device(sc.numpy()),
+                         c.to_device(sh.numpy()))      # keep the device buffers alive across the calls
     for impl in (IMPL_DIRECT, IMPL_MFMA):
         gw = c.empty((cout, cin, 3, 3))
-        check(lib.rfi_op_conv3x3_wgrad(c.handle, impl, P(c.to_device(nhwc(x))), P(c.to_device(nhwc(dy))), n, h, w,
-                                       cin, cout, P(c.to_device(sc.numpy())), P(c.to_device(sh.numpy())), 1, P(gw)))
+        check(lib.rfi_op_conv3x3_wgrad(c.handle, impl, P(dx), P(ddy), n, h, w, cin, cout, P(dsc), P(dsh), 1, P(gw)))
         assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, f"impl={impl}"
 
 
@@ -115,8 +116,104 @@ def test_bn_statistics(m, c_):
     g = torch.Generator().manual_seed(m)
     y = torch.randn(m, c_, generator=g) * (torch.rand(c_, generator=g) * 3 + 0.01) + torch.randn(c_, generator=g) * 50
     c = ctx()
-    mean, var = c.empty((c_,)), c.empty((c_,))
-    check(lib.rfi_op_bn_stats(c.handle, P(c.to_device(y.numpy())), m, c_, P(mean), P(var)))
+    mean, var, dy = c.empty((c_,)), c.empty((c_,)), c.to_device(y.numpy())
+    check(lib.rfi_op_bn_stats(c.handle, P(dy), m, c_, P(mean), P(var)))
     yd = y.double()
     np.testing.assert_allclose(mean.numpy(), yd.mean(0).numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(var.numpy(), yd.var(0, unbiased=False).numpy(), rtol=2e-5, atol=1e-7)
+
+
+def _unet_conv_shapes(f, n, size, depth=4):
+    """(n, h, w, cin, cout) of every 3x3 conv of UNet(3,1,f) on n x size x size inputs."""
+    out, cin = [], 3
+    for lvl in range(depth):
+        c = f << lvl
+        s = size >> lvl
+        out += [(n, s, s, cin, c), (n, s, s, c, c)]
+        cin = c
+    s = size >> depth
+    out += [(n, s, s, cin, 2 * cin), (n, s, s, 2 * cin, 2 * cin)]
+    for lvl in range(depth - 1, -1, -1):
+        c = f << lvl
+        s = size >> lvl
+        out += [(n, s, s, 2 * c, c), (n, s, s, c, c)]
+    return sorted(set(out))
+
+
+@pytest.mark.parametrize("shape", _unet_conv_shapes(16, 2, 64) + _unet_conv_shapes(8, 1, 32))
+def test_every_unet_layer_shape(shape):
+    """forward, dgrad and wgrad at exactly the shapes the model launches (auto implementation)."""
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(hash(shape) % 997)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv2d(x, wt, b, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    c = ctx()
+    dx, dw, db, ddy = (c.to_device(nhwc(x.detach())), c.to_device(wt.detach().numpy()), c.to_device(b.numpy()),
+                       c.to_device(nhwc(dy)))
+    out = c.empty((n, h, w, cout))
+    check(lib.rfi_op_conv3x3(c.handle, 0, P(dx), n, h, w, cin, P(dw), P(db), cout, None, None, 0, P(out)))
+    assert rel_err(out.numpy(), nhwc(y.detach())) <= TOL
+    gx = c.empty((n, h, w, cin))
+    check(lib.rfi_op_conv3x3_dgrad(c.handle, 0, P(ddy), n, h, w, cout, P(dw), cin, P(gx)))
+    assert rel_err(gx.numpy(), nhwc(x.grad)) <= TOL
+    gw = c.empty((cout, cin, 3, 3))
+    check(lib.rfi_op_conv3x3_wgrad(c.handle, 0, P(dx), P(ddy), n, h, w, cin, cout, None, None, 0, P(gw)))
+    assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5
+
+
+POOL_SHAPES = [(2, 32, 32, 32), (2, 64, 64, 16), (1, 8, 8, 128), (3, 4, 6, 5), (1, 16, 16, 64)]
+
+
+@pytest.mark.parametrize("shape", POOL_SHAPES)
+def test_bn_relu_pool_and_backward(shape):
+    n, h, w, ch = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    y = torch.randn(n, ch, h, w, generator=g)
+    y[:, :, ::4, ::4] = -3.0                               # force all-zero windows / ties at zero
+    sc = torch.rand(ch, generator=g) + 0.5
+    sc[::3] *= -1                                          # negative scales: max must follow the activation
+    sh = torch.randn(ch, generator=g) * 0.2
+    a = torch.relu(y * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    p = F.max_pool2d(a, 2, 2)
+    dpool = torch.randn(p.shape, generator=g)
+    dskip = torch.randn(a.shape, generator=g)
+    (p * dpool).sum().backward()
+    want_da = a.grad + dskip
+    c = ctx()
+    dy_, dsc, dsh = c.to_device(nhwc(y)), c.to_device(sc.numpy()), c.to_device(sh.numpy())
+    skip, pooled = c.empty((n, h, w, ch)), c.empty((n, h // 2, w // 2, ch))
+    check(lib.rfi_op_bn_relu_pool(c.handle, P(dy_), n, h, w, ch, P(dsc), P(dsh), P(skip), P(pooled)))
+    np.testing.assert_allclose(skip.numpy(), nhwc(a.detach()), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pooled.numpy(), nhwc(p.detach()), rtol=0, atol=1e-6)
+    da = c.empty((n, h, w, ch))
+    dsk, dpl = c.to_device(nhwc(dskip)), c.to_device(nhwc(dpool))
+    check(lib.rfi_op_pool_bwd_merge(c.handle, P(dy_), n, h, w, ch, P(dsc), P(dsh), P(dsk), P(dpl), P(da)))
+    np.testing.assert_allclose(da.numpy(), nhwc(want_da), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("m,ch", [(2048, 32), (8192, 16), (32, 128), (100, 6), (65536, 64)])
+def test_bn_relu_backward(m, ch):
+    g = torch.Generator().manual_seed(m + ch)
+    y = (torch.randn(m, ch, generator=g) * (torch.rand(ch, generator=g) + 0.2) + torch.randn(ch, generator=g)).double()
+    gamma = (torch.rand(ch, generator=g) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(ch, generator=g) * 0.3).double().requires_grad_(True)
+    da = torch.randn(m, ch, generator=g).double()
+    yl = y.clone().requires_grad_(True)
+    mean, var = yl.mean(0), yl.var(0, unbiased=False)
+    act = torch.relu((yl - mean) / torch.sqrt(var + 1e-5) * gamma + beta)
+    (act * da).sum().backward()
+    c = ctx()
+    dda = c.to_device(da.float().numpy())
+    dy_, dg, db_ = c.to_device(y.float().numpy()), c.to_device(gamma.detach().float().numpy()), c.to_device(beta.detach().float().numpy())
+    og, ob, obias = c.empty((ch,)), c.empty((ch,)), c.empty((ch,))
+    check(lib.rfi_op_bn_relu_backward(c.handle, P(dy_), m, ch, P(dg), P(db_), P(dda), P(og), P(ob), P(obias)))
+    scale = float(yl.grad.abs().max())
+    bad = np.abs(dda.numpy() - yl.grad.numpy()) > 2e-5 * scale + 1e-7
+    assert bad.sum() <= 2, int(bad.sum())       # a ReLU input within fp32 rounding of 0 may flip its mask
+    np.testing.assert_allclose(og.numpy(), gamma.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ob.numpy(), beta.grad.numpy(), rtol=1e-4, atol=1e-4)
+    assert np.abs(obias.numpy()).max() <= 1e-3 * max(1.0, scale * m ** 0.5)
