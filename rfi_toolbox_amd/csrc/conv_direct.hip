@@ -33,7 +33,7 @@ __global__ void conv_direct_kernel(ConvArgs a) {
             const float* __restrict__ wp = w + ((size_t)tap * a.Cout + co) * a.Cin;
             if (a.xf.scale) {
                 for (int ci = 0; ci < a.Cin; ++ci) {
-                    float v = fmaf(xp[ci], a.xf.scale[ci], a.xf.shift[ci]);
+                    float v = xp[ci] * a.xf.scale[ci] + a.xf.shift[ci];
                     if (a.xf.relu) v = v > 0.0f ? v : 0.0f;
                     acc = fmaf(v, wp[ci], acc);
                 }
@@ -72,12 +72,12 @@ __global__ void wgrad_direct_kernel(WgradArgs a, int64_t pix_per_split, int64_t 
         if (iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx) {
             float xv = a.xop.p[(((int64_t)n * a.Hx + iy) * a.Wx + ix) * a.xop.pstride + cx];
             if (a.xf_x.scale) {
-                xv = fmaf(xv, sxs, sxh);
+                xv = xv * sxs + sxh;
                 if (a.xf_x.relu) xv = xv > 0.0f ? xv : 0.0f;
             }
             float yv = a.yop.p[m * a.yop.pstride + cy];
             if (a.xf_y.scale) {
-                yv = fmaf(yv, sys, syh);
+                yv = yv * sys + syh;
                 if (a.xf_y.relu) yv = yv > 0.0f ? yv : 0.0f;
             }
             acc = fmaf(xv, yv, acc);

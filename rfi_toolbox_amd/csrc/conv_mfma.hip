@@ -129,8 +129,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (h_off[it] >= 0 && cvalid) {
                 v = *reinterpret_cast<const f32x4*>(a.x.p + h_off[it] + c0);
                 if (a.xf.scale) {
-                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                    v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                    v = v * sc + sh;
                     if (a.xf.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);

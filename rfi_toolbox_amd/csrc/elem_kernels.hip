@@ -2,6 +2,9 @@
 // optimiser, layout changes.  gfx950 (wave64).  Reductions over pixels accumulate in fp64 per
 // thread (what torch's CPU BatchNorm does, acc_type<float> == double) and are two-stage
 // (per-block partials + a finishing launch) so every result is bitwise run-to-run reproducible.
+// BatchNorm-apply is x*scale + shift with the product and the sum rounded SEPARATELY (the build
+// uses -ffp-contract=off): torch's CPU kernel applies x*alpha+beta with a vector multiply and a
+// vector add, and the ReLU mask of elements at the threshold follows that rounding.
 #include "kernels.hpp"
 
 namespace rfi {
@@ -153,7 +156,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* 
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             const float yv = y[r * C + c];
-            const float dz = (fmaf(yv, sc, sh) > 0.0f) ? da[r * C + c] : 0.0f;
+            const float dz = (yv * sc + sh > 0.0f) ? da[r * C + c] : 0.0f;
             const float xh = (yv - mu) * is;
             s1 += (double)dz;
             s2 += (double)dz * (double)xh;
@@ -220,7 +223,7 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restr
         const float g = gamma[c] * is, k1 = c1[c], k2 = c2[c];
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             const float yv = y[r * C + c];
-            const float dz = (fmaf(yv, sc, sh) > 0.0f) ? da[r * C + c] : 0.0f;
+            const float dz = (yv * sc + sh > 0.0f) ? da[r * C + c] : 0.0f;
             const float xh = (yv - mu) * is;
             const float dy = g * (dz - k1 - xh * k2);
             da[r * C + c] = dy;
@@ -292,7 +295,7 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ y, int N, int H, i
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t pix = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
-            float a = fmaf(y[pix * C + c], sc, sh);
+            float a = y[pix * C + c] * sc + sh;
             a = a > 0.0f ? a : 0.0f;
             skip[pix * skip_ps + c] = a;
             best = (k == 0 || a > best) ? a : best;
@@ -314,7 +317,7 @@ __global__ void bn_relu_edge_kernel(const float* __restrict__ y, int N, int H, i
         const int x = (int)(pix % W);
         const int yy = (int)((pix / W) % H);
         if (yy >= He || x >= We) {
-            float a = fmaf(y[pix * C + c], scale[c], shift[c]);
+            float a = y[pix * C + c] * scale[c] + shift[c];
             skip[pix * skip_ps + c] = a > 0.0f ? a : 0.0f;
         }
     }
@@ -341,7 +344,7 @@ __global__ void pool_bwd_merge_kernel(const float* __restrict__ y, int N, int H,
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             pixk[k] = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
-            float a = fmaf(y[pixk[k] * C + c], sc, sh);
+            float a = y[pixk[k] * C + c] * sc + sh;
             a = a > 0.0f ? a : 0.0f;
             if (k == 0 || a > best) {
                 best = a;
@@ -381,7 +384,7 @@ __global__ void head_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
     for (int o = 0; o < Cout; ++o) {
         float acc = 0.0f;
         for (int c = lane16; c < C; c += 16) {
-            float a = fmaf(y[m * C + c], scale[c], shift[c]);
+            float a = y[m * C + c] * scale[c] + shift[c];
             a = a > 0.0f ? a : 0.0f;
             acc += a * w[o * C + c];
         }
@@ -490,7 +493,7 @@ __global__ void head_bwd_kernel(const float* __restrict__ y, int64_t M, int C, i
             const float sc = scale[c], sh = shift[c], wv = w[o * C + c];
             for (int64_t r = r0 + rl; r < r1; r += RL) {
                 const float d = dl[r * Cout + o];
-                float a = fmaf(y[r * C + c], sc, sh);
+                float a = y[r * C + c] * sc + sh;
                 a = a > 0.0f ? a : 0.0f;
                 sw += (double)d * (double)a;
                 sb += (double)d;

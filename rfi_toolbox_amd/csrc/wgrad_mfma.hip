@@ -144,8 +144,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
             if (a.xf_y.scale && (yvalid >> it & 1u)) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(s_cy + y_q[it] * 4);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(s_cy + BY + y_q[it] * 4);
-                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                    v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                v = v * sc + sh;
                 if (a.xf_y.relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                     v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -160,8 +159,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
             if (a.xf_x.scale && (xvalid >> it & 1u)) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(s_cx + x_q[it] * 4);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(s_cx + BX + x_q[it] * 4);
-                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                    v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                v = v * sc + sh;
                 if (a.xf_x.relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                     v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
