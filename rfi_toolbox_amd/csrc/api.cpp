@@ -233,18 +233,21 @@ int rfi_model_destroy(rfi_model* m) {
 namespace {
 
 // reference layout <-> library layout for one entry; host staging vectors
-void to_lib_conv(const float* oihw, int cout, int cin, int R, std::vector<float>& out) {
-    out.resize((size_t)R * R * cout * cin);
+// cin_p >= cin: library rows are zero-padded to cin_p input channels
+void to_lib_conv(const float* oihw, int cout, int cin, int R, std::vector<float>& out, int cin_p = -1) {
+    if (cin_p < 0) cin_p = cin;
+    out.assign((size_t)R * R * cout * cin_p, 0.0f);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < R * R; ++t)
-                out[((size_t)t * cout + co) * cin + ci] = oihw[((size_t)co * cin + ci) * R * R + t];
+                out[((size_t)t * cout + co) * cin_p + ci] = oihw[((size_t)co * cin + ci) * R * R + t];
 }
-void from_lib_conv(const float* lib, int cout, int cin, int R, float* oihw) {
+void from_lib_conv(const float* lib, int cout, int cin, int R, float* oihw, int cin_p = -1) {
+    if (cin_p < 0) cin_p = cin;
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < R * R; ++t)
-                oihw[((size_t)co * cin + ci) * R * R + t] = lib[((size_t)t * cout + co) * cin + ci];
+                oihw[((size_t)co * cin + ci) * R * R + t] = lib[((size_t)t * cout + co) * cin_p + ci];
 }
 // ConvTranspose2d weight is [cin][cout][2][2]
 void to_lib_convt(const float* iohw, int cin, int cout, std::vector<float>& out) {
@@ -300,10 +303,11 @@ void store_from_flat(rfi_model* m, const float* flat, const Entry& e, void* host
                 "size mismatch for " + e.name + ": expected " + std::to_string(e.numel() * 4) + " bytes, got " +
                     std::to_string(bytes));
     const size_t off = flat_offset(m, e);
-    std::vector<float> tmp((size_t)e.numel());
+    const int cin_p = e.kind == 0 ? m->convs[e.layer].cin_p : 0;
+    std::vector<float> tmp(e.kind == 0 ? (size_t)9 * e.dims[0] * cin_p : (size_t)e.numel());
     download(m, tmp.data(), flat + off, tmp.size());
     float* out = static_cast<float*>(host);
-    if (e.kind == 0) from_lib_conv(tmp.data(), (int)e.dims[0], (int)e.dims[1], 3, out);
+    if (e.kind == 0) from_lib_conv(tmp.data(), (int)e.dims[0], (int)e.dims[1], 3, out, cin_p);
     else if (e.kind == 1) from_lib_convt(tmp.data(), (int)e.dims[0], (int)e.dims[1], out);
     else std::memcpy(out, tmp.data(), bytes);
 }
@@ -325,7 +329,13 @@ int rfi_model_init(rfi_model* m, uint64_t seed) {
                 const double fan_in = (double)e.dims[1] * e.dims[2] * e.dims[3];
                 last_bound = (float)(1.0 / std::sqrt(fan_in));
                 float* w = flat.data() + flat_offset(m, e);
-                for (int64_t i = 0; i < e.numel(); ++i) w[i] = uni(last_bound);   // layout-agnostic iid
+                if (e.kind == 0) {                      // [tap][cout][cin_p], padded channels stay 0
+                    const int cin_p = m->convs[e.layer].cin_p, cin = (int)e.dims[1];
+                    for (int64_t r = 0; r < 9 * e.dims[0]; ++r)
+                        for (int ci = 0; ci < cin; ++ci) w[r * cin_p + ci] = uni(last_bound);
+                } else {
+                    for (int64_t i = 0; i < e.numel(); ++i) w[i] = uni(last_bound);   // layout-agnostic iid
+                }
             } else if (e.kind == 2) {
                 float* v = flat.data() + flat_offset(m, e);
                 for (int64_t i = 0; i < e.numel(); ++i)
@@ -385,7 +395,7 @@ int rfi_model_load_entry(rfi_model* m, const char* name, const void* host, size_
             return;
         }
         std::vector<float> tmp;
-        if (e.kind == 0) to_lib_conv(src, (int)e.dims[0], (int)e.dims[1], 3, tmp);
+        if (e.kind == 0) to_lib_conv(src, (int)e.dims[0], (int)e.dims[1], 3, tmp, m->convs[e.layer].cin_p);
         else if (e.kind == 1) to_lib_convt(src, (int)e.dims[0], (int)e.dims[1], tmp);
         else tmp.assign(src, src + e.numel());
         upload(m, m->params + flat_offset(m, e), tmp.data(), tmp.size());

@@ -290,7 +290,8 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
         launch_conv_direct(ctx, a);
         return;
     }
-    const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.R * a.R * a.Cin * a.zgroups;
+    const double flops = a.algo_flops >= 0 ? a.algo_flops
+                                           : 2.0 * a.N * a.H * a.W * (double)a.Cout * a.R * a.R * a.Cin * a.zgroups;
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0);
     if (a.R == 3) dispatch_tiles<3, 1>(ctx, a);
     else if (a.R == 1) dispatch_tiles<1, 1>(ctx, a);

@@ -22,18 +22,21 @@ __device__ __forceinline__ double wave_sum(double v) {
 // channel-lane geometry shared by the per-channel reductions over a [M][C] tensor:
 // a block = CL channel lanes x RL row lanes (CL*RL == 256), grid = (row blocks, channel blocks)
 struct ChanGeom {
+    int V;                 // channels per lane: 4 (float4 loads) when C % 4 == 0, else 1
     int CL, RL, cblocks;
     int64_t rows_per_block;
     int rblocks;
 };
 
-static ChanGeom chan_geom(int64_t M, int C, int max_rblocks) {
+static ChanGeom chan_geom(int64_t M, int C, int max_rblocks, bool allow_vec = true) {
     ChanGeom g;
-    int cl = 4;
-    while (cl < C && cl < 64) cl <<= 1;
+    g.V = (allow_vec && C % 4 == 0) ? 4 : 1;
+    const int lanes_needed = C / g.V;
+    int cl = (g.V == 4) ? 1 : 4;
+    while (cl < lanes_needed && cl < 64) cl <<= 1;
     g.CL = cl;
     g.RL = kBlock / cl;
-    g.cblocks = (int)cdiv(C, cl);
+    g.cblocks = (int)cdiv(lanes_needed, cl);
     int64_t rpb = cdiv(M, max_rblocks);
     int64_t min_rows = (int64_t)g.RL * 8;
     if (rpb < min_rows) rpb = min_rows;
@@ -43,35 +46,77 @@ static ChanGeom chan_geom(int64_t M, int C, int max_rblocks) {
     return g;
 }
 
+// V consecutive channels per lane (V = 4: one 16-byte load per row and lane)
+template <int V>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = p[0];
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const float (&v)[V]) {
+    if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else p[0] = v[0];
+}
+// block-level sum over the RL row lanes of NQ per-lane quantities of V channels each;
+// lane rl == 0 ends up with the totals in acc.  red: NQ * V * 256 doubles of LDS.
+template <int V, int NQ>
+__device__ __forceinline__ void row_lane_reduce(double (&acc)[NQ][V], double* red, int CL, int RL, int cl,
+                                                int rl) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int v = 0; v < V; ++v) red[(q * V + v) * kBlock + threadIdx.x] = acc[q][v];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                double t = acc[q][v];
+                for (int k = 1; k < RL; ++k) t += red[(q * V + v) * kBlock + k * CL + cl];
+                acc[q][v] = t;
+            }
+    }
+}
+
 // ------------------------------------------------------------------ batch-norm statistics
 // partial[(rb*C + c)*2 + {0,1}] = sum x, sum x^2 over the block's rows (double)
+template <int V>
 __global__ void bn_stats_kernel(const float* __restrict__ y, int64_t M, int C, int CL,
                                 int64_t rows_per_block, double* __restrict__ partial) {
-    __shared__ double red[2 * kBlock];
+    __shared__ double red[2 * V * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
-    const int c = blockIdx.y * CL + cl;
+    const int c = (blockIdx.y * CL + cl) * V;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    double s1 = 0, s2 = 0;
+    double acc[2][V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[0][v] = acc[1][v] = 0;
     if (c < C) {
         for (int64_t r = r0 + rl; r < r1; r += RL) {
-            double v = (double)y[r * C + c];
-            s1 += v;
-            s2 += v * v;
+            float x[V];
+            ldv<V>(y + r * C + c, x);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double d = (double)x[v];
+                acc[0][v] += d;
+                acc[1][v] += d * d;
+            }
         }
     }
-    red[threadIdx.x] = s1;
-    red[kBlock + threadIdx.x] = s2;
-    __syncthreads();
+    row_lane_reduce<V, 2>(acc, red, CL, RL, cl, rl);
     if (rl == 0 && c < C) {
-        for (int k = 1; k < RL; ++k) {
-            s1 += red[k * CL + cl];
-            s2 += red[kBlock + k * CL + cl];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            partial[((int64_t)blockIdx.x * C + c + v) * 2 + 0] = acc[0][v];
+            partial[((int64_t)blockIdx.x * C + c + v) * 2 + 1] = acc[1][v];
         }
-        partial[((int64_t)blockIdx.x * C + c) * 2 + 0] = s1;
-        partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = s2;
     }
 }
 
@@ -139,39 +184,45 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
 
 // ------------------------------------------------------------------ batch-norm backward
 // partial[(rb*C+c)*2 + {0,1}] = sum dz, sum dz*xhat;  dz = da * (y*scale+shift > 0)
+template <int V>
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ y,
                                      int64_t M, int C, int CL, int64_t rows_per_block,
                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                      double* __restrict__ partial) {
-    __shared__ double red[2 * kBlock];
+    __shared__ double red[2 * V * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
-    const int c = blockIdx.y * CL + cl;
+    const int c = (blockIdx.y * CL + cl) * V;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    double s1 = 0, s2 = 0;
+    double acc[2][V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[0][v] = acc[1][v] = 0;
     if (c < C) {
-        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        float sc[V], sh[V], mu[V], is[V];
+        ldv<V>(scale + c, sc); ldv<V>(shift + c, sh); ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
         for (int64_t r = r0 + rl; r < r1; r += RL) {
-            const float yv = y[r * C + c];
-            const float dz = (yv * sc + sh > 0.0f) ? da[r * C + c] : 0.0f;
-            const float xh = (yv - mu) * is;
-            s1 += (double)dz;
-            s2 += (double)dz * (double)xh;
+            float yv[V], dv[V];
+            ldv<V>(y + r * C + c, yv);
+            ldv<V>(da + r * C + c, dv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float dz = (yv[v] * sc[v] + sh[v] > 0.0f) ? dv[v] : 0.0f;
+                const float xh = (yv[v] - mu[v]) * is[v];
+                acc[0][v] += (double)dz;
+                acc[1][v] += (double)dz * (double)xh;
+            }
         }
     }
-    red[threadIdx.x] = s1;
-    red[kBlock + threadIdx.x] = s2;
-    __syncthreads();
+    row_lane_reduce<V, 2>(acc, red, CL, RL, cl, rl);
     if (rl == 0 && c < C) {
-        for (int k = 1; k < RL; ++k) {
-            s1 += red[k * CL + cl];
-            s2 += red[kBlock + k * CL + cl];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            partial[((int64_t)blockIdx.x * C + c + v) * 2 + 0] = acc[0][v];
+            partial[((int64_t)blockIdx.x * C + c + v) * 2 + 1] = acc[1][v];
         }
-        partial[((int64_t)blockIdx.x * C + c) * 2 + 0] = s1;
-        partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = s2;
     }
 }
 
@@ -204,37 +255,47 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int r
 }
 
 // in place: da <- dy;  partial[rb*C+c] = sum dy (double)
+template <int V>
 __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restrict__ y, int64_t M,
                                     int C, int CL, int64_t rows_per_block,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ c1,
                                     const float* __restrict__ c2, double* __restrict__ partial) {
-    __shared__ double red[kBlock];
+    __shared__ double red[V * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
-    const int c = blockIdx.y * CL + cl;
+    const int c = (blockIdx.y * CL + cl) * V;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    double s = 0;
+    double acc[1][V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[0][v] = 0;
     if (c < C) {
-        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-        const float g = gamma[c] * is, k1 = c1[c], k2 = c2[c];
+        float sc[V], sh[V], mu[V], is[V], g[V], k1[V], k2[V];
+        ldv<V>(scale + c, sc); ldv<V>(shift + c, sh); ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
+        ldv<V>(gamma + c, g); ldv<V>(c1 + c, k1); ldv<V>(c2 + c, k2);
+#pragma unroll
+        for (int v = 0; v < V; ++v) g[v] = g[v] * is[v];
         for (int64_t r = r0 + rl; r < r1; r += RL) {
-            const float yv = y[r * C + c];
-            const float dz = (yv * sc + sh > 0.0f) ? da[r * C + c] : 0.0f;
-            const float xh = (yv - mu) * is;
-            const float dy = g * (dz - k1 - xh * k2);
-            da[r * C + c] = dy;
-            s += (double)dy;
+            float yv[V], dv[V], o[V];
+            ldv<V>(y + r * C + c, yv);
+            ldv<V>(da + r * C + c, dv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float dz = (yv[v] * sc[v] + sh[v] > 0.0f) ? dv[v] : 0.0f;
+                const float xh = (yv[v] - mu[v]) * is[v];
+                o[v] = g[v] * (dz - k1[v] - xh * k2[v]);
+                acc[0][v] += (double)o[v];
+            }
+            stv<V>(da + r * C + c, o);
         }
     }
-    red[threadIdx.x] = s;
-    __syncthreads();
+    row_lane_reduce<V, 1>(acc, red, CL, RL, cl, rl);
     if (rl == 0 && c < C) {
-        for (int k = 1; k < RL; ++k) s += red[k * CL + cl];
-        partial[(int64_t)blockIdx.x * C + c] = s;
+#pragma unroll
+        for (int v = 0; v < V; ++v) partial[(int64_t)blockIdx.x * C + c + v] = acc[0][v];
     }
 }
 
@@ -256,23 +317,30 @@ __global__ void finish_channel_sum_kernel(const double* __restrict__ partial, in
     }
 }
 
-__global__ void channel_sum_kernel(const float* __restrict__ v, int pstride, int64_t M, int C, int CL,
+template <int V>
+__global__ void channel_sum_kernel(const float* __restrict__ v_, int pstride, int64_t M, int C, int CL,
                                    int64_t rows_per_block, double* __restrict__ partial) {
-    __shared__ double red[kBlock];
+    __shared__ double red[V * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
-    const int c = blockIdx.y * CL + cl;
+    const int c = (blockIdx.y * CL + cl) * V;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    double s = 0;
+    double acc[1][V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[0][v] = 0;
     if (c < C)
-        for (int64_t r = r0 + rl; r < r1; r += RL) s += (double)v[r * pstride + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            float x[V];
+            ldv<V>(v_ + r * pstride + c, x);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[0][v] += (double)x[v];
+        }
+    row_lane_reduce<V, 1>(acc, red, CL, RL, cl, rl);
     if (rl == 0 && c < C) {
-        for (int k = 1; k < RL; ++k) s += red[k * CL + cl];
-        partial[(int64_t)blockIdx.x * C + c] = s;
+#pragma unroll
+        for (int v = 0; v < V; ++v) partial[(int64_t)blockIdx.x * C + c + v] = acc[0][v];
     }
 }
 
@@ -563,6 +631,15 @@ __global__ void weight_to_dgrad_kernel(const float* __restrict__ wf, int taps, i
         wd[i] = wf[((int64_t)ts * Cout + co) * Cin + ci];
     }
 }
+__global__ void pad_channels_kernel(const float* __restrict__ s, int64_t M, int c, int cp,
+                                    float* __restrict__ d) {
+    const int64_t total = M * cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % cp);
+        d[i] = k < c ? s[(i / cp) * c + k] : 0.0f;
+    }
+}
 __global__ void u8_to_f32_kernel(const uint8_t* __restrict__ s, int64_t n, float* __restrict__ d) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
@@ -660,13 +737,19 @@ constexpr int kMaxRowBlocks = 1024;
 size_t bn_stats_ws_floats(int C) { return (size_t)kMaxRowBlocks * C * 2 * 2; }
 
 // records actually used for (M, C)
-static ChanGeom geom_rows(int64_t M, int C) { return chan_geom(M, C, kMaxRowBlocks); }
+static ChanGeom geom_rows(int64_t M, int C, bool allow_vec = true) {
+    return chan_geom(M, C, kMaxRowBlocks, allow_vec);
+}
 
 void launch_bn_stats(rfi_ctx* ctx, const float* y, int64_t M, int C, float* partial_ws) {
     ChanGeom g = geom_rows(M, C);
     ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 4);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y, M,
-                       C, g.CL, g.rows_per_block, reinterpret_cast<double*>(partial_ws));
+    if (g.V == 4)
+        hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y, M,
+                           C, g.CL, g.rows_per_block, reinterpret_cast<double*>(partial_ws));
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y, M,
+                           C, g.CL, g.rows_per_block, reinterpret_cast<double*>(partial_ws));
     check_launch("bn_stats");
 }
 
@@ -703,9 +786,14 @@ void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t
     ChanGeom g = geom_rows(M, C);
     {
         ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 8);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
-                           ctx->stream, da, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
-                           reinterpret_cast<double*>(partial_ws));
+        if (g.V == 4)
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
+                               ctx->stream, da, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
+                               reinterpret_cast<double*>(partial_ws));
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
+                               ctx->stream, da, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
+                               reinterpret_cast<double*>(partial_ws));
         check_launch("bn_bwd_reduce");
     }
     {
@@ -724,9 +812,14 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t 
     ChanGeom g = geom_rows(M, C);
     {
         ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 12);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
-                           da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
-                           c1, c2, reinterpret_cast<double*>(partial_ws));
+        if (g.V == 4)
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
+                               da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
+                               c1, c2, reinterpret_cast<double*>(partial_ws));
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
+                               da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
+                               c1, c2, reinterpret_cast<double*>(partial_ws));
         check_launch("bn_bwd_apply");
     }
     if (dbias) {
@@ -743,9 +836,16 @@ size_t channel_sum_ws_floats(int64_t M, int C) {
 }
 void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out) {
     ChanGeom g = geom_rows(M, C);
+    const bool vec = g.V == 4 && v.pstride % 4 == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0;
+    if (!vec && g.V == 4) g = geom_rows(M, C, false);   // unaligned view: scalar lanes
     {
         ProfScope ps(ctx, FAM_REDUCE, 0, (double)M * C * 4);
-        hipLaunchKernelGGL(channel_sum_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
+        if (g.V == 4)
+            hipLaunchKernelGGL(channel_sum_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
+                               v.p, v.pstride, M, C, g.CL, g.rows_per_block,
+                               reinterpret_cast<double*>(partial_ws));
+        else
+            hipLaunchKernelGGL(channel_sum_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
                            v.p, v.pstride, M, C, g.CL, g.rows_per_block,
                            reinterpret_cast<double*>(partial_ws));
         check_launch("channel_sum");
@@ -837,7 +937,7 @@ size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
 void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
                      const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                      float* partial_ws, float* dw, float* db) {
-    ChanGeom g = geom_rows(M, C);
+    ChanGeom g = geom_rows(M, C, false);   // the head kernel is one channel per lane
     {
         ProfScope ps(ctx, FAM_ELEMWISE, 4.0 * M * C * Cout, (double)M * C * 8);
         hipLaunchKernelGGL(head_bwd_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
@@ -886,6 +986,12 @@ void launch_weight_to_dgrad(rfi_ctx* ctx, const float* wf, int taps, int Cout, i
     hipLaunchKernelGGL(weight_to_dgrad_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, wf,
                        taps, Cout, Cin, flip, wd);
     check_launch("weight_to_dgrad");
+}
+void launch_pad_channels(rfi_ctx* ctx, const float* src, int64_t M, int c, int cp, float* dst) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * (c + cp) * 4);
+    hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for(M * cp)), dim3(kBlock), 0, ctx->stream, src, M, c,
+                       cp, dst);
+    check_launch("pad_channels");
 }
 void launch_u8_to_f32(rfi_ctx* ctx, const uint8_t* src, int64_t n, float* dst) {
     ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * 5);

@@ -47,6 +47,7 @@ struct ConvArgs {
     int R = 3, S = 1, pad = 1;
     int zgroups = 1;                  // convT fwd: 4 (a,b) groups: w += z*Cout*Cin, (ooy,oox) = (z/2, z%2)
     InXform xf;
+    double algo_flops = -1;           // algorithmic FLOPs for the profile (default: from the shape)
 };
 
 enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2 };
@@ -71,6 +72,7 @@ struct WgradArgs {
     int sy = 0, sx = 0;
     float* slab = nullptr;            // workspace for split partials
     size_t slab_floats = 0;
+    double algo_flops = -1;
 };
 size_t wgrad_slab_floats(const WgradArgs& a, int impl);
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);
@@ -139,6 +141,8 @@ void launch_nhwc_to_nchw(rfi_ctx* ctx, const float* src, int N, int C, int H, in
 void launch_weight_to_dgrad(rfi_ctx* ctx, const float* wf, int taps, int Cout, int Cin, int flip,
                             float* wd);
 void launch_u8_to_f32(rfi_ctx* ctx, const uint8_t* src, int64_t n, float* dst);
+// dst[m][0..cp) = src[m][0..c) followed by zeros (channel padding of the network input to a multiple of 4)
+void launch_pad_channels(rfi_ctx* ctx, const float* src, int64_t M, int c, int cp, float* dst);
 
 // ---------------------------------------------------------------- optimiser
 // sum of squares of g[0..n) -> *sumsq (double), deterministic two-stage

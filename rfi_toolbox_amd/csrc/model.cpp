@@ -63,14 +63,17 @@ void rfi_model::build() {
         c.conv_name = prefix + "." + std::to_string(conv_idx);
         c.bn_name = prefix + "." + std::to_string(bn_idx);
         c.cin = cin;
+        // only the network input can be padded (its staging buffer is ours); inner layers read
+        // tensors whose pixel stride is the true channel count
+        c.cin_p = convs.empty() ? (int)align4((size_t)cin) : cin;
         c.cout = cout;
         c.ema_repeats = ema;
-        c.w_off = off; off = align4(off + (size_t)9 * cin * cout);
+        c.w_off = off; off = align4(off + (size_t)9 * c.cin_p * cout);
         c.b_off = off; off = align4(off + cout);
         c.g_off = off; off = align4(off + cout);
         c.be_off = off; off = align4(off + cout);
         chan_floats += align4((size_t)8 * cout);
-        wd_floats += align4((size_t)9 * cin * cout);
+        wd_floats += align4((size_t)9 * c.cin_p * cout);
         convs.push_back(c);
     };
     int cin = in_ch;
@@ -172,14 +175,14 @@ void rfi_model::build() {
     for (int l = 1; l <= 2 * D + 2; ++l) {   // encoder + bottleneck convs
         ConvBN& c = convs[conv_i++];
         c.chan = chan_pool + co; co += align4((size_t)8 * c.cout);
-        c.wd = wd_pool + wo; wo += align4((size_t)9 * c.cin * c.cout);
+        c.wd = wd_pool + wo; wo += align4((size_t)9 * c.cin_p * c.cout);
     }
     for (int k = 0; k < D; ++k) {
         ups[k].wd = wd_pool + wo; wo += align4((size_t)4 * ups[k].cin * ups[k].cout);
         for (int j = 0; j < 2; ++j) {
             ConvBN& c = convs[conv_i++];
             c.chan = chan_pool + co; co += align4((size_t)8 * c.cout);
-            c.wd = wd_pool + wo; wo += align4((size_t)9 * c.cin * c.cout);
+            c.wd = wd_pool + wo; wo += align4((size_t)9 * c.cin_p * c.cout);
         }
     }
     adam_step = 0;
@@ -203,7 +206,7 @@ void rfi_model::prepare(int n, int h, int w) {
         mk(gA); mk(gB); mk(dconcat); mk(dpool);
         bottY1 = new_buf(); bottY2 = new_buf(); gBottA = new_buf(); gBottB = new_buf();
         logits = new_buf(); dlogits = new_buf();
-        x_stage = new_buf(); x_stage2 = new_buf(); out_stage = new_buf();
+        x_stage = new_buf(); x_stage2 = new_buf(); x_pad = new_buf(); out_stage = new_buf();
         ws_red = new_buf(); ws_slab = new_buf(); lab_stage = new_buf();
     }
     size_t slab_need = 0, red_need = 0;
@@ -227,6 +230,7 @@ void rfi_model::prepare(int n, int h, int w) {
     bufs[dlogits].ensure(ctx, M1 * out_ch);
     bufs[x_stage].ensure(ctx, M1 * in_ch);
     bufs[x_stage2].ensure(ctx, M1 * in_ch);
+    bufs[x_pad].ensure(ctx, M1 * convs[0].cin_p);
     bufs[out_stage].ensure(ctx, M1 * out_ch);
     bufs[lab_stage].ensure(ctx, (M1 + 3) / 4 + 4);
     // workspaces
@@ -253,7 +257,7 @@ void rfi_model::prepare(int n, int h, int w) {
         conv_geom((int)ci, H, W);
         WgradArgs a;
         a.N = n; a.H = H; a.W = W; a.Hx = H; a.Wx = W;
-        a.Cx = convs[ci].cin; a.Cy = convs[ci].cout;
+        a.Cx = convs[ci].cin_p; a.Cy = convs[ci].cout;
         a.xop.pstride = a.Cx; a.yop.pstride = a.Cy;
         a.R = 3; a.S = 1; a.pad = 1;
         a.tap_stride = (int64_t)a.Cx * a.Cy;
@@ -275,7 +279,7 @@ void rfi_model::prepare(int n, int h, int w) {
 
 void rfi_model::refresh_dgrad_weights() {
     if (!wd_dirty) return;
-    for (auto& c : convs) launch_weight_to_dgrad(ctx, params + c.w_off, 9, c.cout, c.cin, 1, c.wd);
+    for (auto& c : convs) launch_weight_to_dgrad(ctx, params + c.w_off, 9, c.cout, c.cin_p, 1, c.wd);
     for (auto& u : ups) launch_weight_to_dgrad(ctx, params + u.w_off, 4, u.cout, u.cin, 0, u.wd);
     wd_dirty = false;
 }
@@ -289,13 +293,14 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
     ConvArgs a;
     a.x = in;
     a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
-    a.Cin = c.cin; a.Cout = c.cout;
+    a.Cin = c.cin_p; a.Cout = c.cout;
     a.w = m->params + c.w_off;
     a.bias = m->params + c.b_off;
     a.y = MutView{Y, c.cout};
     a.Hout = s.H; a.Wout = s.W;
     a.R = 3; a.S = 1; a.pad = 1;
     a.xf = xf;
+    a.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
     launch_conv(m->ctx, a);
     const int64_t M = (int64_t)s.N * s.H * s.W;
     if (train) {
@@ -315,10 +320,19 @@ InXform bn_xf(const ConvBN& c) { return InXform{c.scale(), c.shift(), 1}; }
 
 }  // namespace
 
+// the first conv sees the input with its channels zero-padded to a multiple of 4 (16-byte pixels),
+// so the 3-channel stem runs on the same MFMA kernels as every other layer
+rfi::View rfi_model::network_input(const float* x_dev, int n, int h, int w) {
+    const int cp = convs[0].cin_p;
+    if (cp == in_ch) return View{x_dev, in_ch};
+    launch_pad_channels(ctx, x_dev, (int64_t)n * h * w, in_ch, cp, buf(x_pad));
+    return View{buf(x_pad), cp};
+}
+
 void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode) {
     prepare(n, h, w);
     const int D = depth;
-    View cur{x_dev, in_ch};
+    View cur = network_input(x_dev, n, h, w);
     for (int l = 1; l <= D; ++l) {
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
@@ -395,11 +409,12 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
     wa.yop = View{dA, c.cout};
     wa.xf_x = in_xf;
     wa.N = s.N; wa.H = s.H; wa.W = s.W; wa.Hx = s.H; wa.Wx = s.W;
-    wa.Cx = c.cin; wa.Cy = c.cout;
+    wa.Cx = c.cin_p; wa.Cy = c.cout;
     wa.R = 3; wa.S = 1; wa.pad = 1;
     wa.dw = m->grads + c.w_off;
-    wa.tap_stride = (int64_t)c.cin * c.cout;
-    wa.sy = c.cin; wa.sx = 1;
+    wa.tap_stride = (int64_t)c.cin_p * c.cout;
+    wa.sy = c.cin_p; wa.sx = 1;
+    wa.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
     wa.slab = m->buf(m->ws_slab);
     wa.slab_floats = m->bufs[m->ws_slab].n;
     launch_wgrad(ctx, wa);
@@ -407,7 +422,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
         ConvArgs a;
         a.x = View{dA, c.cout};
         a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
-        a.Cin = c.cout; a.Cout = c.cin;
+        a.Cin = c.cout; a.Cout = c.cin;     // dx exists only for layers whose cin == cin_p
         a.w = c.wd;
         a.bias = nullptr;
         a.y = MutView{dx, c.cin};
@@ -493,7 +508,8 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
                               View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]));
         backward_conv_bn(this, c2, buf(gA[l]), buf(encY2[l]), View{buf(encY1[l]), c1.cout}, bn_xf(c1), s,
                          buf(gB[l]), 0);
-        View in = (l == 1) ? View{x_dev, in_ch} : View{buf(pool[l - 1]), c1.cin};
+        View in = (l == 1) ? (c1.cin_p == in_ch ? View{x_dev, in_ch} : View{buf(x_pad), c1.cin_p})
+                           : View{buf(pool[l - 1]), c1.cin};
         backward_conv_bn(this, c1, buf(gB[l]), buf(encY1[l]), in, InXform{}, s,
                          (l == 1) ? nullptr : buf(dpool[l - 1]), 0);
     }

@@ -16,6 +16,7 @@ struct DevBuf {
 struct ConvBN {
     std::string conv_name, bn_name;     // e.g. "encoder1.conv.conv.0", "encoder1.conv.conv.1"
     int cin = 0, cout = 0;
+    int cin_p = 0;                      // cin rounded up to a multiple of 4 (library layout; zero padded)
     size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;   // offsets into the flat param/grad buffers
     int ema_repeats = 1;
     int64_t nbt = 0;                    // num_batches_tracked (host side)
@@ -29,7 +30,7 @@ struct ConvBN {
     float* shift() const { return chan + 5 * cout; }
     float* c1() const { return chan + 6 * cout; }
     float* c2() const { return chan + 7 * cout; }
-    float* wd = nullptr;                // dgrad-layout copy of the weight [9][cin][cout]
+    float* wd = nullptr;                // dgrad-layout copy of the weight [9][cin_p][cout]
 };
 
 // ConvTranspose2d(k2,s2)+bias
@@ -82,7 +83,7 @@ struct rfi_model {
     // indices into bufs
     std::vector<int> encY1, encY2, concat, pool, decY1, decY2, gA, gB, dconcat, dpool;
     int bottY1 = -1, bottY2 = -1, gBottA = -1, gBottB = -1, logits = -1, dlogits = -1;
-    int x_stage = -1, x_stage2 = -1, out_stage = -1, ws_red = -1, ws_slab = -1, lab_stage = -1;
+    int x_stage = -1, x_stage2 = -1, x_pad = -1, out_stage = -1, ws_red = -1, ws_slab = -1, lab_stage = -1;
     double* d_sums = nullptr;         // [0..3] loss sums, [4] grad sumsq
     float* d_scalars = nullptr;       // [0] loss, [1] grad norm
     float last_loss = 0, last_norm = 0;
@@ -93,6 +94,7 @@ struct rfi_model {
     int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
 
     void refresh_dgrad_weights();
+    rfi::View network_input(const float* x_dev, int n, int h, int w);
     void forward(const float* x_dev, int n, int h, int w, bool train_mode);
     void loss_forward(const uint8_t* labels_dev, int n, int h, int w);
     void backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w);

@@ -35,7 +35,10 @@ struct WCfg {
     static constexpr int KSTEPS = BM / 2 / WP;              // k-steps (2 pixels each) per wave per tile
     static constexpr int Y_ITEMS = (BM * (BY / 4) + 255) / 256;
     static constexpr int X_ITEMS = (HP * (BX / 4) + 255) / 256;
-    static constexpr int LDS_FLOATS = BM * BYP + HP * BXP + 2 * BY + 2 * BX;
+    static constexpr int TC = (NTAP % 3 == 0) ? 3 : NTAP;  // taps per cross-wave reduction round
+    static constexpr int STAGE_FLOATS = BM * BYP + HP * BXP + 2 * BY + 2 * BX;
+    static constexpr int RED_FLOATS = (WP > 1) ? BLOCKS * TC * 1024 : 0;
+    static constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
     static_assert(BLOCKS == 1 || BLOCKS == 2 || BLOCKS == 4, "1, 2 or 4 channel blocks");
     static_assert((BM / 2) % WP == 0, "pixels must split evenly over waves");
 };
@@ -206,16 +209,45 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         }
     }
 
-    // ---- write this wave's partial: rows (reg) = cy, cols (lane&31) = cx
-    float* slab = a.slab + (size_t)(split * C::WP + ps) * d.slab_stride;
-    const int cx = cx0 + bx * 32 + li;
+    // ---- waves that split the tile's pixels (WP > 1) first add their accumulators together through
+    // LDS (the staging area is free now: the tile loop ended on a barrier), TC taps at a time, so a
+    // workgroup always emits exactly one partial slab
+    if constexpr (C::WP > 1) {
+        constexpr int TC = C::TC;                                  // 3 x 4 KB (R=3) or 4 x 4 KB (R=2) per block
+        float* s_red = smem + blk * TC * 1024;
 #pragma unroll
-    for (int tap = 0; tap < C::NTAP; ++tap) {
+        for (int t0 = 0; t0 < C::NTAP; t0 += TC) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cy = cy0 + by * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (cy < a.Cy && cx < a.Cx)
-                slab[(int64_t)tap * a.tap_stride + (int64_t)cy * a.sy + (int64_t)cx * a.sx] = acc[tap][r];
+            for (int w = 1; w < C::WP; ++w) {
+                __syncthreads();
+                if (ps == w) {
+#pragma unroll
+                    for (int t = 0; t < TC; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s_red[(t * 16 + r) * 64 + lane] = acc[t0 + t][r];
+                }
+                __syncthreads();
+                if (ps == 0) {
+#pragma unroll
+                    for (int t = 0; t < TC; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t0 + t][r] += s_red[(t * 16 + r) * 64 + lane];
+                }
+            }
+        }
+    }
+    // ---- write the workgroup's partial: rows (reg) = cy, cols (lane&31) = cx
+    if (ps == 0) {
+        float* slab = a.slab + (size_t)split * d.slab_stride;
+        const int cx = cx0 + bx * 32 + li;
+#pragma unroll
+        for (int tap = 0; tap < C::NTAP; ++tap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cy = cy0 + by * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cy < a.Cy && cx < a.Cx)
+                    slab[(int64_t)tap * a.tap_stride + (int64_t)cy * a.sy + (int64_t)cx * a.sx] = acc[tap][r];
+            }
         }
     }
 }
@@ -235,7 +267,7 @@ Plan plan_cfg(const WgradArgs& a, int cus) {
     if (nsplit < 1) nsplit = 1;
     Plan p;
     p.nsplit = nsplit;
-    p.wp = C::WP;
+    p.wp = 1;                     // pixel-split waves are summed inside the workgroup
     p.slab_stride = (int64_t)C::NTAP * a.tap_stride;
     return p;
 }
@@ -257,7 +289,7 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
         attr_set = true;
     }
     {
-        const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cy * a.Cx * R * R;
+        const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cy * a.Cx * R * R;
         ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0);
         hipLaunchKernelGGL((wgrad_igemm_kernel<R, S, BY, BX, TH, TW>), grid, dim3(256), lds, ctx->stream, d);
         check_launch("wgrad_igemm");

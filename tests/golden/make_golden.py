@@ -230,6 +230,8 @@ def golden_unet_f8():
             ious[s] = evaluate_segmentation(pred, y)
             if s == 40:
                 rec["logits_eval40"] = lg.numpy().copy()
+                for k, v in sd_np(model).items():      # reference-TRAINED weights (inference parity)
+                    rec[f"state40/{k}"] = v
     rec = {k: v for k, v in rec.items() if not k.startswith("_")}
     rec.update(img=img, lab=lab, losses=np.array(losses), grad_norms=np.array(norms),
                iou_steps=np.array(sorted(ious)), iou=np.array([ious[s]["iou"] for s in sorted(ious)]),

@@ -192,6 +192,13 @@ def test_f8_step1_and_trajectory(golden_dir):
             ious[s] = metrics_ref.evaluate_segmentation(pred, y)["iou"]
     for s, want in zip(g["iou_steps"], g["iou"]):
         assert abs(ious[int(s)] - float(want)) <= 1e-3, (s, ious[int(s)], want)
+    # the reference-trained weights stored for the inference-parity test score the reference's IoU
+    st40 = _state(g, "state40")
+    with torch.no_grad():
+        lg = unet_ref.forward(st40, x, training=False)
+    np.testing.assert_allclose(lg.numpy(), g["logits_eval40"], rtol=0, atol=1e-5)
+    assert metrics_ref.evaluate_segmentation(unet_ref.predict_mask(lg), y)["iou"] == pytest.approx(
+        float(g["iou"][-1]), abs=1e-3)
 
 
 def test_unet_bigger_variant(golden_dir):
