@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-csv", default=None, help="write the per-launch HIP-event profile here")
     args = ap.parse_args()
 
     import torch
@@ -141,6 +142,8 @@ def main():
         ctx.synchronize()
         ctx.profile(False)
         fam = ctx.profile_report()
+        if args.launch_csv and rank == 0:
+            ctx.profile_dump(args.launch_csv)
     D.barrier()
 
     if rank != 0:

@@ -65,6 +65,8 @@ int rfi_profile_family_count(void);
 const char* rfi_profile_family_name(int family);
 int rfi_profile_get(rfi_ctx* ctx, int family, int64_t* launches, double* total_ms,
                     double* flops, double* bytes);
+/* every profiled launch in stream order as CSV (family, shape label, ms, GFLOP, TFLOP/s, MB, GB/s) */
+int rfi_profile_dump(rfi_ctx* ctx, const char* csv_path);
 
 /* ---- model: replaces rfi_toolbox.models.UNet (models/unet.py:41-77; UNetBigger :79-118
  *      is depth=5) as constructed by scripts/train_model.py:111, evaluate_model.py:34 ---- */

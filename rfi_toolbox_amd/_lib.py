@@ -59,6 +59,7 @@ _PROTOS = {
     "rfi_profile_family_count": (_i, []),
     "rfi_profile_family_name": (_cp, [_i]),
     "rfi_profile_get": (_i, [_vp, _i, _pi64, _pd, _pd, _pd]),
+    "rfi_profile_dump": (_i, [_vp, _cp]),
     "rfi_unet_create": (_i, [_vp, _i, _i, _i, _i, _pvp]),
     "rfi_model_destroy": (_i, [_vp]),
     "rfi_model_init": (_i, [_vp, C.c_uint64]),

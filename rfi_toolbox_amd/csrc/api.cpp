@@ -47,6 +47,7 @@ void rfi_ctx::drain_profile() {
         float ms = 0;
         RFI_CHECK_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
         fam[pe.family].ms += ms;
+        launches.push_back({pe.family, (double)ms, pe.flops, pe.bytes, pe.label});
         event_pool.push_back(pe.a);
         event_pool.push_back(pe.b);
     }
@@ -180,6 +181,22 @@ int rfi_profile_reset(rfi_ctx* ctx) {
         ctx->activate();
         ctx->drain_profile();
         for (auto& f : ctx->fam) f = FamilyStat();
+        ctx->launches.clear();
+    });
+}
+int rfi_profile_dump(rfi_ctx* ctx, const char* csv_path) {
+    return guarded([&] {
+        ctx->activate();
+        ctx->drain_profile();
+        FILE* f = std::fopen(csv_path, "w");
+        RFI_REQUIRE(f, std::string("cannot open ") + csv_path);
+        std::fprintf(f, "index,family,label,ms,gflop,tflops,mbytes,gbs\n");
+        int i = 0;
+        for (auto& l : ctx->launches)
+            std::fprintf(f, "%d,%s,%s,%.6f,%.4f,%.3f,%.3f,%.1f\n", i++, kFamilyNames[l.family], l.label.c_str(), l.ms,
+                         l.flops * 1e-9, l.ms > 0 ? l.flops / (l.ms * 1e-3) * 1e-12 : 0.0, l.bytes * 1e-6,
+                         l.ms > 0 ? l.bytes / (l.ms * 1e-3) * 1e-9 : 0.0);
+        std::fclose(f);
     });
 }
 int rfi_profile_family_count(void) { return FAM_COUNT; }

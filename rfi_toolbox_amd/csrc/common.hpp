@@ -72,6 +72,14 @@ struct FamilyStat {
 struct PendingEvent {
     hipEvent_t a, b;
     int family;
+    double flops, bytes;
+    std::string label;
+};
+
+struct LaunchRecord {        // one profiled launch, in stream order
+    int family;
+    double ms, flops, bytes;
+    std::string label;
 };
 
 }  // namespace rfi
@@ -87,6 +95,7 @@ struct rfi_ctx {
     bool profiling = false;
     rfi::FamilyStat fam[rfi::FAM_COUNT];
     std::vector<rfi::PendingEvent> pending;
+    std::vector<rfi::LaunchRecord> launches;
     std::vector<hipEvent_t> event_pool;
     // pinned scratch for small D2H readbacks
     float* pinned = nullptr;
@@ -108,20 +117,24 @@ struct ProfScope {
     rfi_ctx* c;
     int fam;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(rfi_ctx* ctx, int family, double flops = 0, double bytes = 0) : c(ctx), fam(family) {
+    double fl, by;
+    std::string label;
+    ProfScope(rfi_ctx* ctx, int family, double flops = 0, double bytes = 0, std::string lbl = std::string())
+        : c(ctx), fam(family), fl(flops), by(bytes) {
         if (c->profiling) {
+            label = std::move(lbl);
             a = c->get_event();
             b = c->get_event();
-            hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, c->stream);
             c->fam[fam].flops += flops;
             c->fam[fam].bytes += bytes;
         }
     }
     ~ProfScope() {
         if (c->profiling) {
-            hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, c->stream);
             c->fam[fam].launches += 1;
-            c->pending.push_back({a, b, fam});
+            c->pending.push_back({a, b, fam, fl, by, std::move(label)});
         }
     }
 };

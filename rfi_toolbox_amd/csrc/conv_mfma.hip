@@ -15,8 +15,12 @@
 // conflict-free for consecutive pixels (slot = 5*i mod 16 is a bijection).
 // MFMA operand mapping (32x32x2): lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; a lane's
 // b128 holds k = kb*8 + 4*(l>>5) + {0..3}; step t multiplies element t of both operands, so A and
-// B agree on k without any shuffle.  The next chunk's global loads are issued before the MFMAs of
-// the current chunk and written to LDS after them (issue-early / write-late).
+// B agree on k without any shuffle.  Workgroups are persistent over several spatial tiles and run a
+// software pipeline over (tile, chunk) items: the next item's global loads (unconditional, issued
+// back to back) are in flight under the current item's MFMAs and are transformed + written to LDS
+// afterwards (issue-early / write-late), across tile boundaries as well.
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace rfi {
@@ -49,7 +53,7 @@ struct Cfg {
 };
 
 template <int R, int S, int TH, int TW, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     using C = Cfg<R, S, TH, TW, BN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_halo = smem;
@@ -60,98 +64,115 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    // ---- which tile: XCD-aware bijective remap of blockIdx.x (blocks b and b+8 share an XCD)
+    // ---- persistent workgroup: which spatial tiles are mine.  Blocks b and b+8 share an XCD
+    // (round-robin dispatch), so each XCD label gets one contiguous range of tiles and its
+    // workgroups stride through it: neighbouring tiles (shared halos, same filters) hit one L2.
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntiles = a.N * tiles_y * tiles_x;
-    int bid = blockIdx.x;
-    {
-        const int q = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    const int G = gridDim.x;
+    int t_begin, t_count, j, gx;
+    if (G >= 8 && (G & 7) == 0) {
+        const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+        j = blockIdx.x >> 3;
+        gx = G >> 3;
+        t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        t_count = q8 + (xcd < r8 ? 1 : 0);
+    } else {
+        j = blockIdx.x; gx = G; t_begin = 0; t_count = ntiles;
     }
-    const int tx_i = bid % tiles_x;
-    const int ty_i = (bid / tiles_x) % tiles_y;
-    const int n = bid / (tiles_x * tiles_y);
-    const int oy0 = ty_i * TH, ox0 = tx_i * TW;
+    const int my_tiles = (j < t_count) ? (t_count - j + gx - 1) / gx : 0;
+    if (my_tiles == 0) return;                       // uniform for the workgroup, before any barrier
     const int n0 = blockIdx.y * BN;
     const int z = blockIdx.z;
     const float* __restrict__ wbase = a.w + (a.zgroups > 1 ? (size_t)z * a.Cout * a.Cin : 0);
     const int ooy = a.zgroups > 1 ? (z >> 1) : a.ooy;
     const int oox = a.zgroups > 1 ? (z & 1) : a.oox;
+    const int q4 = (tid & 3) * 4;                    // channel offset of this thread's float4 in a chunk
+    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int nitems = my_tiles * nchunks;
 
-    // ---- per-thread staging descriptors (independent of the chunk)
-    long h_off[C::HALO_ITEMS];    // global float offset of the item's pixel (+4q), or -1
-    int h_lds[C::HALO_ITEMS];
+    // ---- staging descriptors.  Loads are UNCONDITIONAL (invalid items read a safe address and are
+    // zeroed when written to LDS) so the compiler can issue them back to back and wait once.
+    // (32-bit float offsets: the launcher checks that every tensor has < 2^31 elements)
+    int h_off[C::HALO_ITEMS];
+    unsigned h_mask = 0;                             // bit it: item `it` of the tile being loaded is in range
 #pragma unroll
-    for (int it = 0; it < C::HALO_ITEMS; ++it) {
-        const int idx = tid + it * 256;
-        const int pix = idx >> 2, q = idx & 3;
-        h_lds[it] = pix * KCP + q * 4;
-        h_off[it] = -1;
-        if (idx < C::HP * 4) {
-            const int hy = pix / C::HW, hx = pix % C::HW;
-            const int iy = oy0 * S - a.pad + hy, ix = ox0 * S - a.pad + hx;
-            if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-                h_off[it] = (((long)n * a.Hin + iy) * a.Win + ix) * a.x.pstride + q * 4;
-        } else {
-            h_lds[it] = -1;
-        }
-    }
-    long w_off[C::W_ITEMS];
-    int w_lds[C::W_ITEMS];
+    for (int it = 0; it < C::HALO_ITEMS; ++it) h_off[it] = 0;
+    int w_off[C::W_ITEMS];
 #pragma unroll
     for (int it = 0; it < C::W_ITEMS; ++it) {
         const int idx = tid + it * 256;
         const int row = idx >> 2, q = idx & 3;       // row = tap*BN + nloc
-        w_lds[it] = row * KCP + q * 4;
         w_off[it] = -1;
         if (idx < C::NTAP * BN * 4) {
             const int tap = row / BN, nloc = row % BN;
-            if (n0 + nloc < a.Cout) w_off[it] = ((long)tap * a.Cout + n0 + nloc) * a.Cin + q * 4;
-        } else {
-            w_lds[it] = -1;
+            if (n0 + nloc < a.Cout) w_off[it] = (tap * a.Cout + n0 + nloc) * a.Cin + q * 4;
         }
     }
-    const int q4 = (tid & 3) * 4;    // channel offset of this thread's float4 within a chunk
+    const int lds_item0 = (tid >> 2) * KCP + (tid & 3) * 4;   // LDS float offset of item 0; item it: + it*64*KCP
+    struct Tile { int n, oy0, ox0; };
+    auto tile_of = [&](int k) {
+        const int t = t_begin + j + k * gx;
+        Tile r;
+        r.ox0 = (t % tiles_x) * TW;
+        r.oy0 = ((t / tiles_x) % tiles_y) * TH;
+        r.n = t / (tiles_x * tiles_y);
+        return r;
+    };
+    auto setup_halo = [&](const Tile& t) {
+        h_mask = 0;
+#pragma unroll
+        for (int it = 0; it < C::HALO_ITEMS; ++it) {
+            const int idx = tid + it * 256;
+            const int pix = idx >> 2, q = idx & 3;
+            const int hy = pix / C::HW, hx = pix % C::HW;
+            const int iy = t.oy0 * S - a.pad + hy, ix = t.ox0 * S - a.pad + hx;
+            const bool ok = idx < C::HP * 4 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            h_off[it] = ok ? ((t.n * a.Hin + iy) * a.Win + ix) * a.x.pstride + q * 4 : 0;
+            h_mask |= (ok ? 1u : 0u) << it;
+        }
+    };
 
     f32x4 hreg[C::HALO_ITEMS];
     f32x4 wreg[C::W_ITEMS];
+    f32x4 screg = {1.f, 1.f, 1.f, 1.f}, shreg = {0.f, 0.f, 0.f, 0.f};
+    bool cv_l = false;                               // channel validity of the chunk in the registers
 
-    auto load_chunk = [&](int c0) {
-        const bool cvalid = (c0 + q4) < a.Cin;     // Cin % 4 == 0 is a launch precondition
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (a.xf.scale && cvalid) {
-            sc = *reinterpret_cast<const f32x4*>(a.xf.scale + c0 + q4);
-            sh = *reinterpret_cast<const f32x4*>(a.xf.shift + c0 + q4);
+    auto issue_loads = [&](int c0) {
+        cv_l = (c0 + q4) < a.Cin;                    // Cin % 4 == 0 is a launch precondition
+        const int cc = cv_l ? c0 : 0;
+        if (a.xf.scale) {
+            screg = *reinterpret_cast<const f32x4*>(a.xf.scale + cc + (cv_l ? q4 : 0));
+            shreg = *reinterpret_cast<const f32x4*>(a.xf.shift + cc + (cv_l ? q4 : 0));
         }
 #pragma unroll
+        for (int it = 0; it < C::HALO_ITEMS; ++it)
+            hreg[it] = *reinterpret_cast<const f32x4*>(
+                a.x.p + ((((h_mask >> it) & 1u) && cv_l) ? h_off[it] + cc : 0));   // never past the tensor
+#pragma unroll
+        for (int it = 0; it < C::W_ITEMS; ++it)
+            wreg[it] = *reinterpret_cast<const f32x4*>(wbase + ((w_off[it] >= 0 && cv_l) ? w_off[it] + cc : 0));
+    };
+    auto store_chunk = [&]() {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int it = 0; it < C::HALO_ITEMS; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (h_off[it] >= 0 && cvalid) {
-                v = *reinterpret_cast<const f32x4*>(a.x.p + h_off[it] + c0);
-                if (a.xf.scale) {
-                    v = v * sc + sh;
-                    if (a.xf.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
+            f32x4 v = hreg[it];
+            if (a.xf.scale) {
+                v = v * screg + shreg;
+                if (a.xf.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
             }
-            hreg[it] = v;
+            v = (((h_mask >> it) & 1u) && cv_l) ? v : zero;      // zero padding AFTER the transform
+            if (tid + it * 256 < C::HP * 4) *reinterpret_cast<f32x4*>(s_halo + lds_item0 + it * 64 * KCP) = v;
         }
 #pragma unroll
         for (int it = 0; it < C::W_ITEMS; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (w_off[it] >= 0 && cvalid) v = *reinterpret_cast<const f32x4*>(wbase + w_off[it] + c0);
-            wreg[it] = v;
+            const f32x4 v = (w_off[it] >= 0 && cv_l) ? wreg[it] : zero;
+            if (tid + it * 256 < C::NTAP * BN * 4) *reinterpret_cast<f32x4*>(s_w + lds_item0 + it * 64 * KCP) = v;
         }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int it = 0; it < C::HALO_ITEMS; ++it)
-            if (h_lds[it] >= 0) *reinterpret_cast<f32x4*>(s_halo + h_lds[it]) = hreg[it];
-#pragma unroll
-        for (int it = 0; it < C::W_ITEMS; ++it)
-            if (w_lds[it] >= 0) *reinterpret_cast<f32x4*>(s_w + w_lds[it]) = wreg[it];
     };
 
     // ---- fragment addresses
@@ -175,13 +196,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    const int nchunks = (a.Cin + KC - 1) / KC;
-    load_chunk(0);
-    store_chunk();
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const bool more = (ch + 1) < nchunks;
-        if (more) load_chunk((ch + 1) * KC);
+    // ---- software pipeline over (tile, chunk) items: item q+1's global loads are in flight while
+    // item q's MFMAs run; across tile boundaries too, so only the first item of a workgroup's life
+    // exposes its load latency
+    Tile ctile = tile_of(0);                         // tile being computed
+    int lk = 0, lch = 0;                             // load cursor (tile index, chunk)
+    setup_halo(ctile);
+    issue_loads(0);
+    for (int q = 0; q < nitems; ++q) {
+        store_chunk();
+        __syncthreads();
+        const int cch = lch;                         // chunk now in LDS
+        Tile ltile = ctile;
+        if (q + 1 < nitems) {
+            if (++lch == nchunks) {
+                lch = 0;
+                ++lk;
+                ltile = tile_of(lk);
+                setup_halo(ltile);
+            }
+        }
+        issue_loads(lch * KC);                       // (the very last item is re-read once: harmless)
 #pragma unroll
         for (int tap = 0; tap < C::NTAP; ++tap) {
             const int tr = tap / R, ts = tap % R;
@@ -206,40 +241,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             }
         }
         __syncthreads();
-        if (more) {
-            store_chunk();
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: C/D layout of 32x32: col = lane&31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        if (cch == nchunks - 1) {
+            // ---- epilogue of tile `ctile`: C/D layout of 32x32: col = lane&31 (channel),
+            // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
 #pragma unroll
-    for (int nt = 0; nt < C::NTL; ++nt) {
-        const int co = n0 + wn * (BN / WN) + nt * 32 + li;
-        const bool cok = co < a.Cout;
-        const float bv = (a.bias && cok) ? a.bias[co] : 0.0f;
+            for (int nt = 0; nt < C::NTL; ++nt) {
+                const int co = n0 + wn * (BN / WN) + nt * 32 + li;
+                const bool cok = co < a.Cout;
+                const float bv = (a.bias && cok) ? a.bias[co] : 0.0f;
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
+                for (int mt = 0; mt < C::MT; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int p = (wm * C::MT + mt) * 32 + row;
-                const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-                if (cok && oy < a.H && ox < a.W) {
-                    const long opix = ((long)n * a.Hout + (oy * a.osy + ooy)) * a.Wout + (ox * a.osx + oox);
-                    a.y.p[opix * a.y.pstride + co] = acc[mt][nt][r] + bv;
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int p = (wm * C::MT + mt) * 32 + row;
+                        const int oy = ctile.oy0 + p / TW, ox = ctile.ox0 + p % TW;
+                        if (cok && oy < a.H && ox < a.W) {
+                            const long opix =
+                                ((long)ctile.n * a.Hout + (oy * a.osy + ooy)) * a.Wout + (ox * a.osx + oox);
+                            a.y.p[opix * a.y.pstride + co] = acc[mt][nt][r] + bv;
+                        }
+                        acc[mt][nt][r] = 0.0f;
+                    }
                 }
             }
+            ctile = ltile;
         }
     }
+}
+
+// LDS bytes -> resident workgroups per CU (160 KiB LDS, <= 8 waves/SIMD is never the limit here)
+static int occupancy_for(size_t lds_bytes) {
+    int o = (int)((160 * 1024) / lds_bytes);
+    return o < 1 ? 1 : (o > 3 ? 3 : o);   // VGPRs: <= 215 for the 72 KB tiles (2 waves/SIMD), <= 151 for the others (3)
 }
 
 template <int R, int S, int TH, int TW, int BN, int WM, int WN>
 void launch_cfg(rfi_ctx* ctx, const ConvArgs& a) {
     using C = Cfg<R, S, TH, TW, BN, WM, WN>;
-    const int tiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
-    dim3 grid(tiles, (unsigned)cdiv(a.Cout, BN), a.zgroups);
+    const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
+    const int ychunks = (int)cdiv(a.Cout, BN);
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    // persistent grid: about (256 CUs x occupancy) workgroups in total, a multiple of 8 along x,
+    // tiles spread evenly over the workgroups of each XCD
+    const int gmax = std::max(8, (256 * occupancy_for(lds)) / (ychunks * a.zgroups));
+    const int tx = (int)cdiv(ntiles, 8);                       // tiles per XCD label (max)
+    const int per = (int)cdiv(tx, std::max(1, gmax / 8));      // tiles per workgroup
+    int gx = (int)cdiv(tx, per);
+    int G = 8 * gx;
+    if (ntiles < 8) G = ntiles;                                // tiny problems: one tile per workgroup
+    dim3 grid(G, ychunks, a.zgroups);
     static bool attr_set = false;
     if (!attr_set) {
         RFI_CHECK_HIP(hipFuncSetAttribute(
@@ -252,18 +303,30 @@ void launch_cfg(rfi_ctx* ctx, const ConvArgs& a) {
     check_launch("conv_igemm");
 }
 
+// tile choice: by output width (TW = 32 / 16 / 8) and channel tile (BN = 32 for Cout <= 32, else 64).
+// Where the grid stays >= 2 workgroups per CU, a workgroup takes twice the pixels (wave tile 64x64 or
+// 128x32): twice the MFMAs between barriers and half the filter staging per output.
 template <int R, int S>
 void dispatch_tiles(rfi_ctx* ctx, const ConvArgs& a) {
-    // tile shape by output width, channel tile by Cout
+    const int ychunks64 = (int)cdiv(a.Cout, 64) * a.zgroups;
+    auto big_ok = [&](int th, int tw, int ych) {
+        return (int64_t)a.N * cdiv(a.H, th) * cdiv(a.W, tw) * ych >= 512;
+    };
+    if constexpr (S == 1) {          // (a stride-2 halo of the double tile would not fit the LDS)
+        if (a.W >= 32 && a.Cout <= 32 && big_ok(16, 32, a.zgroups)) return launch_cfg<R, S, 16, 32, 32, 4, 1>(ctx, a);
+        if (a.W >= 32 && a.Cout > 32 && big_ok(8, 32, ychunks64)) return launch_cfg<R, S, 8, 32, 64, 4, 1>(ctx, a);
+        if (a.W >= 16 && a.W < 32 && a.Cout > 32 && big_ok(16, 16, ychunks64))
+            return launch_cfg<R, S, 16, 16, 64, 4, 1>(ctx, a);
+    }
     if (a.W >= 32) {
         if (a.Cout <= 32) launch_cfg<R, S, 8, 32, 32, 4, 1>(ctx, a);
-        else              launch_cfg<R, S, 4, 32, 64, 2, 2>(ctx, a);
+        else launch_cfg<R, S, 4, 32, 64, 2, 2>(ctx, a);
     } else if (a.W >= 16) {
         if (a.Cout <= 32) launch_cfg<R, S, 8, 16, 32, 4, 1>(ctx, a);
-        else              launch_cfg<R, S, 8, 16, 64, 2, 2>(ctx, a);
+        else launch_cfg<R, S, 8, 16, 64, 2, 2>(ctx, a);
     } else {
         if (a.Cout <= 32) launch_cfg<R, S, 16, 8, 32, 4, 1>(ctx, a);
-        else              launch_cfg<R, S, 8, 8, 64, 2, 2>(ctx, a);
+        else launch_cfg<R, S, 8, 8, 64, 2, 2>(ctx, a);
     }
 }
 
@@ -284,6 +347,9 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "conv: empty shape");
     RFI_REQUIRE(a.x.pstride >= a.Cin && a.y.pstride >= a.Cout, "conv: pixel stride smaller than channels");
     RFI_REQUIRE(a.zgroups == 1 || (a.zgroups == 4 && a.R == 1), "conv: zgroups only for convT forward");
+    RFI_REQUIRE((int64_t)a.N * a.Hin * a.Win * a.x.pstride < (int64_t)1 << 31 &&
+                    (int64_t)a.R * a.R * a.Cin * a.Cout * a.zgroups < (int64_t)1 << 31,
+                "conv: tensor too large for 32-bit element offsets");
     const bool ok = conv_mfma_eligible(a);
     if (impl == IMPL_MFMA) RFI_REQUIRE(ok, "conv: shape/alignment not eligible for the MFMA kernel");
     if (impl == IMPL_DIRECT || !ok) {
@@ -292,7 +358,12 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     }
     const double flops = a.algo_flops >= 0 ? a.algo_flops
                                            : 2.0 * a.N * a.H * a.W * (double)a.Cout * a.R * a.R * a.Cin * a.zgroups;
-    ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0);
+    std::string label;
+    if (ctx->profiling)
+        label = "conv R" + std::to_string(a.R) + "S" + std::to_string(a.S) + " N" + std::to_string(a.N) + " " +
+                std::to_string(a.H) + "x" + std::to_string(a.W) + " " + std::to_string(a.Cin) + "->" +
+                std::to_string(a.Cout) + (a.xf.scale ? " xf" : "") + (a.zgroups > 1 ? " z4" : "");
+    ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0, label);
     if (a.R == 3) dispatch_tiles<3, 1>(ctx, a);
     else if (a.R == 1) dispatch_tiles<1, 1>(ctx, a);
     else dispatch_tiles<2, 2>(ctx, a);

