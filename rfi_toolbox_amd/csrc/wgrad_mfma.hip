@@ -36,7 +36,7 @@ struct WCfg {
     static constexpr int Y_ITEMS = (BM * (BY / 4) + 255) / 256;
     static constexpr int X_ITEMS = (HP * (BX / 4) + 255) / 256;
     static constexpr int TC = (NTAP % 3 == 0) ? 3 : NTAP;  // taps per cross-wave reduction round
-    static constexpr int STAGE_FLOATS = BM * BYP + HP * BXP + 2 * BY + 2 * BX;
+    static constexpr int STAGE_FLOATS = BM * BYP + HP * BXP;
     static constexpr int RED_FLOATS = (WP > 1) ? BLOCKS * TC * 1024 : 0;
     static constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
     static_assert(BLOCKS == 1 || BLOCKS == 2 || BLOCKS == 4, "1, 2 or 4 channel blocks");
@@ -56,8 +56,6 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_y = smem;
     float* s_x = s_y + C::BM * C::BYP;
-    float* s_cy = s_x + C::HP * C::BXP;      // [scale BY][shift BY]
-    float* s_cx = s_cy + 2 * BY;             // [scale BX][shift BX]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -67,35 +65,35 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
     const int cy0 = blockIdx.y * BY, cx0 = blockIdx.z * BX;
     const int split = blockIdx.x;
 
-    // per-channel load transforms of this workgroup's channel tiles -> LDS (identity if absent)
-    for (int i = tid; i < BY; i += 256) {
-        const bool ok = a.xf_y.scale && (cy0 + i) < a.Cy;
-        s_cy[i] = ok ? a.xf_y.scale[cy0 + i] : 1.0f;
-        s_cy[BY + i] = ok ? a.xf_y.shift[cy0 + i] : 0.0f;
+    // ---- staging descriptors.  Item `it` of a thread is float4 number tid + it*256 of the tile;
+    // 256 is a multiple of BY/4 and BX/4, so ALL items of a thread carry the same 4 channels: one
+    // scale/shift pair per operand lives in registers for the whole kernel.
+    constexpr int YQ = BY / 4, XQ = BX / 4;
+    const int yq = tid % YQ, xq = tid % XQ;
+    const int cyq = cy0 + yq * 4, cxq = cx0 + xq * 4;
+    const bool y_cok = cyq < a.Cy, x_cok = cxq < a.Cx;            // Cx, Cy % 4 == 0 (launch precondition)
+    f32x4 ysc = {1.f, 1.f, 1.f, 1.f}, ysh = {0.f, 0.f, 0.f, 0.f}, xsc = ysc, xsh = ysh;
+    if (a.xf_y.scale && y_cok) {
+        ysc = *reinterpret_cast<const f32x4*>(a.xf_y.scale + cyq);
+        ysh = *reinterpret_cast<const f32x4*>(a.xf_y.shift + cyq);
     }
-    for (int i = tid; i < BX; i += 256) {
-        const bool ok = a.xf_x.scale && (cx0 + i) < a.Cx;
-        s_cx[i] = ok ? a.xf_x.scale[cx0 + i] : 1.0f;
-        s_cx[BX + i] = ok ? a.xf_x.shift[cx0 + i] : 0.0f;
+    if (a.xf_x.scale && x_cok) {
+        xsc = *reinterpret_cast<const f32x4*>(a.xf_x.scale + cxq);
+        xsh = *reinterpret_cast<const f32x4*>(a.xf_x.shift + cxq);
     }
-
-    // per-thread staging descriptors (tile-independent parts)
-    int y_pix[C::Y_ITEMS], y_q[C::Y_ITEMS];
+    // tile-independent pixel coordinates of every item (packed row<<16 | col)
+    int y_rc[C::Y_ITEMS], x_rc[C::X_ITEMS];
 #pragma unroll
     for (int it = 0; it < C::Y_ITEMS; ++it) {
-        const int idx = tid + it * 256;
-        y_pix[it] = idx / (BY / 4);
-        y_q[it] = idx % (BY / 4);
-        if (idx >= C::BM * (BY / 4)) y_pix[it] = -1;
+        const int pix = (tid + it * 256) / YQ;
+        y_rc[it] = ((pix / TW) << 16) | (pix % TW);
     }
-    int x_pix[C::X_ITEMS], x_q[C::X_ITEMS];
 #pragma unroll
     for (int it = 0; it < C::X_ITEMS; ++it) {
-        const int idx = tid + it * 256;
-        x_pix[it] = idx / (BX / 4);
-        x_q[it] = idx % (BX / 4);
-        if (idx >= C::HP * (BX / 4)) x_pix[it] = -1;
+        const int pix = (tid + it * 256) / XQ;
+        x_rc[it] = ((pix / C::HW) << 16) | (pix % C::HW);
     }
+    const int y_lds0 = (tid / YQ) * C::BYP + yq * 4, x_lds0 = (tid / XQ) * C::BXP + xq * 4;
 
     f32x4 yreg[C::Y_ITEMS], xreg[C::X_ITEMS];
     unsigned yvalid = 0, xvalid = 0;
@@ -110,23 +108,23 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         const int ty_i = (tile / tiles_x) % tiles_y;
         const int n = tile / (tiles_x * tiles_y);
         const int oy0 = ty_i * TH, ox0 = tx_i * TW;
+        const int ybase = (n * a.H + oy0) * a.W + ox0;                     // pixel index of the tile origin
+        const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
         yvalid = 0;
         xvalid = 0;
 #pragma unroll
         for (int it = 0; it < C::Y_ITEMS; ++it) {
-            const int oy = oy0 + y_pix[it] / TW, ox = ox0 + y_pix[it] % TW;
-            const int c = cy0 + y_q[it] * 4;
-            const bool ok = y_pix[it] >= 0 && oy < a.H && ox < a.W && c < a.Cy;
-            const long off = ok ? (((long)n * a.H + oy) * a.W + ox) * a.yop.pstride + c : 0;
+            const int r = y_rc[it] >> 16, c = y_rc[it] & 0xffff;
+            const bool ok = (tid + it * 256 < C::BM * YQ) && oy0 + r < a.H && ox0 + c < a.W && y_cok;
+            const int off = ok ? (ybase + r * a.W + c) * a.yop.pstride + cyq : 0;
             yreg[it] = *reinterpret_cast<const f32x4*>(a.yop.p + off);
             yvalid |= (ok ? 1u : 0u) << it;
         }
 #pragma unroll
         for (int it = 0; it < C::X_ITEMS; ++it) {
-            const int iy = oy0 * S - a.pad + x_pix[it] / C::HW, ix = ox0 * S - a.pad + x_pix[it] % C::HW;
-            const int c = cx0 + x_q[it] * 4;
-            const bool ok = x_pix[it] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < a.Cx;
-            const long off = ok ? (((long)n * a.Hx + iy) * a.Wx + ix) * a.xop.pstride + c : 0;
+            const int iy = iy0 + (x_rc[it] >> 16), ix = ix0 + (x_rc[it] & 0xffff);
+            const bool ok = (tid + it * 256 < C::HP * XQ) && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && x_cok;
+            const int off = ok ? ((n * a.Hx + iy) * a.Wx + ix) * a.xop.pstride + cxq : 0;
             xreg[it] = *reinterpret_cast<const f32x4*>(a.xop.p + off);
             xvalid |= (ok ? 1u : 0u) << it;
         }
@@ -135,35 +133,31 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < C::Y_ITEMS; ++it) {
-            if (y_pix[it] < 0) continue;
             f32x4 v = yreg[it];
             if (a.xf_y.scale) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(s_cy + y_q[it] * 4);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(s_cy + BY + y_q[it] * 4);
-                v = v * sc + sh;
+                v = v * ysc + ysh;
                 if (a.xf_y.relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                     v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
             }
             v = ((yvalid >> it) & 1u) ? v : zero;
-            *reinterpret_cast<f32x4*>(s_y + y_pix[it] * C::BYP + y_q[it] * 4) = v;
+            if ((it + 1) * 256 <= C::BM * YQ || tid + it * 256 < C::BM * YQ)
+                *reinterpret_cast<f32x4*>(s_y + y_lds0 + it * (256 / YQ) * C::BYP) = v;
         }
 #pragma unroll
         for (int it = 0; it < C::X_ITEMS; ++it) {
-            if (x_pix[it] < 0) continue;
             f32x4 v = xreg[it];
             if (a.xf_x.scale) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(s_cx + x_q[it] * 4);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(s_cx + BX + x_q[it] * 4);
-                v = v * sc + sh;
+                v = v * xsc + xsh;
                 if (a.xf_x.relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                     v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
             }
             v = ((xvalid >> it) & 1u) ? v : zero;
-            *reinterpret_cast<f32x4*>(s_x + x_pix[it] * C::BXP + x_q[it] * 4) = v;
+            if ((it + 1) * 256 <= C::HP * XQ || tid + it * 256 < C::HP * XQ)
+                *reinterpret_cast<f32x4*>(s_x + x_lds0 + it * (256 / XQ) * C::BXP) = v;
         }
     };
 
@@ -173,7 +167,6 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    __syncthreads();                       // s_cy / s_cx visible
     // software pipeline over this workgroup's tiles: tile t+1's loads fly under tile t's MFMAs
     const int my_tiles = split < ntiles ? (ntiles - split + d.nsplit - 1) / d.nsplit : 0;
     if (my_tiles > 0) load_tile(split);
@@ -182,19 +175,31 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         __syncthreads();
         const int next = split + (k + 1 < my_tiles ? k + 1 : k) * d.nsplit;   // last tile re-read once
         load_tile(next);
-        // ---- MFMA over this wave's share of the tile's pixels
+        // ---- MFMA over this wave's share of the tile's pixels.  Operands of k-step ks+1 are read
+        // from LDS into a second register set before the MFMAs of k-step ks are issued, so the
+        // matrix pipe never waits on an LDS round trip (one wave per SIMD here: nobody else hides it)
         const int a_col = by * 32 + li, b_col = bx * 32 + li;
-#pragma unroll 4
-        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        float av[2], bv[2][C::NTAP];
+        auto lds_operands = [&](int ks, float& a_, float (&b_)[C::NTAP]) {
             const int p = (ps * C::KSTEPS + ks) * 2 + lh;          // pixel within the tile
             const int ty = p / TW, tx = p % TW;
-            const float av = s_y[p * C::BYP + a_col];
+            a_ = s_y[p * C::BYP + a_col];
             const float* xb = s_x + ((ty * S) * C::HW + tx * S) * C::BXP + b_col;
 #pragma unroll
-            for (int tap = 0; tap < C::NTAP; ++tap) {
-                const float bv = xb[((tap / R) * C::HW + (tap % R)) * C::BXP];
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
-            }
+            for (int tap = 0; tap < C::NTAP; ++tap) b_[tap] = xb[((tap / R) * C::HW + (tap % R)) * C::BXP];
+        };
+        lds_operands(0, av[0], bv[0]);
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < C::KSTEPS) lds_operands(ks + 1, av[cur ^ 1], bv[cur ^ 1]);
+            // hipcc otherwise sinks each ds_read to just before its MFMA (lgkmcnt(0) per MFMA);
+            // the fences keep "reads of step ks+1, then MFMAs of step ks" in program order
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < C::NTAP; ++tap)
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][tap], acc[tap], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -252,7 +257,9 @@ Plan plan_cfg(const WgradArgs& a, int cus) {
     using C = WCfg<R, S, BY, BX, TH, TW>;
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
     const int chunks = (int)cdiv(a.Cy, BY) * (int)cdiv(a.Cx, BX);
-    int nsplit = (int)cdiv((int64_t)cus * 2, chunks);      // ~2 workgroups per CU in total
+    // 144 accumulator + ~170 working registers per lane: ONE workgroup per CU is resident, so one
+    // workgroup per CU in total (a second round would only repeat the prologue/epilogue)
+    int nsplit = (int)cdiv((int64_t)cus, chunks);
     if (nsplit > ntiles) nsplit = ntiles;
     if (nsplit < 1) nsplit = 1;
     Plan p;
@@ -317,7 +324,13 @@ bool wgrad_mfma_eligible(const WgradArgs& a) {
 }
 
 Plan dispatch(rfi_ctx* ctx, const WgradArgs& a, int what, int cus) {
-    if (a.R == 3) return select<3, 1, 8, 8>(ctx, a, what, cus);
+    if (a.R == 3) {
+        // channel tiles with fewer than 4 blocks split the tile's PIXELS over the waves: give them a
+        // 16x8 tile so each wave still has 16+ k-steps between barriers
+        const bool splits_pixels = !(a.Cy > 32 && a.Cx > 32);
+        if (splits_pixels && a.H >= 16) return select<3, 1, 16, 8>(ctx, a, what, cus);
+        return select<3, 1, 8, 8>(ctx, a, what, cus);
+    }
     return select<2, 2, 4, 8>(ctx, a, what, cus);
 }
 
@@ -336,6 +349,9 @@ size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
 
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl) {
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cx > 0 && a.Cy > 0, "wgrad: empty shape");
+    RFI_REQUIRE((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride < (int64_t)1 << 31 &&
+                    (int64_t)a.N * a.H * a.W * a.yop.pstride < (int64_t)1 << 31,
+                "wgrad: tensor too large for 32-bit element offsets");
     const bool ok = wgrad_mfma_eligible(a);
     if (impl == IMPL_MFMA) RFI_REQUIRE(ok, "wgrad: shape/alignment not eligible for the MFMA kernel");
     if (impl == IMPL_DIRECT || !ok) {
