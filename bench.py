@@ -162,6 +162,18 @@ def main():
             per["gbs"] = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else None
         fam_out[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in per.items()}
     dom = "conv_igemm_mfma"
+    # HBM bytes per launch of the dominant family from the committed rocprofv3 PMC passes of this
+    # same command (bench.py cannot run under the profiler and time itself at once)
+    import glob
+    traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if traffic_files:
+        try:
+            tj = json.load(open(traffic_files[-1]))["families"].get(dom)
+            if tj:
+                roof["traffic"] = tj["hbm_bytes_per_launch"]
+                roof["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
+        except Exception:
+            pass
     if dom in fam and fam[dom]["ms"]:
         ach = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3) / 1e12
         roof.update(achieved=round(ach, 3), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), kernel=dom,
