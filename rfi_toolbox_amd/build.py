@@ -27,6 +27,8 @@ HEADERS = ["common.hpp", "kernels.hpp", "model.hpp", os.path.join(ROOT, "include
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-ffp-contract=off"]
+if os.environ.get("RFI_DIAG_STAMPS"):        # diagnostic build with in-kernel cycle stamps (never shipped)
+    COMMON.append("-DRFI_DIAG_STAMPS=1")
 
 
 def _newer(target, deps):

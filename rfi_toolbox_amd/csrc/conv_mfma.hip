@@ -20,6 +20,7 @@
 // back to back) are in flight under the current item's MFMAs and are transformed + written to LDS
 // afterwards (issue-early / write-late), across tile boundaries as well.
 #include <algorithm>
+#include <vector>
 
 #include "kernels.hpp"
 
@@ -46,7 +47,9 @@ struct Cfg {
     static constexpr int NTL = BN / WN / 32;      // 32-channel n-tiles per wave
     static constexpr int HALO_ITEMS = (HP * 4 + 255) / 256;
     static constexpr int W_ITEMS = (NTAP * BN * 4 + 255) / 256;
-    static constexpr int LDS_FLOATS = HP * KCP + NTAP * BN * KCP;
+    static constexpr int STAGE_FLOATS = HP * KCP + NTAP * BN * KCP;
+    static constexpr int EPI_FLOATS = 4 * 32 * 36;            // epilogue transpose scratch (4 waves)
+    static constexpr int LDS_FLOATS = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
     static_assert(32 % TW == 0 || TW % 32 == 0, "TW must divide or be a multiple of 32");
@@ -119,16 +122,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         r.n = t / (tiles_x * tiles_y);
         return r;
     };
+    // tile-independent halo coordinates of every item (row<<16 | col); out-of-range items get a
+    // row that fails every bounds test
+    int h_rc[C::HALO_ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::HALO_ITEMS; ++it) {
+        const int idx = tid + it * 256, pix = idx >> 2;
+        h_rc[it] = idx < C::HP * 4 ? (((pix / C::HW) << 16) | (pix % C::HW)) : (0x4000 << 16);
+    }
     auto setup_halo = [&](const Tile& t) {
+        const int iy0 = t.oy0 * S - a.pad, ix0 = t.ox0 * S - a.pad, nb = t.n * a.Hin;
         h_mask = 0;
 #pragma unroll
         for (int it = 0; it < C::HALO_ITEMS; ++it) {
-            const int idx = tid + it * 256;
-            const int pix = idx >> 2, q = idx & 3;
-            const int hy = pix / C::HW, hx = pix % C::HW;
-            const int iy = t.oy0 * S - a.pad + hy, ix = t.ox0 * S - a.pad + hx;
-            const bool ok = idx < C::HP * 4 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            h_off[it] = ok ? ((t.n * a.Hin + iy) * a.Win + ix) * a.x.pstride + q * 4 : 0;
+            const int iy = iy0 + (h_rc[it] >> 16), ix = ix0 + (h_rc[it] & 0xffff);
+            const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            h_off[it] = ok ? ((nb + iy) * a.Win + ix) * a.x.pstride + q4 : 0;
             h_mask |= (ok ? 1u : 0u) << it;
         }
     };
@@ -148,10 +157,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < C::HALO_ITEMS; ++it)
             hreg[it] = *reinterpret_cast<const f32x4*>(
-                a.x.p + ((((h_mask >> it) & 1u) && cv_l) ? h_off[it] + cc : 0));   // never past the tensor
+                a.x.p + (unsigned)((((h_mask >> it) & 1u) && cv_l) ? h_off[it] + cc : 0));   // never past the tensor
 #pragma unroll
         for (int it = 0; it < C::W_ITEMS; ++it)
-            wreg[it] = *reinterpret_cast<const f32x4*>(wbase + ((w_off[it] >= 0 && cv_l) ? w_off[it] + cc : 0));
+            wreg[it] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)((w_off[it] >= 0 && cv_l) ? w_off[it] + cc : 0));
     };
     auto store_chunk = [&]() {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -160,10 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             f32x4 v = hreg[it];
             if (a.xf.scale) {
                 v = v * screg + shreg;
-                if (a.xf.relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
+                if (a.xf.relu) v = __builtin_elementwise_max(v, zero);
             }
             v = (((h_mask >> it) & 1u) && cv_l) ? v : zero;      // zero padding AFTER the transform
             if (tid + it * 256 < C::HP * 4) *reinterpret_cast<f32x4*>(s_halo + lds_item0 + it * 64 * KCP) = v;
@@ -203,9 +209,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     int lk = 0, lch = 0;                             // load cursor (tile index, chunk)
     setup_halo(ctile);
     issue_loads(0);
+#ifdef RFI_DIAG_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+#define RFI_T(v) const unsigned long long v = clock64()
+#define RFI_ACC(i, a_, b_) st_[i] += (b_) - (a_)
+#else
+#define RFI_T(v)
+#define RFI_ACC(i, a_, b_)
+#endif
     for (int q = 0; q < nitems; ++q) {
+        RFI_T(t0);
         store_chunk();
+        RFI_T(t1);
         __syncthreads();
+        RFI_T(t2);
         const int cch = lch;                         // chunk now in LDS
         Tile ltile = ctile;
         if (q + 1 < nitems) {
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             }
         }
         issue_loads(lch * KC);                       // (the very last item is re-read once: harmless)
+        RFI_T(t3);
 #pragma unroll
         for (int tap = 0; tap < C::NTAP; ++tap) {
             const int tr = tap / R, ts = tap % R;
@@ -240,34 +258,86 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                                                                               acc[mt][nt], 0, 0, 0);
             }
         }
+        RFI_T(t4);
         __syncthreads();
+        RFI_T(t5);
         if (cch == nchunks - 1) {
-            // ---- epilogue of tile `ctile`: C/D layout of 32x32: col = lane&31 (channel),
-            // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
+            // ---- epilogue of tile `ctile`.  C/D layout of 32x32: col = lane&31 (channel), row =
+            // (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel): a lane holds ONE channel of 16 pixels, i.e.
+            // 16 dword stores a tile.  64 narrow stores per wave saturate the 6-bit vmcnt queue and the
+            // next item's staging then waits on them, so each 32x32 tile is transposed through the
+            // (now idle) staging LDS and leaves as 4 x 16-byte-per-lane stores of whole 128-B pixel rows.
+            const int xs = a.osx * a.y.pstride;                         // floats per tile column step
+            const bool vec_out = (a.Cout & 3) == 0 && (a.y.pstride & 3) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(a.y.p) & 15) == 0;
+            float* s_ep = smem + wave * (32 * 36);                      // 4.5 KiB per wave, rows of 36 floats
 #pragma unroll
             for (int nt = 0; nt < C::NTL; ++nt) {
-                const int co = n0 + wn * (BN / WN) + nt * 32 + li;
-                const bool cok = co < a.Cout;
-                const float bv = (a.bias && cok) ? a.bias[co] : 0.0f;
+                const int co0 = n0 + wn * (BN / WN) + nt * 32;
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt) {
+                    constexpr int ROWS = (32 + TW - 1) / TW;            // image rows per 32-pixel m-tile
+                    const int oyb = ctile.oy0 + ((wm * C::MT + mt) * 32) / TW;
+                    if (vec_out) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const int p = (wm * C::MT + mt) * 32 + row;
-                        const int oy = ctile.oy0 + p / TW, ox = ctile.ox0 + p % TW;
-                        if (cok && oy < a.H && ox < a.W) {
-                            const long opix =
-                                ((long)ctile.n * a.Hout + (oy * a.osy + ooy)) * a.Wout + (ox * a.osx + oox);
-                            a.y.p[opix * a.y.pstride + co] = acc[mt][nt][r] + bv;
+                        for (int r = 0; r < 16; ++r)
+                            s_ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[mt][nt][r];
+                        const int g4 = (lane & 7) * 4;                  // 4 channels of this lane
+                        const int co = co0 + g4;
+                        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                        if (a.bias && co < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int pp = ps * 8 + (lane >> 3);        // pixel of the m-tile
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pp * 36 + g4) + b4;
+                            const int oy = oyb + pp / TW, ox = ctile.ox0 + pp % TW;
+                            if (co < a.Cout && oy < a.H && ox < a.W)
+                                *reinterpret_cast<f32x4*>(
+                                    a.y.p + (unsigned)(((ctile.n * a.Hout + oy * a.osy + ooy) * a.Wout + ox * a.osx + oox) *
+                                                           a.y.pstride + co)) = v;
                         }
-                        acc[mt][nt][r] = 0.0f;
+                    } else {
+                        const int co = co0 + li;
+                        const bool cok = co < a.Cout;
+                        const float bv = (a.bias && cok) ? a.bias[co] : 0.0f;
+                        const int lane_x = ctile.ox0 + 4 * lh;
+#pragma unroll
+                        for (int dyi = 0; dyi < ROWS; ++dyi) {
+                            const int oy = oyb + dyi;
+                            const bool yok = cok && oy < a.H;
+                            float* rowp = a.y.p + (unsigned)(((ctile.n * a.Hout + oy * a.osy + ooy) * a.Wout + oox) *
+                                                                 a.y.pstride + co);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int c = (r & 3) + 8 * (r >> 2);   // row of reg r for lh == 0
+                                if (c / TW != dyi) continue;            // compile-time filter
+                                const int ox = lane_x + (c % TW);
+                                if (yok && ox < a.W) rowp[(unsigned)(ox * xs)] = acc[mt][nt][r] + bv;
+                            }
+                        }
                     }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
                 }
             }
+            __syncthreads();          // the staging LDS is about to be overwritten by the next item
             ctile = ltile;
         }
+#ifdef RFI_DIAG_STAMPS
+        {
+            const unsigned long long t6 = clock64();
+            RFI_ACC(0, t0, t1); RFI_ACC(1, t1, t2); RFI_ACC(2, t2, t3); RFI_ACC(3, t3, t4); RFI_ACC(4, t4, t5);
+            RFI_ACC(5, t5, t6);
+        }
+#endif
     }
+#ifdef RFI_DIAG_STAMPS
+    if (a.stamps && (tid & 63) == 0) {
+        unsigned long long* o = a.stamps + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wave * 8;
+        for (int i = 0; i < 6; ++i) o[i] = st_[i];
+        o[6] = nitems;
+    }
+#endif
 }
 
 // LDS bytes -> resident workgroups per CU (160 KiB LDS, <= 8 waves/SIMD is never the limit here)
@@ -298,6 +368,31 @@ void launch_cfg(rfi_ctx* ctx, const ConvArgs& a) {
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+#ifdef RFI_DIAG_STAMPS
+    {   // diagnostic build: run with per-phase cycle stamps and print the per-wave averages
+        ConvArgs b = a;
+        const size_t nw = (size_t)G * ychunks * a.zgroups * 32;
+        RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&b.stamps), nw * 8));
+        RFI_CHECK_HIP(hipMemsetAsync(b.stamps, 0, nw * 8, ctx->stream));
+        hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN>), grid, dim3(256), lds, ctx->stream, b);
+        std::vector<unsigned long long> h(nw);
+        RFI_CHECK_HIP(hipMemcpyAsync(h.data(), b.stamps, nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        double s[7] = {0, 0, 0, 0, 0, 0, 0};
+        size_t cnt = 0;
+        for (size_t w = 0; w < nw / 8; ++w) {
+            if (h[w * 8 + 6] == 0) continue;
+            for (int i = 0; i < 7; ++i) s[i] += (double)h[w * 8 + i];
+            ++cnt;
+        }
+        std::fprintf(stderr, "[stamps] conv<%d,%d,%d,%d,%d> N%d %dx%d %d->%d grid %dx%d items/wg %.1f | per item (cycles): "
+                     "store %.0f bar1 %.0f loads %.0f mfma %.0f bar2 %.0f epi %.0f\n", R, S, TH, TW, BN, a.N, a.H, a.W,
+                     a.Cin, a.Cout, G, ychunks, s[6] / cnt, s[0] / s[6], s[1] / s[6], s[2] / s[6], s[3] / s[6], s[4] / s[6],
+                     s[5] / s[6]);
+        RFI_CHECK_HIP(hipFree(b.stamps));
+        return;
+    }
+#endif
     hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN>), grid, dim3(256), lds, ctx->stream,
                        a);
     check_launch("conv_igemm");
@@ -348,6 +443,7 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     RFI_REQUIRE(a.x.pstride >= a.Cin && a.y.pstride >= a.Cout, "conv: pixel stride smaller than channels");
     RFI_REQUIRE(a.zgroups == 1 || (a.zgroups == 4 && a.R == 1), "conv: zgroups only for convT forward");
     RFI_REQUIRE((int64_t)a.N * a.Hin * a.Win * a.x.pstride < (int64_t)1 << 31 &&
+                    (int64_t)a.N * a.Hout * a.Wout * a.y.pstride < (int64_t)1 << 31 &&
                     (int64_t)a.R * a.R * a.Cin * a.Cout * a.zgroups < (int64_t)1 << 31,
                 "conv: tensor too large for 32-bit element offsets");
     const bool ok = conv_mfma_eligible(a);

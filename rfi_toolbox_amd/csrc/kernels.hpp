@@ -48,6 +48,9 @@ struct ConvArgs {
     int zgroups = 1;                  // convT fwd: 4 (a,b) groups: w += z*Cout*Cin, (ooy,oox) = (z/2, z%2)
     InXform xf;
     double algo_flops = -1;           // algorithmic FLOPs for the profile (default: from the shape)
+#ifdef RFI_DIAG_STAMPS
+    unsigned long long* stamps = nullptr;   // diagnostic build only: per-workgroup phase cycle sums
+#endif
 };
 
 enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2 };
