@@ -12,11 +12,29 @@ namespace rfi {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kFinCh = 2;                    // finishing kernels: channels per block ...
+constexpr int kFinLanes = kBlock / kFinCh;   // ... x record lanes
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
+}
+
+// finishing kernels: thread = (channel lane cl = tid % kFinCh, record lane tid / kFinCh).  Sums the
+// record lanes of each channel lane: xor-shuffles over the lane bits above kFinCh inside a wave,
+// then the 4 waves through LDS.  Result valid in threads tid < kFinCh.  red: 4 * kFinCh doubles.
+__device__ __forceinline__ double finish_sum(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o >= kFinCh; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();                       // red may still be read from a previous call
+    if (lane < kFinCh) red[wave * kFinCh + lane] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x < kFinCh)
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w * kFinCh + threadIdx.x];
+    return t;
 }
 
 // channel-lane geometry shared by the per-channel reductions over a [M][C] tensor:
@@ -129,23 +147,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int recor
                                    float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ var_out) {
     __shared__ double red[2 * kBlock];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
+    const int cl = threadIdx.x & (kFinCh - 1), rl = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
     double s1 = 0, s2 = 0;
     if (c < C) {
-        for (int r = rl; r < records; r += 32) {
+        for (int r = rl; r < records; r += kFinLanes) {
             s1 += partial[((int64_t)r * C + c) * 2 + 0];
             s2 += partial[((int64_t)r * C + c) * 2 + 1];
         }
     }
-    red[threadIdx.x] = s1;
-    red[kBlock + threadIdx.x] = s2;
-    __syncthreads();
+    s1 = finish_sum(s1, red);
+    s2 = finish_sum(s2, red);
     if (rl == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) {
-            s1 += red[k * 8 + cl];
-            s2 += red[kBlock + k * 8 + cl];
-        }
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0) var = 0;
@@ -230,23 +243,18 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int r
                                        double count, float* c1, float* c2, float* dgamma,
                                        float* dbeta) {
     __shared__ double red[2 * kBlock];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
+    const int cl = threadIdx.x & (kFinCh - 1), rl = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
     double s1 = 0, s2 = 0;
     if (c < C) {
-        for (int r = rl; r < records; r += 32) {
+        for (int r = rl; r < records; r += kFinLanes) {
             s1 += partial[((int64_t)r * C + c) * 2 + 0];
             s2 += partial[((int64_t)r * C + c) * 2 + 1];
         }
     }
-    red[threadIdx.x] = s1;
-    red[kBlock + threadIdx.x] = s2;
-    __syncthreads();
+    s1 = finish_sum(s1, red);
+    s2 = finish_sum(s2, red);
     if (rl == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) {
-            s1 += red[k * 8 + cl];
-            s2 += red[kBlock + k * 8 + cl];
-        }
         c1[c] = (float)(s1 / count);
         c2[c] = (float)(s2 / count);
         dgamma[c] = (float)s2;
@@ -303,18 +311,14 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restr
 __global__ void finish_channel_sum_kernel(const double* __restrict__ partial, int records,
                                           int64_t stride, int count, float* __restrict__ out) {
     __shared__ double red[kBlock];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
+    const int cl = threadIdx.x & (kFinCh - 1), rl = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
     const int C = count;
     double s = 0;
     if (c < C)
-        for (int r = rl; r < records; r += 32) s += partial[(int64_t)r * stride + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) s += red[k * 8 + cl];
-        out[c] = (float)s;
-    }
+        for (int r = rl; r < records; r += kFinLanes) s += partial[(int64_t)r * stride + c];
+    s = finish_sum(s, red);
+    if (rl == 0 && c < C) out[c] = (float)s;
 }
 
 template <int V>
@@ -631,6 +635,23 @@ __global__ void weight_to_dgrad_kernel(const float* __restrict__ wf, int taps, i
         wd[i] = wf[((int64_t)ts * Cout + co) * Cin + ci];
     }
 }
+// all layers in one launch: blockIdx.y selects the layer descriptor
+__global__ void weight_to_dgrad_batched_kernel(const RelayoutDesc* __restrict__ descs, const float* __restrict__ src,
+                                               float* __restrict__ dst) {
+    const RelayoutDesc d = descs[blockIdx.y];
+    const float* __restrict__ wf = src + d.src_off;
+    float* __restrict__ wd = dst + d.dst_off;
+    const int64_t total = (int64_t)d.taps * d.cout * d.cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % d.cout);
+        int64_t t = i / d.cout;
+        const int ci = (int)(t % d.cin);
+        const int tp = (int)(t / d.cin);
+        const int ts = d.flip ? (d.taps - 1 - tp) : tp;
+        wd[i] = wf[((int64_t)ts * d.cout + co) * d.cin + ci];
+    }
+}
 __global__ void pad_channels_kernel(const float* __restrict__ s, int64_t M, int c, int cp,
                                     float* __restrict__ d) {
     const int64_t total = M * cp;
@@ -759,7 +780,7 @@ void launch_bn_finalize(rfi_ctx* ctx, const float* partial, int64_t M, int C, co
                           float* var_out) {
     ChanGeom g = geom_rows(M, C);
     ProfScope ps(ctx, FAM_BN);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, ctx->stream,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0, ctx->stream,
                        reinterpret_cast<const double*>(partial), g.rblocks, C, (double)M, gamma, beta,
                        running_mean, running_var, ema_repeats, mean, invstd, scale, shift, var_out);
     check_launch("bn_finalize");
@@ -798,7 +819,7 @@ void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t
     }
     {
         ProfScope ps(ctx, FAM_BN);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, ctx->stream,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0, ctx->stream,
                            reinterpret_cast<const double*>(partial_ws), g.rblocks, C, (double)M, c1, c2,
                            dgamma, dbeta);
         check_launch("bn_bwd_finalize");
@@ -824,7 +845,7 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t 
     }
     if (dbias) {
         ProfScope ps(ctx, FAM_BN);
-        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0,
                            ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, dbias);
         check_launch("finish_channel_sum");
     }
@@ -852,7 +873,7 @@ void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_w
     }
     {
         ProfScope ps(ctx, FAM_REDUCE);
-        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0,
                            ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, out);
         check_launch("finish_channel_sum");
     }
@@ -951,14 +972,14 @@ void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float
         ProfScope ps(ctx, FAM_REDUCE);
         // dw and db are adjacent in the flat gradient buffer only by construction of the caller;
         // finish into dw[0..Cout*C) and db[0..Cout) separately
-        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(Cout * C, 8)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(Cout * C, kFinCh)), dim3(kBlock), 0,
                            ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)n, Cout * C, dw);
         check_launch("head_bwd_finish_dw");
     }
     {
         const int n = Cout * C + Cout;
         ProfScope ps(ctx, FAM_REDUCE);
-        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(Cout, 8)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(Cout, kFinCh)), dim3(kBlock), 0,
                            ctx->stream, reinterpret_cast<const double*>(partial_ws) + (size_t)Cout * C,
                            g.rblocks, (int64_t)n, Cout, db);
         check_launch("head_bwd_finish_db");
@@ -986,6 +1007,13 @@ void launch_weight_to_dgrad(rfi_ctx* ctx, const float* wf, int taps, int Cout, i
     hipLaunchKernelGGL(weight_to_dgrad_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, wf,
                        taps, Cout, Cin, flip, wd);
     check_launch("weight_to_dgrad");
+}
+void launch_weight_to_dgrad_batched(rfi_ctx* ctx, const RelayoutDesc* descs_dev, int n, const float* src,
+                                    float* dst, double total_bytes) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, total_bytes);
+    hipLaunchKernelGGL(weight_to_dgrad_batched_kernel, dim3(64, n), dim3(kBlock), 0, ctx->stream, descs_dev, src,
+                       dst);
+    check_launch("weight_to_dgrad_batched");
 }
 void launch_pad_channels(rfi_ctx* ctx, const float* src, int64_t M, int c, int cp, float* dst) {
     ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * (c + cp) * 4);

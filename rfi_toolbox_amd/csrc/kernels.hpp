@@ -143,6 +143,12 @@ void launch_nhwc_to_nchw(rfi_ctx* ctx, const float* src, int N, int C, int H, in
 // forward layout [tap][co][ci] -> dgrad layout [tap'][ci][co]; flip: tap' = taps-1-tap
 void launch_weight_to_dgrad(rfi_ctx* ctx, const float* wf, int taps, int Cout, int Cin, int flip,
                             float* wd);
+struct RelayoutDesc {          // one conv-like layer of launch_weight_to_dgrad_batched (float offsets)
+    int64_t src_off, dst_off;
+    int taps, cout, cin, flip;
+};
+void launch_weight_to_dgrad_batched(rfi_ctx* ctx, const RelayoutDesc* descs_dev, int n, const float* src,
+                                    float* dst, double total_bytes);
 void launch_u8_to_f32(rfi_ctx* ctx, const uint8_t* src, int64_t n, float* dst);
 // dst[m][0..cp) = src[m][0..c) followed by zeros (channel padding of the network input to a multiple of 4)
 void launch_pad_channels(rfi_ctx* ctx, const float* src, int64_t M, int c, int cp, float* dst);

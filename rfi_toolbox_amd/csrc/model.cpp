@@ -46,6 +46,7 @@ rfi_model::~rfi_model() {
     for (auto& b : bufs) b.free();
     for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool})
         if (p) ctx->release(p);
+    if (relayout_descs) ctx->release(relayout_descs);
     if (d_sums) ctx->release(d_sums);
     if (d_scalars) ctx->release(d_scalars);
 }
@@ -279,8 +280,25 @@ void rfi_model::prepare(int n, int h, int w) {
 
 void rfi_model::refresh_dgrad_weights() {
     if (!wd_dirty) return;
-    for (auto& c : convs) launch_weight_to_dgrad(ctx, params + c.w_off, 9, c.cout, c.cin_p, 1, c.wd);
-    for (auto& u : ups) launch_weight_to_dgrad(ctx, params + u.w_off, 4, u.cout, u.cin, 0, u.wd);
+    if (!relayout_descs) {          // one descriptor per conv-like layer, built once
+        std::vector<RelayoutDesc> h;
+        relayout_bytes = 0;
+        for (auto& c : convs) {
+            h.push_back({(int64_t)c.w_off, (int64_t)(c.wd - wd_pool), 9, c.cout, c.cin_p, 1});
+            relayout_bytes += 8.0 * 9 * c.cout * c.cin_p;
+        }
+        for (auto& u : ups) {
+            h.push_back({(int64_t)u.w_off, (int64_t)(u.wd - wd_pool), 4, u.cout, u.cin, 0});
+            relayout_bytes += 8.0 * 4 * u.cout * u.cin;
+        }
+        relayout_n = (int)h.size();
+        relayout_descs = ctx->alloc(h.size() * sizeof(RelayoutDesc));
+        RFI_CHECK_HIP(hipMemcpyAsync(relayout_descs, h.data(), h.size() * sizeof(RelayoutDesc),
+                                     hipMemcpyHostToDevice, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // h goes out of scope
+    }
+    launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
+                                   wd_pool, relayout_bytes);
     wd_dirty = false;
 }
 

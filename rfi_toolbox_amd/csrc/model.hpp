@@ -76,6 +76,9 @@ struct rfi_model {
     float* wd_pool = nullptr;
     int64_t adam_step = 0;
     bool wd_dirty = true;
+    void* relayout_descs = nullptr;   // device table for the batched dgrad-layout rebuild
+    int relayout_n = 0;
+    double relayout_bytes = 0;
 
     // activations / workspaces for the prepared shape
     int pN = 0, pH = 0, pW = 0;

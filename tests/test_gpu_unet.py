@@ -116,7 +116,7 @@ def test_three_steps_golden_f4(golden_dir):
                     # an element whose gradient is ~0 can move by up to ~lr per step in either
                     # direction: nearly all elements within a fraction of lr, none beyond 2 lr / step
                     d = np.abs(v.numpy() - want)
-                    assert (d > 2.5e-4 * s).mean() <= 3e-2 and d.max() <= 2e-3 * s, (k, d.max())
+                    assert (d > 2.5e-4 * s).sum() <= max(2, 0.03 * d.size) and d.max() <= 2e-3 * s, (k, d.max())
             m.eval()
             ev = m.forward_nhwc(g["img"])
             m.train()
