@@ -130,6 +130,11 @@ int rfi_model_param_buffer(rfi_model* m, float** dptr, int64_t* n_floats);
 int rfi_model_store_grad(rfi_model* m, const char* name, void* host, size_t bytes);
 int rfi_model_store_adam(rfi_model* m, const char* name, void* host_m, void* host_v, size_t bytes,
                          int64_t* step);
+/* resume: load Adam moments of one parameter (reference layout) / set the step counter
+ * (the optimizer_state_dict the reference saves, train_model.py:180) */
+int rfi_model_load_adam(rfi_model* m, const char* name, const void* host_m, const void* host_v,
+                        size_t bytes);
+int rfi_model_set_adam_step(rfi_model* m, int64_t step);
 int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, double* step);
 /* read an internal activation / gradient buffer of the last prepared shape (parity debugging):
  * "encY1.<l>" "encY2.<l>" "decY1.<l>" "decY2.<l>" "concat.<l>" "pool.<l>" "bottY1" "bottY2" "logits"
@@ -138,6 +143,12 @@ int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, 
  * host == NULL only reports the element count. */
 int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t host_floats,
                            int64_t* n_floats);
+
+/* one batch of scripts/evaluate_model.py:40-51 entirely on device: forward in the CURRENT mode,
+ * sigmoid > threshold, confusion counts against the uint8 labels (non-zero == positive) */
+int rfi_model_eval_batch(rfi_model* m, const float* x_nhwc, int x_mem, const uint8_t* labels,
+                         int labels_mem, int n, int h, int w, float threshold, int64_t* tp,
+                         int64_t* fp, int64_t* fn);
 
 /* ---- data-parallel gradient exchange (new; the reference has no multi-GPU path) -------
  * RCCL over xGMI: ncclAllReduce(sum) of the flat gradient buffer on the ctx stream.

@@ -81,6 +81,9 @@ _PROTOS = {
     "rfi_model_param_buffer": (_i, [_vp, _pvp, _pi64]),
     "rfi_model_store_grad": (_i, [_vp, _cp, _vp, _sz]),
     "rfi_model_store_adam": (_i, [_vp, _cp, _vp, _vp, _sz, _pi64]),
+    "rfi_model_load_adam": (_i, [_vp, _cp, _vp, _vp, _sz]),
+    "rfi_model_set_adam_step": (_i, [_vp, _i64]),
+    "rfi_model_eval_batch": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _pi64, _pi64, _pi64]),
     "rfi_model_algorithmic_flops": (_i, [_vp, _i, _i, _i, _pd, _pd]),
     "rfi_model_debug_tensor": (_i, [_vp, _cp, _vp, _sz, _pi64]),
     "rfi_comm_unique_id": (_i, [_vp]),

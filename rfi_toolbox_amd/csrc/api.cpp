@@ -457,6 +457,31 @@ int rfi_model_store_adam(rfi_model* m, const char* name, void* host_m, void* hos
     });
 }
 
+int rfi_model_load_adam(rfi_model* m, const char* name, const void* host_m, const void* host_v,
+                        size_t bytes) {
+    return guarded([&] {
+        m->ctx->activate();
+        const Entry& e = find_entry(m, name);
+        RFI_REQUIRE(bytes == (size_t)e.numel() * sizeof(float), "size mismatch for " + e.name);
+        const size_t off = flat_offset(m, e);
+        for (int which = 0; which < 2; ++which) {
+            const float* src = static_cast<const float*>(which ? host_v : host_m);
+            if (!src) continue;
+            std::vector<float> tmp;
+            if (e.kind == 0) to_lib_conv(src, (int)e.dims[0], (int)e.dims[1], 3, tmp, m->convs[e.layer].cin_p);
+            else if (e.kind == 1) to_lib_convt(src, (int)e.dims[0], (int)e.dims[1], tmp);
+            else tmp.assign(src, src + e.numel());
+            upload(m, (which ? m->adam_v : m->adam_m) + off, tmp.data(), tmp.size());
+        }
+    });
+}
+int rfi_model_set_adam_step(rfi_model* m, int64_t step) {
+    return guarded([&] {
+        RFI_REQUIRE(step >= 0, "Adam step must be >= 0");
+        m->adam_step = step;
+    });
+}
+
 int rfi_model_set_training(rfi_model* m, int training) {
     return guarded([&] { m->training = training != 0; });
 }
@@ -608,6 +633,27 @@ int rfi_model_loss(rfi_model* m, const float* x, int x_mem, const uint8_t* label
         m->forward(xd, n, h, w, m->training);
         m->loss_forward(yd, n, h, w);
         if (loss_out) *loss_out = read_scalar(m, m->d_scalars);
+    });
+}
+
+int rfi_model_eval_batch(rfi_model* m, const float* x, int x_mem, const uint8_t* labels, int labels_mem, int n,
+                         int h, int w, float threshold, int64_t* tp, int64_t* fp, int64_t* fn) {
+    return guarded([&] {
+        RFI_REQUIRE(m->out_ch == 1, "eval_batch: defined for out_channels == 1");
+        m->ctx->activate();
+        m->prepare(n, h, w);
+        const float* xd = stage_input(m, x, x_mem, n, h, w, false);
+        const uint8_t* yd = stage_labels(m, labels, labels_mem, n, h, w);
+        m->forward(xd, n, h, w, m->training);
+        const int64_t cnt = (int64_t)n * h * w;
+        uint8_t* mask = reinterpret_cast<uint8_t*>(m->buf(m->out_stage));      // cnt bytes fit (cnt floats)
+        launch_threshold(m->ctx, m->buf(m->logits), cnt, threshold, mask);
+        auto* d3 = reinterpret_cast<unsigned long long*>(m->d_sums + 5);      // 3 spare 64-bit words
+        launch_confusion(m->ctx, mask, RFI_U8, yd, RFI_U8, cnt, d3);
+        unsigned long long h3[3];
+        RFI_CHECK_HIP(hipMemcpyAsync(h3, d3, sizeof(h3), hipMemcpyDeviceToHost, m->ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        *tp = (int64_t)h3[0]; *fp = (int64_t)h3[1]; *fn = (int64_t)h3[2];
     });
 }
 

@@ -336,6 +336,48 @@ class UNet:
                                          C.byref(n)))
         return out
 
+    def load_adam_state(self, name, m, v):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        check(lib.rfi_model_load_adam(self._h, name.encode(), m.ctypes.data_as(C.c_void_p),
+                                      v.ctypes.data_as(C.c_void_p), m.nbytes))
+
+    def set_adam_step(self, step):
+        check(lib.rfi_model_set_adam_step(self._h, int(step)))
+
+    def optimizer_state_dict(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):
+        """torch.optim.Adam-format state (what train_model.py:180 stores): parameter i is the
+        i-th entry of ``named_parameters()``, exactly torch's numbering of ``model.parameters()``."""
+        names = [n for n, _, k in self._entries if k in ("conv_w", "conv_b", "bn_g", "bn_b")]
+        state, step = {}, 0
+        for i, n in enumerate(names):
+            m, v, step = self.adam_state(n)
+            if step:
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": torch.from_numpy(m),
+                            "exp_avg_sq": torch.from_numpy(v)}
+        group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, osd):
+        names = [n for n, _, k in self._entries if k in ("conv_w", "conv_b", "bn_g", "bn_b")]
+        step = 0
+        for i, st in osd.get("state", {}).items():
+            n = names[int(i)]
+            self.load_adam_state(n, st["exp_avg"].detach().cpu().numpy(), st["exp_avg_sq"].detach().cpu().numpy())
+            step = max(step, int(float(st["step"])))
+        self.set_adam_step(step)
+
+    def eval_batch(self, data, mask, threshold=0.5):
+        """(tp, fp, fn) of one batch: forward, sigmoid > threshold, counts -- all on the GPU."""
+        n, h, w, xp, xm, yp, ym, keep = self._xy(data, mask, True)
+        tp, fp, fn = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.rfi_model_eval_batch(self._h, C.c_void_p(xp), xm, C.c_void_p(yp), ym, n, h, w, float(threshold),
+                                       C.byref(tp), C.byref(fp), C.byref(fn)))
+        del keep
+        return tp.value, fp.value, fn.value
+
     def algorithmic_flops(self, n, h, w):
         f, s = C.c_double(), C.c_double()
         check(lib.rfi_model_algorithmic_flops(self._h, n, h, w, C.byref(f), C.byref(s)))

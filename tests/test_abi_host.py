@@ -74,3 +74,29 @@ def test_python_argument_validation_without_gpu():
         Preprocessor(np.zeros((4, 4)))
     p = patchify(np.arange(16).reshape(4, 4), (2, 2), 2)
     assert p[0, 0].tolist() == [[0, 1], [4, 5]] and p[1, 1].tolist() == [[10, 11], [14, 15]]
+
+
+def test_batch_writer_shards_round_trip(tmp_path):
+    """reference shard format (datasets/batched_dataset.py:126-175): batch_%03d.pt + metadata.json."""
+    import json
+
+    from rfi_toolbox_amd.datasets import BatchWriter, TorchDataset, load_batches
+    imgs = torch.arange(7 * 4 * 4 * 3, dtype=torch.float32).reshape(7, 4, 4, 3)
+    labs = (torch.arange(7 * 16) % 3 == 0).to(torch.uint8).reshape(7, 4, 4)
+    w = BatchWriter(tmp_path / "shards", samples_per_batch=3)
+    w.add_batch(TorchDataset(imgs[:2], labs[:2]))
+    w.add_batch(TorchDataset(imgs[2:], labs[2:]))
+    meta = w.finalize()
+    assert sorted(p.name for p in (tmp_path / "shards").iterdir()) == ["batch_000.pt", "batch_001.pt", "batch_002.pt",
+                                                                      "metadata.json"]
+    assert meta["num_samples"] == 7 and meta["num_batches"] == 3 and meta["samples_per_batch"] == 3
+    shard = torch.load(tmp_path / "shards" / "batch_000.pt", weights_only=False)
+    assert set(shard) == {"images", "labels"} and len(shard["images"]) == 3
+    ds = load_batches(tmp_path / "shards")
+    assert torch.equal(ds.images, imgs) and torch.equal(ds.labels, labs)
+    assert json.load(open(tmp_path / "shards" / "metadata.json"))["dtype"] == "float32"
+    ds.save_to_disk(tmp_path / "one.pt")
+    back = TorchDataset.load_from_disk(tmp_path / "one.pt")
+    assert torch.equal(back.images, imgs) and back[1]["label"].shape == (4, 4)
+    with pytest.raises(AssertionError):
+        TorchDataset(imgs.double(), labs)
