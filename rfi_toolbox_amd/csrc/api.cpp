@@ -31,6 +31,17 @@ void rfi_ctx::release(void* p) {
     allocs.erase(it);
     RFI_CHECK_HIP(hipFree(p));
 }
+void* rfi_ctx::get_scratch(size_t bytes) {
+    if (bytes > scratch_bytes) {
+        if (scratch) {
+            RFI_CHECK_HIP(hipStreamSynchronize(stream));
+            release(scratch);
+        }
+        scratch = alloc(bytes);
+        scratch_bytes = bytes;
+    }
+    return scratch;
+}
 hipEvent_t rfi_ctx::get_event() {
     if (!event_pool.empty()) {
         hipEvent_t e = event_pool.back();
@@ -853,14 +864,15 @@ int rfi_preprocess_patches(rfi_ctx* ctx, const void* patches, int patches_mem, i
             tmp_out = ctx->alloc(px * 3 * sizeof(float));
             dout = static_cast<float*>(tmp_out);
         }
-        void* mm = ctx->alloc((size_t)n * 4 * sizeof(unsigned long long));
+        void* mm = ctx->get_scratch((size_t)n * 4 * sizeof(unsigned long long));
         launch_preprocess(ctx, din, dtype, n, ps_h, ps_w, static_cast<float*>(mm), dout);
         if (out_mem == RFI_HOST)
             RFI_CHECK_HIP(hipMemcpyAsync(out_nhwc, dout, px * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->release(mm);
-        if (tmp_in) ctx->release(tmp_in);
-        if (tmp_out) ctx->release(tmp_out);
+        if (tmp_in || tmp_out) {            // device-to-device calls stay asynchronous on the ctx stream
+            RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            if (tmp_in) ctx->release(tmp_in);
+            if (tmp_out) ctx->release(tmp_out);
+        }
     });
 }
 

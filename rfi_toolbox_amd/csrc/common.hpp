@@ -99,6 +99,10 @@ struct rfi_ctx {
     std::vector<hipEvent_t> event_pool;
     // pinned scratch for small D2H readbacks
     float* pinned = nullptr;
+    // grow-only device scratch (per-patch min/max words of the preprocessing kernels)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void* get_scratch(size_t bytes);
     // RCCL
     void* nccl_comm = nullptr;
     int rank = 0, world = 1;

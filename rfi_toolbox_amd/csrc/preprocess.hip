@@ -4,7 +4,10 @@
 // ImageNet normalisation, written NHWC.  Math in fp64 for 64-bit inputs exactly as NumPy does it,
 // rounded to fp32 where the reference casts (.astype(np.float32), :376) and normalised in fp32 (:783).
 // Also the confusion counts of evaluation/metrics.py and the sigmoid threshold of evaluate_model.py.
-// HBM-bound: 16 B in + 12 B out per pixel for complex128.
+// Algorithmic traffic 16 B in + 12 B out (+1 B label on the host side) per pixel for complex128;
+// the per-patch min-max forces a second, 24 B/pixel pass over the output.
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace rfi {
@@ -37,125 +40,7 @@ __device__ __forceinline__ T load_amp(const void* p, int dtype, int64_t i, T* ph
 __device__ __forceinline__ double logamp_d(double amp) { return log10(amp + 1e-10); }
 __device__ __forceinline__ float logamp_f(float amp) { return log10f(amp + 1e-10f); }
 
-// ordered-int encoding so float min/max can use integer atomics (handles negatives)
-__device__ __forceinline__ unsigned enc(float f) {
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float dec(unsigned u) {
-    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-
-// pass 1: per patch min/max of channel 0 (gradient) and of log-amp (real input's channel 1)
-// mm[patch*4 + {0,1,2,3}] = enc(min grad), enc(max grad), enc(min la), enc(max la)
-template <bool WIDE>
-__global__ void prep_minmax_kernel(const void* __restrict__ src, int dtype, int ph, int pw,
-                                   unsigned* __restrict__ mm) {
-    const int patch = blockIdx.y;
-    const int64_t base = (int64_t)patch * ph * pw;
-    float gmin = INFINITY, gmax = -INFINITY, lmin = INFINITY, lmax = -INFINITY;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ph * pw; i += gridDim.x * blockDim.x) {
-        const int r = i / pw, c = i % pw;
-        float g, laf;
-        if (WIDE) {
-            double phs;
-            const double la = logamp_d(load_amp<double>(src, dtype, base + i, &phs));
-            const double d0 = r > 0 ? la - logamp_d(load_amp<double>(src, dtype, base + i - pw, &phs)) : 0.0;
-            const double d1 = c > 0 ? la - logamp_d(load_amp<double>(src, dtype, base + i - 1, &phs)) : 0.0;
-            g = (float)sqrt(d0 * d0 + d1 * d1);
-            // min-max is taken in the source precision by the reference; order is preserved by
-            // the monotone rounding to float, the exact double extrema are recomputed in pass 2
-            laf = (float)la;
-        } else {
-            float phs;
-            const float la = logamp_f(load_amp<float>(src, dtype, base + i, &phs));
-            const float d0 = r > 0 ? la - logamp_f(load_amp<float>(src, dtype, base + i - pw, &phs)) : 0.0f;
-            const float d1 = c > 0 ? la - logamp_f(load_amp<float>(src, dtype, base + i - 1, &phs)) : 0.0f;
-            g = sqrtf(d0 * d0 + d1 * d1);
-            laf = la;
-        }
-        if (!isnan(g)) { gmin = fminf(gmin, g); gmax = fmaxf(gmax, g); }
-        if (!isnan(laf)) { lmin = fminf(lmin, laf); lmax = fmaxf(lmax, laf); }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        gmin = fminf(gmin, __shfl_down(gmin, o, 64));
-        gmax = fmaxf(gmax, __shfl_down(gmax, o, 64));
-        lmin = fminf(lmin, __shfl_down(lmin, o, 64));
-        lmax = fmaxf(lmax, __shfl_down(lmax, o, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mm[patch * 4 + 0], enc(gmin));
-        atomicMax(&mm[patch * 4 + 1], enc(gmax));
-        atomicMin(&mm[patch * 4 + 2], enc(lmin));
-        atomicMax(&mm[patch * 4 + 3], enc(lmax));
-    }
-}
-
-__global__ void prep_init_mm_kernel(unsigned* mm, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        mm[i * 4 + 0] = 0xffffffffu; mm[i * 4 + 1] = 0u;
-        mm[i * 4 + 2] = 0xffffffffu; mm[i * 4 + 3] = 0u;
-    }
-}
-
-template <bool WIDE>
-__global__ void prep_channels_kernel(const void* __restrict__ src, int dtype, int ph, int pw,
-                                     const unsigned* __restrict__ mm, float* __restrict__ out) {
-    const int patch = blockIdx.y;
-    const int64_t base = (int64_t)patch * ph * pw;
-    const bool is_complex = dtype == RFI_C128 || dtype == RFI_C64;
-    // the float-rounded extrema bracket the exact ones within 1 ulp(float); the reference's
-    // (g-min)/(max-min) is evaluated in source precision -> recover exact extrema for WIDE below
-    const float gminf = dec(mm[patch * 4 + 0]), gmaxf = dec(mm[patch * 4 + 1]);
-    const float lminf = dec(mm[patch * 4 + 2]), lmaxf = dec(mm[patch * 4 + 3]);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ph * pw; i += gridDim.x * blockDim.x) {
-        const int r = i / pw, c = i % pw;
-        float ch0, ch1, ch2;
-        if (WIDE) {
-            double phs, tmp;
-            const double la = logamp_d(load_amp<double>(src, dtype, base + i, &phs));
-            const double d0 = r > 0 ? la - logamp_d(load_amp<double>(src, dtype, base + i - pw, &tmp)) : 0.0;
-            const double d1 = c > 0 ? la - logamp_d(load_amp<double>(src, dtype, base + i - 1, &tmp)) : 0.0;
-            const double g = sqrt(d0 * d0 + d1 * d1);
-            const double gmin = (double)gminf, gmax = (double)gmaxf;
-            ch0 = (gmax > gmin) ? (float)((g - gmin) / (gmax - gmin)) : 0.0f;
-            if (is_complex) {
-                double v = (la - (-3.0)) / (4.0 - (-3.0));
-                v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-                ch1 = (float)v;
-                ch2 = (float)((phs + 3.141592653589793) / (2.0 * 3.141592653589793));
-            } else {
-                const double lmin = (double)lminf, lmax = (double)lmaxf;
-                ch1 = (lmax > lmin) ? (float)((la - lmin) / (lmax - lmin)) : 0.0f;
-                ch2 = 0.0f;
-            }
-        } else {
-            float phs, tmp;
-            const float la = logamp_f(load_amp<float>(src, dtype, base + i, &phs));
-            const float d0 = r > 0 ? la - logamp_f(load_amp<float>(src, dtype, base + i - pw, &tmp)) : 0.0f;
-            const float d1 = c > 0 ? la - logamp_f(load_amp<float>(src, dtype, base + i - 1, &tmp)) : 0.0f;
-            const float g = sqrtf(d0 * d0 + d1 * d1);
-            ch0 = (gmaxf > gminf) ? (g - gminf) / (gmaxf - gminf) : 0.0f;
-            if (is_complex) {
-                float v = (la + 3.0f) / 7.0f;
-                v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                ch1 = v;
-                ch2 = (phs + 3.14159265358979f) / (2.0f * 3.14159265358979f);
-            } else {
-                ch1 = (lmaxf > lminf) ? (la - lminf) / (lmaxf - lminf) : 0.0f;
-                ch2 = 0.0f;
-            }
-        }
-        float* o = out + (base + i) * 3;
-        o[0] = (ch0 - 0.485f) / 0.229f;
-        o[1] = (ch1 - 0.456f) / 0.224f;
-        o[2] = (ch2 - 0.406f) / 0.225f;
-    }
-}
-
-// exact fp64 extrema for 64-bit inputs (second reduction in double through 64-bit atomics)
+// ordered-int encoding so double min/max can use 64-bit integer atomics (handles negatives)
 __device__ __forceinline__ unsigned long long encd(double f) {
     unsigned long long u = (unsigned long long)__double_as_longlong(f);
     return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
@@ -164,71 +49,103 @@ __device__ __forceinline__ double decd(unsigned long long u) {
     return __longlong_as_double((long long)((u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u));
 }
 
-__global__ void prep_minmax64_kernel(const void* __restrict__ src, int dtype, int ph, int pw,
-                                     unsigned long long* __restrict__ mm) {
-    const int patch = blockIdx.y;
-    const int64_t base = (int64_t)patch * ph * pw;
-    double gmin = INFINITY, gmax = -INFINITY, lmin = INFINITY, lmax = -INFINITY;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ph * pw; i += gridDim.x * blockDim.x) {
-        const int r = i / pw, c = i % pw;
-        double phs;
-        const double la = logamp_d(load_amp<double>(src, dtype, base + i, &phs));
-        const double d0 = r > 0 ? la - logamp_d(load_amp<double>(src, dtype, base + i - pw, &phs)) : 0.0;
-        const double d1 = c > 0 ? la - logamp_d(load_amp<double>(src, dtype, base + i - 1, &phs)) : 0.0;
-        const double g = sqrt(d0 * d0 + d1 * d1);
-        if (!isnan(g)) { gmin = fmin(gmin, g); gmax = fmax(gmax, g); }
-        if (!isnan(la)) { lmin = fmin(lmin, la); lmax = fmax(lmax, la); }
+// ------------------------------------------------------------------ two passes, one log/phase per pixel
+// Pass 1: a block owns NPB consecutive pixels of one patch (row-major) plus the pw pixels before
+// them (the row above); log-amplitude is computed ONCE per pixel into LDS, channels 1 (log-amp) and
+// 2 (phase) leave in final form, the raw gradient magnitude goes to channel 0's slot and its
+// per-patch extrema to mm (ordered-int atomics).  Real input: raw log-amp goes to channel 1's slot
+// and its extrema to mm as well.  Pass 2 rescales the slots with the extrema.  T = double for
+// 64-bit inputs (NumPy's precision), float for 32-bit inputs.
+
+template <typename T> struct LogAmp;
+template <> struct LogAmp<double> { static __device__ double f(double a) { return log10(a + 1e-10); } };
+template <> struct LogAmp<float> { static __device__ float f(float a) { return log10f(a + 1e-10f); } };
+
+template <typename T>
+__global__ void prep_pass1_kernel(const void* __restrict__ src, int dtype, int ph, int pw, int NPB,
+                                  unsigned long long* __restrict__ mm, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* s_la = reinterpret_cast<T*>(smem_raw);                      // [pw + NPB]
+    const int patch = blockIdx.y, npix = ph * pw;
+    const int p0 = blockIdx.x * NPB;
+    const int64_t base = (int64_t)patch * npix;
+    const bool is_complex = dtype == RFI_C128 || dtype == RFI_C64;
+    // log-amp of [p0 - pw, p0 + NPB) ∩ [0, npix); channels 1/2 of the block's own pixels
+    for (int k = threadIdx.x; k < pw + NPB; k += blockDim.x) {
+        const int p = p0 - pw + k;
+        if (p < 0 || p >= npix) continue;
+        T phs;
+        const T la = LogAmp<T>::f(load_amp<T>(src, dtype, base + p, &phs));
+        s_la[k] = la;
+        if (p >= p0) {
+            float* o = out + (base + p) * 3;
+            if (is_complex) {
+                T v = (la - (T)(-3.0)) / (T)7.0;
+                v = v < (T)0 ? (T)0 : (v > (T)1 ? (T)1 : v);
+                o[1] = ((float)v - 0.456f) / 0.224f;
+                o[2] = ((float)((phs + (T)3.141592653589793) / (T)(2.0 * 3.141592653589793)) - 0.406f) / 0.225f;
+            } else {
+                o[1] = (float)la;                                   // rescaled by pass 2
+                o[2] = (0.0f - 0.406f) / 0.225f;
+            }
+        }
     }
+    __syncthreads();
+    T gmin = INFINITY, gmax = -INFINITY, lmin = INFINITY, lmax = -INFINITY;
+    for (int k = threadIdx.x; k < NPB; k += blockDim.x) {
+        const int p = p0 + k;
+        if (p >= npix) break;
+        const int r = p / pw, c = p % pw;
+        const T la = s_la[pw + k];
+        const T d0 = r > 0 ? la - s_la[k] : (T)0;                  // pixel p - pw
+        const T d1 = c > 0 ? la - s_la[pw + k - 1] : (T)0;
+        const T g = sqrt(d0 * d0 + d1 * d1);
+        out[(base + p) * 3] = (float)g;                             // rescaled by pass 2
+        if (!isnan(g)) { gmin = g < gmin ? g : gmin; gmax = g > gmax ? g : gmax; }
+        if (!isnan(la)) { lmin = la < lmin ? la : lmin; lmax = la > lmax ? la : lmax; }
+    }
+    double e[4] = {(double)gmin, (double)gmax, (double)lmin, (double)lmax};
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        gmin = fmin(gmin, __shfl_down(gmin, o, 64));
-        gmax = fmax(gmax, __shfl_down(gmax, o, 64));
-        lmin = fmin(lmin, __shfl_down(lmin, o, 64));
-        lmax = fmax(lmax, __shfl_down(lmax, o, 64));
+        e[0] = fmin(e[0], __shfl_down(e[0], o, 64));
+        e[1] = fmax(e[1], __shfl_down(e[1], o, 64));
+        e[2] = fmin(e[2], __shfl_down(e[2], o, 64));
+        e[3] = fmax(e[3], __shfl_down(e[3], o, 64));
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mm[patch * 4 + 0], encd(gmin));
-        atomicMax(&mm[patch * 4 + 1], encd(gmax));
-        atomicMin(&mm[patch * 4 + 2], encd(lmin));
-        atomicMax(&mm[patch * 4 + 3], encd(lmax));
+        atomicMin(&mm[patch * 4 + 0], encd(e[0]));
+        atomicMax(&mm[patch * 4 + 1], encd(e[1]));
+        atomicMin(&mm[patch * 4 + 2], encd(e[2]));
+        atomicMax(&mm[patch * 4 + 3], encd(e[3]));
     }
 }
+
+// pass 2: channel 0 <- (g - gmin)/(gmax - gmin) (0 when the patch is flat), real input also channel 1,
+// then the ImageNet normalisation of those slots.  The extrema are the exact T-precision values; g
+// was stored rounded to fp32, which moves the quotient by < 1 ulp(fp32).
+__global__ void prep_pass2_kernel(int real_input, int npix, const unsigned long long* __restrict__ mm,
+                                  float* __restrict__ out) {
+    const int patch = blockIdx.y;
+    const double gmin = decd(mm[patch * 4 + 0]), gmax = decd(mm[patch * 4 + 1]);
+    const double lmin = decd(mm[patch * 4 + 2]), lmax = decd(mm[patch * 4 + 3]);
+    const double gs = gmax > gmin ? 1.0 / (gmax - gmin) : 0.0, ls = lmax > lmin ? 1.0 / (lmax - lmin) : 0.0;
+    float* o = out + (int64_t)patch * npix * 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const float ch0 = gmax > gmin ? (float)(((double)o[i * 3] - gmin) / (gmax - gmin)) : 0.0f;
+        o[i * 3] = (ch0 - 0.485f) / 0.229f;
+        if (real_input) {
+            const float ch1 = lmax > lmin ? (float)(((double)o[i * 3 + 1] - lmin) / (lmax - lmin)) : 0.0f;
+            o[i * 3 + 1] = (ch1 - 0.456f) / 0.224f;
+        }
+    }
+    (void)gs; (void)ls;
+}
+
 __global__ void prep_init_mm64_kernel(unsigned long long* mm, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         mm[i * 4 + 0] = ~0ull; mm[i * 4 + 1] = 0ull;
         mm[i * 4 + 2] = ~0ull; mm[i * 4 + 3] = 0ull;
-    }
-}
-__global__ void prep_channels64_kernel(const void* __restrict__ src, int dtype, int ph, int pw,
-                                       const unsigned long long* __restrict__ mm, float* __restrict__ out) {
-    const int patch = blockIdx.y;
-    const int64_t base = (int64_t)patch * ph * pw;
-    const bool is_complex = dtype == RFI_C128;
-    const double gmin = decd(mm[patch * 4 + 0]), gmax = decd(mm[patch * 4 + 1]);
-    const double lmin = decd(mm[patch * 4 + 2]), lmax = decd(mm[patch * 4 + 3]);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ph * pw; i += gridDim.x * blockDim.x) {
-        const int r = i / pw, c = i % pw;
-        double phs, tmp;
-        const double la = logamp_d(load_amp<double>(src, dtype, base + i, &phs));
-        const double d0 = r > 0 ? la - logamp_d(load_amp<double>(src, dtype, base + i - pw, &tmp)) : 0.0;
-        const double d1 = c > 0 ? la - logamp_d(load_amp<double>(src, dtype, base + i - 1, &tmp)) : 0.0;
-        const double g = sqrt(d0 * d0 + d1 * d1);
-        float ch0 = (gmax > gmin) ? (float)((g - gmin) / (gmax - gmin)) : 0.0f;
-        float ch1, ch2;
-        if (is_complex) {
-            double v = (la - (-3.0)) / (4.0 - (-3.0));
-            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-            ch1 = (float)v;
-            ch2 = (float)((phs + 3.141592653589793) / (2.0 * 3.141592653589793));
-        } else {
-            ch1 = (lmax > lmin) ? (float)((la - lmin) / (lmax - lmin)) : 0.0f;
-            ch2 = 0.0f;
-        }
-        float* o = out + (base + i) * 3;
-        o[0] = (ch0 - 0.485f) / 0.229f;
-        o[1] = (ch1 - 0.456f) / 0.224f;
-        o[2] = (ch2 - 0.406f) / 0.225f;
     }
 }
 
@@ -273,48 +190,41 @@ void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int 
                        float* minmax_ws, float* out_nhwc) {
     RFI_REQUIRE(dtype >= RFI_C128 && dtype <= RFI_F32, "preprocess: unknown dtype");
     const int per = ph * pw;
-    int bx = (int)cdiv(per, kBlock);
-    if (bx > 64) bx = 64;
     const double in_b = dtype == RFI_C128 ? 16 : (dtype == RFI_F32 ? 4 : 8);
     const bool wide = dtype == RFI_C128 || dtype == RFI_F64;
-    if (wide) {
-        unsigned long long* mm = reinterpret_cast<unsigned long long*>(minmax_ws);
-        {
-            ProfScope ps(ctx, FAM_PREPROCESS);
-            hipLaunchKernelGGL(prep_init_mm64_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, ctx->stream, mm, n);
-            check_launch("prep_init_mm64");
-        }
-        {
-            ProfScope ps(ctx, FAM_PREPROCESS, 0, (double)n * per * in_b);
-            hipLaunchKernelGGL(prep_minmax64_kernel, dim3(bx, n), dim3(kBlock), 0, ctx->stream, patches,
-                               dtype, ph, pw, mm);
-            check_launch("prep_minmax64");
-        }
-        {
-            ProfScope ps(ctx, FAM_PREPROCESS, 0, (double)n * per * (in_b + 12));
-            hipLaunchKernelGGL(prep_channels64_kernel, dim3(bx, n), dim3(kBlock), 0, ctx->stream, patches,
-                               dtype, ph, pw, mm, out_nhwc);
-            check_launch("prep_channels64");
-        }
-    } else {
-        unsigned* mm = reinterpret_cast<unsigned*>(minmax_ws);
-        {
-            ProfScope ps(ctx, FAM_PREPROCESS);
-            hipLaunchKernelGGL(prep_init_mm_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, ctx->stream, mm, n);
-            check_launch("prep_init_mm");
-        }
-        {
-            ProfScope ps(ctx, FAM_PREPROCESS, 0, (double)n * per * in_b);
-            hipLaunchKernelGGL(prep_minmax_kernel<false>, dim3(bx, n), dim3(kBlock), 0, ctx->stream, patches,
-                               dtype, ph, pw, mm);
-            check_launch("prep_minmax");
-        }
-        {
-            ProfScope ps(ctx, FAM_PREPROCESS, 0, (double)n * per * (in_b + 12));
-            hipLaunchKernelGGL(prep_channels_kernel<false>, dim3(bx, n), dim3(kBlock), 0, ctx->stream,
-                               patches, dtype, ph, pw, mm, out_nhwc);
-            check_launch("prep_channels");
-        }
+    const bool real_input = dtype == RFI_F64 || dtype == RFI_F32;
+    unsigned long long* mm = reinterpret_cast<unsigned long long*>(minmax_ws);
+    {
+        ProfScope ps(ctx, FAM_PREPROCESS);
+        hipLaunchKernelGGL(prep_init_mm64_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, ctx->stream, mm, n);
+        check_launch("prep_init_mm64");
+    }
+    {
+        ProfScope ps(ctx, FAM_PREPROCESS, 0, (double)n * per * (in_b + 12));
+        // pixels per block: at least 4 rows so the halo row costs <= 25 % extra log/phase work
+        const int esz = wide ? 8 : 4;
+        int npb = std::max(2048, 4 * pw);
+        npb = std::min(npb, 64 * 1024 / esz - pw);
+        RFI_REQUIRE(npb >= pw, "preprocess: patch rows this long are not supported");
+        const dim3 grid((unsigned)cdiv(per, npb), n);
+        const size_t lds = (size_t)(pw + npb) * esz;
+        if (wide)
+            hipLaunchKernelGGL(prep_pass1_kernel<double>, grid, dim3(kBlock), lds, ctx->stream, patches, dtype, ph, pw,
+                               npb, mm, out_nhwc);
+        else
+            hipLaunchKernelGGL(prep_pass1_kernel<float>, grid, dim3(kBlock), lds, ctx->stream, patches, dtype, ph, pw,
+                               npb, mm, out_nhwc);
+        check_launch("prep_pass1");
+    }
+    {
+        ProfScope ps(ctx, FAM_PREPROCESS, 0, (double)n * per * 24);
+        int bx = (int)cdiv(per, kBlock * 4);
+        const int cap = std::max(1, 4096 / n);              // ~4096 blocks in total
+        if (bx > cap) bx = cap;
+        if (bx < 1) bx = 1;
+        hipLaunchKernelGGL(prep_pass2_kernel, dim3(bx, n), dim3(kBlock), 0, ctx->stream, real_input ? 1 : 0, per, mm,
+                           out_nhwc);
+        check_launch("prep_pass2");
     }
 }
 
