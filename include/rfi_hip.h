@@ -104,8 +104,8 @@ int rfi_model_forward_nchw(rfi_model* m, const float* x, int x_mem, int n, int h
  *      clip_grad_norm_(max_norm) (:149) -> Adam(lr, betas, eps, coupled L2 weight_decay)
  *      (:130,150).  labels are uint8 (N,H,W), non-zero == RFI.  fp32 throughout (the
  *      reference's CPU path; autocast/GradScaler are off there, :131,144). ---- */
-typedef struct rfi_hyper {
-    float lr, beta1, beta2, eps, weight_decay, max_grad_norm;
+typedef struct rfi_hyper {   /* doubles: the reference's hyper-parameters are python floats */
+    double lr, beta1, beta2, eps, weight_decay, max_grad_norm;
 } rfi_hyper;
 
 int rfi_train_step(rfi_model* m, const float* x_nhwc, int x_mem, const uint8_t* labels,

@@ -282,11 +282,13 @@ def train_step(state, adam, x_nchw, y, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
         for k, g in grads.items():
             g = g * coef
             p = state[k]
-            g = g + weight_decay * p
-            m = adam["m"][k].mul_(b1).add_(g, alpha=1 - b1)
+            # torch.optim.Adam's single-tensor CPU sequence (the one train_model.py:130,150 runs):
+            # add(alpha=wd) -> lerp_ -> mul_/addcmul_ -> sqrt/div/add_ -> addcdiv_
+            g = g.add(p, alpha=weight_decay)
+            m = adam["m"][k].lerp_(g, 1 - b1)
             v = adam["v"][k].mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
-            state[k] = p - (lr / bc1) * (m / denom)
+            state[k] = p.addcdiv(m, denom, value=-(lr / bc1))
         for k, v in bufs.items():
             state[k] = v
     return {"loss": float(loss), "grad_norm": float(total), "clip_coef": float(coef),

@@ -20,8 +20,8 @@ IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
 
 
 class Hyper(C.Structure):
-    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float)]
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("max_grad_norm", C.c_double)]
 
 
 def _load():

@@ -706,24 +706,28 @@ __global__ void sumsq_finish_kernel(const double* __restrict__ partial, int bloc
     }
 }
 
+// One Adam step with torch.optim.Adam's CPU (single-tensor) rounding sequence, which the golden
+// trajectories pin bit-for-bit on m and v: g' = fma(wd, p, g); m = lerp(m, g', 1-b1) = fma(1-b1, g'-m, m);
+// v = fma((1-b2) g', g', b2 v); p += (-(lr/bc1) m) / (sqrt(v)/sqrt(bc2) + eps).  The scalars are
+// formed in double on the host (python floats in the reference) and rounded to float once.
 __global__ void adam_kernel(AdamArgs a) {
     const float norm = (float)sqrt(a.sumsq[0]) * a.grad_scale;
     float coef = a.max_norm / (norm + 1e-6f);
     coef = coef > 1.0f ? 1.0f : coef;
     if (a.max_norm <= 0.0f) coef = 1.0f;   // clipping disabled
     const float gs = a.grad_scale;
-    const float step = a.lr / a.bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const float p = a.p[i];
         float g = (a.g[i] * gs) * coef;
-        g = g + a.wd * p;
-        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
-        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        g = __fmaf_rn(a.wd, p, g);
+        const float m0 = a.m[i];
+        const float m = __fmaf_rn(a.one_minus_beta1, g - m0, m0);
+        const float v = __fmaf_rn(a.one_minus_beta2 * g, g, a.beta2 * a.v[i]);
         a.m[i] = m;
         a.v[i] = v;
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-        a.p[i] = p - step * (m / denom);
+        a.p[i] = p + (a.neg_step * m) / denom;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) a.norm_out[0] = norm;
 }

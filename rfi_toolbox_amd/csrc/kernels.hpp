@@ -159,8 +159,9 @@ void launch_sumsq(rfi_ctx* ctx, const float* g, int64_t n, double* partial_ws, d
 size_t sumsq_ws_doubles(int64_t n);
 struct AdamArgs {
     float* p; float* g; float* m; float* v; int64_t n;
-    float lr, beta1, beta2, eps, wd, max_norm, grad_scale;
-    float bc1, bc2_sqrt;            // 1-beta1^t, sqrt(1-beta2^t)
+    float beta2, eps, wd, max_norm, grad_scale;
+    float one_minus_beta1, one_minus_beta2;   // formed in double, rounded once (as torch does)
+    float neg_step, bc2_sqrt;                 // -lr/(1-beta1^t), sqrt(1-beta2^t)
     const double* sumsq;            // device scalar: ||g||^2 BEFORE grad_scale
     float* norm_out;                // device scalar out: ||g*grad_scale||
 };

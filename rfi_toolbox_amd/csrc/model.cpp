@@ -540,10 +540,12 @@ void rfi_model::apply(const rfi_hyper& hp, float grad_scale) {
     adam_step += 1;
     AdamArgs a;
     a.p = params; a.g = grads; a.m = adam_m; a.v = adam_v; a.n = (int64_t)n_flat;
-    a.lr = hp.lr; a.beta1 = hp.beta1; a.beta2 = hp.beta2; a.eps = hp.eps; a.wd = hp.weight_decay;
-    a.max_norm = hp.max_grad_norm; a.grad_scale = grad_scale;
-    a.bc1 = (float)(1.0 - std::pow((double)hp.beta1, (double)adam_step));
-    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)hp.beta2, (double)adam_step));
+    a.beta2 = (float)hp.beta2; a.eps = (float)hp.eps; a.wd = (float)hp.weight_decay;
+    a.max_norm = (float)hp.max_grad_norm; a.grad_scale = grad_scale;
+    a.one_minus_beta1 = (float)(1.0 - hp.beta1);
+    a.one_minus_beta2 = (float)(1.0 - hp.beta2);
+    a.neg_step = (float)(-(hp.lr / (1.0 - std::pow(hp.beta1, (double)adam_step))));
+    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(hp.beta2, (double)adam_step));
     a.sumsq = d_sums + 4;
     a.norm_out = d_scalars + 1;
     launch_adam(ctx, a);

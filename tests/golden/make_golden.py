@@ -141,10 +141,17 @@ def run_steps(model, img, lab, steps, lr, wd, record):
     crit = nn.BCEWithLogitsLoss()
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
     losses, norms = [], []
+    # distance of the nearest training-mode BatchNorm output to the ReLU threshold, per step: a
+    # fixture with an element within float32 rounding of 0 makes every backward comparison a coin flip
+    margins, cur = [], []
+    hooks = [mod.register_forward_hook(lambda _m, _i, o: cur.append(float(o.detach().abs().min())) if _m.training else None)
+             for mod in model.modules() if isinstance(mod, nn.BatchNorm2d)]
     for s in range(1, steps + 1):
         model.train()
         opt.zero_grad()
+        cur.clear()
         out = model(x)
+        margins.append(min(cur))
         loss = crit(out, y) + dice_loss(out, y)
         loss.backward()
         norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
@@ -167,23 +174,30 @@ def run_steps(model, img, lab, steps, lr, wd, record):
             model.eval()
             with torch.no_grad():
                 record[f"logits_eval{s}"] = model(x).numpy().copy()
+    for h in hooks:
+        h.remove()
     record["losses"] = np.array(losses, dtype=np.float64)
     record["grad_norms"] = np.array(norms, dtype=np.float64)
+    record["relu_margin"] = np.array(margins, dtype=np.float64)
     return x, y
 
 
 def golden_unet_small():
     """f=4, batch 4, 32x32: complete state before/after steps 1 and 3 (+Adam moments)."""
     img, lab = make_batch(1234, 32)
-    torch.manual_seed(1234)
-    model = UNet(in_channels=3, out_channels=1, init_features=4)
-    rec = {"_grad_steps": (1,), "_state_steps": (1, 3), "_adam_steps": (3,)}
-    for k, v in sd_np(model).items():
-        rec[f"state0/{k}"] = v
-    model.eval()
-    with torch.no_grad():
-        rec["logits_eval0"] = model(torch.from_numpy(img).permute(0, 3, 1, 2).contiguous()).numpy()
-    run_steps(model, img, lab, 3, lr=1e-3, wd=1e-5, record=rec)
+    for seed in range(1234, 1300):        # first init seed whose 3 steps stay clear of a ReLU threshold
+        torch.manual_seed(seed)
+        model = UNet(in_channels=3, out_channels=1, init_features=4)
+        rec = {"_grad_steps": (1,), "_state_steps": (1, 3), "_adam_steps": (3,)}
+        for k, v in sd_np(model).items():
+            rec[f"state0/{k}"] = v
+        model.eval()
+        with torch.no_grad():
+            rec["logits_eval0"] = model(torch.from_numpy(img).permute(0, 3, 1, 2).contiguous()).numpy()
+        run_steps(model, img, lab, 3, lr=1e-3, wd=1e-5, record=rec)
+        print(f"unet_f4 init seed {seed}: relu margins {rec['relu_margin']}")
+        if rec["relu_margin"].min() > 1e-5:
+            break
     rec = {k: v for k, v in rec.items() if not k.startswith("_")}
     rec.update(img=img, lab=lab, names=np.array(list(model.state_dict().keys())),
                hyper=np.array([1e-3, 0.9, 0.999, 1e-8, 1e-5, 1.0]))

@@ -74,35 +74,33 @@ def test_forward_golden_f4(golden_dir):
 
 
 def test_three_steps_golden_f4(golden_dir):
+    """Three reference optimisation steps (train_model.py:139-154) replayed on MI355X.  The fixture's
+    init seed was chosen so that no BatchNorm output sits within 1e-5 of the ReLU threshold
+    (`relu_margin`, tests/golden/make_golden.py), so the comparison measures arithmetic, not a coin
+    flip: gradients agree to ~1e-5 relative, weights / Adam moments to float32 rounding."""
     g = _load(golden_dir, "unet_f4_b4_s32.npz")
+    assert g["relu_margin"].min() > 1e-5
     lr, b1, b2, eps, wd, clip = [float(v) for v in g["hyper"]]
     m = UNet(3, 1, 4).load_state_dict(_state(g, "state0"))
     for s in (1, 2, 3):
         if s == 1:
             loss = m.forward_backward(g["img"], g["lab"])
-            # golden grads are post-clip: compare direction and scale via the clip coefficient
+            # golden grads are post-clip: compare via the clip coefficient
             gn = float(g["grad_norms"][0])
             coef = min(1.0, clip / (gn + 1e-6))
-            rels = []
             for k in [k[6:] for k in g.files if k.startswith("grad1/")]:
                 want = g[f"grad1/{k}"]
-                if _is_prebn_bias(k):
+                if _is_prebn_bias(k):         # exact gradient is 0: both sides hold rounding noise
                     np.testing.assert_allclose(m.grad(k) * coef, want, rtol=0, atol=1e-6, err_msg=k)
                     continue
-                # relative L2 per tensor; this 4x2x2-pixel-bottleneck net is ill-conditioned and a
-                # single ReLU input at the threshold (see test_flagship_width_vs_oracle) moves
-                # gradients everywhere downstream by ~1e-2, so: every tensor within 2e-2 (the well-conditioned
-                # flagship-width test bounds the typical tensor at the fp32 oracle's own noise level)
                 rel = np.linalg.norm(m.grad(k) * coef - want) / (np.linalg.norm(want) + 1e-30)
-                assert rel <= 2e-2, (k, rel)
-                rels.append(rel)
-            assert np.median(rels) <= 1e-2, np.median(rels)
+                assert rel <= 5e-5, (k, rel)
             norm = m.apply_gradients(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, max_grad_norm=clip)
-            assert norm == pytest.approx(gn, rel=5e-3)
+            assert norm == pytest.approx(gn, rel=1e-5)
         else:
             loss = m.train_step(g["img"], g["lab"], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd,
                                 max_grad_norm=clip)
-        assert loss == pytest.approx(float(g["losses"][s - 1]), abs=2e-5 if s == 1 else 2e-4 * s), s
+        assert loss == pytest.approx(float(g["losses"][s - 1]), abs=2e-6), s
         if s in (1, 3):
             sd = m.state_dict()
             for k, v in sd.items():
@@ -110,26 +108,21 @@ def test_three_steps_golden_f4(golden_dir):
                 if k.endswith("num_batches_tracked"):
                     assert int(v) == int(want), k
                 elif _is_prebn_bias(k):
-                    np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=3e-3, err_msg=k)
+                    # Adam turns the noise gradient of these biases into +-lr per step, either sign
+                    np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=2.2 * lr * s, err_msg=k)
                 else:
-                    # Adam normalises every update to O(lr) = 1e-3 whatever the gradient's size, so
-                    # an element whose gradient is ~0 can move by up to ~lr per step in either
-                    # direction: nearly all elements within a fraction of lr, none beyond 2 lr / step
-                    # (after 3 such steps on this 16-sample-BatchNorm net the weights have drifted apart
-                    # everywhere by a fraction of lr, so only the bound is asserted there)
-                    d = np.abs(v.numpy() - want)
-                    assert d.max() <= 2e-3 * s, (k, d.max())
-                    if s == 1:
-                        assert (d > 2.5e-4).sum() <= max(2, 0.03 * d.size), (k, d.max())
+                    np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=1e-4, err_msg=k)
             m.eval()
             ev = m.forward_nhwc(g["img"])
             m.train()
-            np.testing.assert_allclose(ev[..., 0], g[f"logits_eval{s}"][:, 0], rtol=0, atol=2e-3)
+            # eval mode sees the +-lr pre-BN biases through the running means: ~1e-4 on the logits
+            np.testing.assert_allclose(ev[..., 0], g[f"logits_eval{s}"][:, 0], rtol=0, atol=1e-3)
     for k in ("encoder1.conv.conv.0.weight", "decoder2.up.weight", "final_conv.weight"):
         mm, vv, step = m.adam_state(k)
         assert step == 3
-        np.testing.assert_allclose(mm, g[f"adam_m3/{k}"], rtol=0, atol=2e-5)
-        np.testing.assert_allclose(vv, g[f"adam_v3/{k}"], rtol=0, atol=1e-6)
+        wm, wv = g[f"adam_m3/{k}"], g[f"adam_v3/{k}"]
+        assert np.linalg.norm(mm - wm) <= 2e-5 * np.linalg.norm(wm), k
+        assert np.linalg.norm(vv - wv) <= 2e-5 * np.linalg.norm(wv), k
 
 
 def test_trained_weights_inference_iou(golden_dir):

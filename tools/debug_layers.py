@@ -19,6 +19,11 @@ g = torch.Generator().manual_seed(5)
 x = torch.randn(n, size, size, 3, generator=g)
 y = (torch.rand(n, size, size, generator=g) > 0.8).to(torch.uint8)
 y[:, :, 10:14] = 1
+if len(sys.argv) > 4:                      # golden fixture: its own initial state and batch
+    gz = np.load(sys.argv[4])
+    st = OrderedDict((k[7:], torch.from_numpy(gz[k])) for k in gz.files if k.startswith("state0/"))
+    m.load_state_dict(st)
+    x, y = torch.from_numpy(gz["img"]), torch.from_numpy(gz["lab"])
 xo, yo = unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1)
 
 
