@@ -36,35 +36,39 @@ def usable_cpus():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(features, size, seconds_cap=25.0):
+def cpu_baseline(workload, features, size, seconds_cap=25.0):
     """The oracle (torch-CPU fp32 restatement of the reference step) timed on this host: batch 4
-    (BASELINE config 0), all host threads.  A reported baseline, not the target."""
-    from collections import OrderedDict
-
+    (BASELINE config 0; batch 1 for the 1024x1024 workload), all host threads.  A reported baseline,
+    not the target."""
     import torch
 
-    from oracle import unet_ref
+    from oracle import cnn_ref, unet_ref
     threads = usable_cpus()
     torch.set_num_threads(threads)
-    st = unet_ref.init_state(3, 1, features, seed=0)
+    if workload == "cnn3":
+        st, step, what = cnn_ref.init_state(3, 1, features, seed=0), cnn_ref.train_step, f"cnn_ref SimpleCNN(3,1,{features})"
+    else:
+        st, step, what = unet_ref.init_state(3, 1, features, seed=0), unet_ref.train_step, f"unet_ref UNet(3,1,{features})"
+    batch, warm, timed = (1, 1, 3) if size >= 512 else (4, 2, 10)
     adam = unet_ref.new_adam_state(st)
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(4, 3, size, size, generator=g)
-    y = (torch.rand(4, 1, size, size, generator=g) > 0.8).float()
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = (torch.rand(batch, 1, size, size, generator=g) > 0.8).float()
     t_all0 = time.perf_counter()
     times = []
-    for i in range(2 + 10):
+    for i in range(warm + timed):
         t0 = time.perf_counter()
-        unet_ref.train_step(st, adam, x, y, lr=1e-4, weight_decay=1e-5)
+        step(st, adam, x, y, lr=1e-4, weight_decay=1e-5)
         dt = time.perf_counter() - t0
-        if i >= 2:
+        if i >= warm:
             times.append(dt)
         if time.perf_counter() - t_all0 > seconds_cap and len(times) >= 2:
             break
     med = float(np.median(times))
-    return {"value": round(4 / med, 3), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/unet_ref.train_step, UNet(3,1,{features}) batch 4 x {size}x{size}x3 fp32, "
-                      f"{len(times)} timed steps after 2 warm-up, median {med * 1e3:.1f} ms/step, "
+    return {"value": round(batch / med, 3), "unit": "patches/s" if size < 512 else "samples/s", "cores": threads,
+            "kind": "port",
+            "sample": f"oracle/{what}.train_step, batch {batch} x {size}x{size}x3 fp32, "
+                      f"{len(times)} timed steps after {warm} warm-up, median {med * 1e3:.1f} ms/step, "
                       f"torch.set_num_threads({threads})"}
 
 
@@ -80,20 +84,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="patches per GPU per step")
-    ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--features", type=int, default=32)
+    ap.add_argument("--workload", choices=("unet", "cnn3", "unet1024"), default="unet",
+                    help="unet: UNet(3,1,32) batch 64 x 128^2 (headline, BASELINE configs[1]/[4] shape); "
+                         "cnn3: the builder-defined 3-layer CNN of configs[1] (SURVEY 8a A9), batch 64 x 128^2; "
+                         "unet1024: UNet(3,1,32) on 1 x 1024^2 (configs[2] shape, fp32)")
+    ap.add_argument("--batch", type=int, default=None, help="patches per GPU per step")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--features", type=int, default=None)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-csv", default=None, help="write the per-launch HIP-event profile here")
     args = ap.parse_args()
+
+    if args.batch is None:
+        args.batch = 1 if args.workload == "unet1024" else 64
+    if args.size is None:
+        args.size = 1024 if args.workload == "unet1024" else 128
+    if args.features is None:
+        args.features = 64 if args.workload == "cnn3" else 32
 
     import torch
 
     from rfi_toolbox_amd import distributed as D
     from rfi_toolbox_amd._lib import Hyper
     from rfi_toolbox_amd.data_generation import make_training_patches
-    from rfi_toolbox_amd.models import UNet
+    from rfi_toolbox_amd.models import SimpleCNN, UNet
     from rfi_toolbox_amd.runtime import Context
 
     log("imports done")
@@ -104,7 +119,10 @@ def main():
     D.init_gradient_exchange(ctx, rank, world)
 
     torch.manual_seed(1234)                       # identical replicas on every rank
-    model = UNet(3, 1, args.features, device=local_rank)
+    if args.workload == "cnn3":
+        model = SimpleCNN(3, 1, args.features, device=local_rank)
+    else:
+        model = UNet(3, 1, args.features, device=local_rank)
     model.train()
     log("model built")
     B, S = args.batch, args.size
@@ -161,12 +179,14 @@ def main():
         if f["bytes"]:
             per["gbs"] = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else None
         fam_out[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in per.items()}
-    dom = "conv_igemm_mfma"
+    # the kernel family the step spends most time in (conv_igemm_mfma for the U-Net)
+    mfma_fams = [k for k in ("conv_igemm_mfma", "wgrad_igemm_mfma") if k in fam and fam[k]["ms"]]
+    dom = max(mfma_fams, key=lambda k: fam[k]["ms"]) if mfma_fams else "conv_igemm_mfma"
     # HBM bytes per launch of the dominant family from the committed rocprofv3 PMC passes of this
     # same command (bench.py cannot run under the profiler and time itself at once)
     import glob
     traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if traffic_files:
+    if traffic_files and args.workload == "unet":
         try:
             tj = json.load(open(traffic_files[-1]))["families"].get(dom)
             if tj:
@@ -182,12 +202,19 @@ def main():
                     algorithmic_flops_per_launch=fam[dom]["flops"] / fam[dom]["launches"])
     step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
     out = {
-        "metric": "training patches/sec (128x128x3)", "value": round(value, 2), "unit": "patches/s",
+        "metric": ("training patches/sec (128x128x3)" if S == 128 else f"training samples/sec ({S}x{S}x3)"),
+        "value": round(value, 2), "unit": "patches/s" if S < 512 else "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"UNet(3,1,{args.features}) train step (fwd+BCE/dice+bwd+clip+Adam), "
-                               f"batch {B}/GPU x {S}x{S}x3 NHWC fp32, BASELINE configs[1] shape on the "
-                               "reference's U-Net (the '3-layer CNN' of configs[1] is not in the reference)",
+        "config": {"workload": {
+            "unet": f"UNet(3,1,{args.features}) train step (fwd+BCE/dice+bwd+clip+Adam), "
+                    f"batch {B}/GPU x {S}x{S}x3 NHWC fp32, BASELINE configs[1] shape on the "
+                    "reference's U-Net (the '3-layer CNN' of configs[1] is not in the reference; "
+                    "its builder-defined form runs with --workload cnn3)",
+            "cnn3": f"SimpleCNN(3,1,{args.features}) = Conv3x3+ReLU, Conv3x3+ReLU, Conv1x1 (BASELINE configs[1]; "
+                    f"builder-defined, SURVEY 8a A9) train step, batch {B}/GPU x {S}x{S}x3 NHWC fp32",
+            "unet1024": f"UNet(3,1,{args.features}) train step on {B} x {S}x{S}x3 per GPU, fp32 "
+                        "(BASELINE configs[2] shape on the reference's U-Net)"}[args.workload],
                    "global_batch": B * world, "patch": [S, S, 3], "parallelism": f"dp{world}",
                    "params": model.num_parameters()},
         "roofline": roof,
@@ -199,7 +226,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline ...")
-        out["cpu_baseline"] = cpu_baseline(args.features, S)
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.features, S)
     print(json.dumps(out))
 
 

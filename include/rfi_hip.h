@@ -72,6 +72,11 @@ int rfi_profile_dump(rfi_ctx* ctx, const char* csv_path);
  *      is depth=5) as constructed by scripts/train_model.py:111, evaluate_model.py:34 ---- */
 int rfi_unet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_features,
                     int depth, rfi_model** out);
+/* the "3-layer CNN segmenter" of BASELINE.json configs[0]/[1] (not a reference
+ * class -- nearest text is the elided example README.md:379-398): Conv3x3(in->width,p1)+ReLU ->
+ * Conv3x3(width->width,p1)+ReLU -> Conv1x1(width->out) logits.  Entries: encoder.0.weight/bias,
+ * encoder.2.weight/bias, decoder.0.weight/bias.  Every rfi_model_* / rfi_train_* call below applies. */
+int rfi_cnn3_create(rfi_ctx* ctx, int in_channels, int out_channels, int width, rfi_model** out);
 int rfi_model_destroy(rfi_model* m);
 /* deterministic init with torch's default distributions (kaiming-uniform(a=sqrt5) conv
  * weights/biases, BN gamma=1 beta=0, running stats 0/1) from a 64-bit seed */

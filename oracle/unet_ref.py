@@ -246,7 +246,8 @@ def new_adam_state(state):
             "v": {k: torch.zeros_like(state[k]) for k in param_names(state)}}
 
 
-def loss_and_grads(state, x_nchw, y, training=True, tape=None):
+def loss_and_grads(state, x_nchw, y, training=True, tape=None, forward_fn=None):
+    """``forward_fn`` defaults to the U-Net ``forward``; oracle/cnn_ref.py passes its own."""
     names = param_names(state)
     work = OrderedDict(state)
     leaves = []
@@ -255,7 +256,7 @@ def loss_and_grads(state, x_nchw, y, training=True, tape=None):
         work[k] = t
         leaves.append(t)
     bufs = {}
-    logits = forward(work, x_nchw, training=training, buffer_updates=bufs, tape=tape)
+    logits = (forward_fn or forward)(work, x_nchw, training=training, buffer_updates=bufs, tape=tape)
     loss = segmentation_loss(logits, y)
     grads = torch.autograd.grad(loss, leaves)
     return loss.detach(), logits.detach(), OrderedDict(zip(names, grads)), bufs
@@ -269,9 +270,9 @@ def clip_coefficient(grads, max_norm=1.0):
 
 
 def train_step(state, adam, x_nchw, y, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-               weight_decay=1e-5, clip=1.0, tape=None):
+               weight_decay=1e-5, clip=1.0, tape=None, forward_fn=None):
     """One optimisation step in place on ``state``/``adam``.  Returns dict of scalars+grads."""
-    loss, logits, grads, bufs = loss_and_grads(state, x_nchw, y, training=True, tape=tape)
+    loss, logits, grads, bufs = loss_and_grads(state, x_nchw, y, training=True, tape=tape, forward_fn=forward_fn)
     total, coef = clip_coefficient(grads, clip)
     adam["step"] += 1
     t = adam["step"]

@@ -21,7 +21,7 @@ LIB = os.path.join(PKG, "librfi_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["api.cpp", "model.cpp", "elem_kernels.hip", "conv_direct.hip", "conv_mfma.hip",
+SOURCES = ["api.cpp", "model.cpp", "model_cnn.cpp", "elem_kernels.hip", "conv_direct.hip", "conv_mfma.hip",
            "wgrad_mfma.hip", "preprocess.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "model.hpp", os.path.join(ROOT, "include", "rfi_hip.h")]
 

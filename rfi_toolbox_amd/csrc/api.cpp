@@ -249,6 +249,26 @@ int rfi_unet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_fe
         *out = m;
     });
 }
+int rfi_cnn3_create(rfi_ctx* ctx, int in_channels, int out_channels, int width, rfi_model** out) {
+    return guarded([&] {
+        RFI_REQUIRE(ctx && out, "rfi_cnn3_create: null argument");
+        auto* m = new rfi_model();
+        m->ctx = ctx;
+        m->arch = 1;
+        m->in_ch = in_channels;
+        m->out_ch = out_channels;
+        m->feat = width;
+        m->depth = 0;
+        try {
+            m->build();
+        } catch (...) {
+            m->ctx = nullptr;
+            delete m;
+            throw;
+        }
+        *out = m;
+    });
+}
 int rfi_model_destroy(rfi_model* m) {
     return guarded([&] {
         if (!m) return;
@@ -371,12 +391,7 @@ int rfi_model_init(rfi_model* m, uint64_t seed) {
             }
         }
         upload(m, m->params, flat.data(), m->n_flat);
-        for (auto& c : m->convs) {
-            std::vector<float> ch((size_t)8 * c.cout, 0.0f);
-            for (int i = 0; i < c.cout; ++i) ch[c.cout + i] = 1.0f;     // running_var = 1
-            upload(m, c.chan, ch.data(), ch.size());
-            c.nbt = 0;
-        }
+        m->reset_channel_state();
         RFI_CHECK_HIP(hipMemsetAsync(m->adam_m, 0, m->n_flat * sizeof(float), m->ctx->stream));
         RFI_CHECK_HIP(hipMemsetAsync(m->adam_v, 0, m->n_flat * sizeof(float), m->ctx->stream));
         m->adam_step = 0;
@@ -696,6 +711,8 @@ int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t h
         const float* src = nullptr;
         size_t n = 0;
         const int D = m->depth;
+        RFI_REQUIRE(m->arch == 0 || base == "logits" || base == "dlogits" || base == "chan",
+                    "debug_tensor: this model exposes only logits / dlogits / chan");
         auto level = [&](const std::vector<int>& v, size_t chmul) {
             RFI_REQUIRE(idx >= 1 && idx <= D, "debug_tensor: level out of range");
             const size_t M = (size_t)m->pN * (m->pH >> (idx - 1)) * (m->pW >> (idx - 1));
@@ -740,6 +757,14 @@ int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, 
         // 2*M*K*N over every conv / convT / head, each layer evaluated once
         double f = 0, stem = 0;
         const int D = m->depth;
+        if (m->arch == 1) {             // 3-layer CNN: two 3x3 convs at full resolution + the 1x1 head
+            const double M = (double)n * h * w;
+            stem = 2.0 * M * 9.0 * m->convs[0].cin * m->convs[0].cout;
+            f = stem + 2.0 * M * 9.0 * m->convs[1].cin * m->convs[1].cout + 2.0 * M * (double)m->feat * m->out_ch;
+            if (fwd) *fwd = f;
+            if (step) *step = 3.0 * f - stem;
+            return;
+        }
         for (size_t ci = 0; ci < m->convs.size(); ++ci) {
             int lvl;
             if ((int)ci < 2 * D) lvl = (int)ci / 2 + 1;

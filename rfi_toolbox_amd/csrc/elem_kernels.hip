@@ -652,6 +652,18 @@ __global__ void weight_to_dgrad_batched_kernel(const RelayoutDesc* __restrict__ 
         wd[i] = wf[((int64_t)ts * d.cout + co) * d.cin + ci];
     }
 }
+__global__ void relu_bwd_kernel(float4* __restrict__ dA, const float4* __restrict__ Y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 g = dA[i];
+        const float4 y = Y[i];
+        g.x = y.x > 0.0f ? g.x : 0.0f;
+        g.y = y.y > 0.0f ? g.y : 0.0f;
+        g.z = y.z > 0.0f ? g.z : 0.0f;
+        g.w = y.w > 0.0f ? g.w : 0.0f;
+        dA[i] = g;
+    }
+}
 __global__ void pad_channels_kernel(const float* __restrict__ s, int64_t M, int c, int cp,
                                     float* __restrict__ d) {
     const int64_t total = M * cp;
@@ -1018,6 +1030,13 @@ void launch_weight_to_dgrad_batched(rfi_ctx* ctx, const RelayoutDesc* descs_dev,
     hipLaunchKernelGGL(weight_to_dgrad_batched_kernel, dim3(64, n), dim3(kBlock), 0, ctx->stream, descs_dev, src,
                        dst);
     check_launch("weight_to_dgrad_batched");
+}
+void launch_relu_bwd(rfi_ctx* ctx, float* dA, const float* Y, int64_t n) {
+    RFI_REQUIRE(n % 4 == 0, "relu_bwd: element count must be a multiple of 4");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * 12);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<float4*>(dA), reinterpret_cast<const float4*>(Y), n / 4);
+    check_launch("relu_bwd");
 }
 void launch_pad_channels(rfi_ctx* ctx, const float* src, int64_t M, int c, int cp, float* dst) {
     ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * (c + cp) * 4);

@@ -151,6 +151,8 @@ void launch_weight_to_dgrad_batched(rfi_ctx* ctx, const RelayoutDesc* descs_dev,
                                     float* dst, double total_bytes);
 void launch_u8_to_f32(rfi_ctx* ctx, const uint8_t* src, int64_t n, float* dst);
 // dst[m][0..cp) = src[m][0..c) followed by zeros (channel padding of the network input to a multiple of 4)
+// dA[i] = Y[i] > 0 ? dA[i] : 0  (backward of a BN-less Conv -> ReLU; n % 4 == 0)
+void launch_relu_bwd(rfi_ctx* ctx, float* dA, const float* Y, int64_t n);
 void launch_pad_channels(rfi_ctx* ctx, const float* src, int64_t M, int c, int cp, float* dst);
 
 // ---------------------------------------------------------------- optimiser

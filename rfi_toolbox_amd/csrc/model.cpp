@@ -53,6 +53,7 @@ rfi_model::~rfi_model() {
 
 // ------------------------------------------------------------------------------------ build
 void rfi_model::build() {
+    if (arch == 1) return build_cnn3();
     RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
     RFI_REQUIRE(depth >= 1 && depth <= 6, "UNet: depth must be in [1,6]");
     const int D = depth;
@@ -188,11 +189,26 @@ void rfi_model::build() {
     }
     adam_step = 0;
     wd_dirty = true;
+    reset_channel_state();
+}
+
+void rfi_model::reset_channel_state() {
+    for (auto& c : convs) {
+        std::vector<float> ch((size_t)8 * c.cout, 0.0f);
+        for (int i = 0; i < c.cout; ++i) ch[c.cout + i] = 1.0f;                          // running_var = 1
+        if (!c.has_bn)
+            for (int i = 0; i < c.cout; ++i) ch[(size_t)4 * c.cout + i] = 1.0f;          // scale = 1, shift = 0
+        RFI_CHECK_HIP(hipMemcpyAsync(c.chan, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice,
+                                     ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        c.nbt = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------ prepare
 void rfi_model::prepare(int n, int h, int w) {
     RFI_REQUIRE(n > 0 && h > 0 && w > 0, "forward: empty batch or image");
+    if (arch == 1) return prepare_cnn3(n, h, w);
     const int div = 1 << depth;
     RFI_REQUIRE(h % div == 0 && w % div == 0,
                 "forward: H and W must be multiples of 2^depth (" + std::to_string(div) +
@@ -349,6 +365,7 @@ rfi::View rfi_model::network_input(const float* x_dev, int n, int h, int w) {
 
 void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode) {
     prepare(n, h, w);
+    if (arch == 1) return forward_cnn3(x_dev, n, h, w);
     const int D = depth;
     View cur = network_input(x_dev, n, h, w);
     for (int l = 1; l <= D; ++l) {
@@ -453,6 +470,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
 }  // namespace
 
 void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
+    if (arch == 1) return backward_cnn3(x_dev, labels_dev, n, h, w);
     const int D = depth;
     const int64_t M1 = (int64_t)n * h * w;
     refresh_dgrad_weights();

@@ -19,6 +19,7 @@ struct ConvBN {
     int cin_p = 0;                      // cin rounded up to a multiple of 4 (library layout; zero padded)
     size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;   // offsets into the flat param/grad buffers
     int ema_repeats = 1;
+    bool has_bn = true;                 // false: Conv+bias -> ReLU (SimpleCNN); scale=1, shift=0 stay fixed
     int64_t nbt = 0;                    // num_batches_tracked (host side)
     // device per-channel state: [running_mean | running_var | mean | invstd | scale | shift | c1 | c2]
     float* chan = nullptr;
@@ -61,6 +62,7 @@ struct Entry {
 struct rfi_model {
     rfi_ctx* ctx = nullptr;
     int in_ch = 0, out_ch = 0, feat = 0, depth = 0;
+    int arch = 0;                     // 0: U-Net (models/unet.py), 1: 3-layer CNN (depth == 0)
     bool training = true;
 
     std::vector<rfi::ConvBN> convs;   // enc1.c1, enc1.c2, ..., encD.c2, bott.c1, bott.c2, decD.c1, decD.c2, ..., dec1.c2
@@ -93,6 +95,13 @@ struct rfi_model {
 
     void build();
     void prepare(int n, int h, int w);
+    // 3-layer CNN (model_cnn.cpp)
+    int cY1 = -1, cY2 = -1, cG1 = -1, cG2 = -1;
+    void build_cnn3();
+    void prepare_cnn3(int n, int h, int w);
+    void forward_cnn3(const float* x_dev, int n, int h, int w);
+    void backward_cnn3(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w);
+    void reset_channel_state();       // running stats 0/1, BN-less layers: scale 1, shift 0
     float* buf(int i) { return bufs[i].p; }
     int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
 

@@ -1,5 +1,7 @@
 """Drop-in for ``rfi_toolbox.models`` (reference: rfi_toolbox/models/__init__.py:12-14 exports
 ``UNet``; ``UNetBigger`` is models/unet.py:79-118) running on MI355X through librfi_hip.so."""
-from .unet import UNet, UNetBigger, default_init_state, unet_entries
+from .simple_cnn import SimpleCNN, simple_cnn_entries
+from .unet import HipSegmenter, UNet, UNetBigger, default_init_state, unet_entries
 
-__all__ = ["UNet", "UNetBigger", "default_init_state", "unet_entries"]
+__all__ = ["UNet", "UNetBigger", "SimpleCNN", "HipSegmenter", "default_init_state", "unet_entries",
+           "simple_cnn_entries"]

@@ -62,14 +62,16 @@ def unet_entries(in_channels, out_channels, init_features, depth=4):
     return ent
 
 
-def default_init_state(in_channels, out_channels, init_features, depth=4):
+def default_init_state(in_channels, out_channels, init_features, depth=4, entries=None):
     """torch's default Conv2d/ConvTranspose2d/BatchNorm2d initialisation, drawn from the global
     torch RNG in module-construction order == the reference's ``UNet.__init__`` draw order."""
     if torch is None:
         raise RuntimeError("torch is required for the default initialisation")
     sd = OrderedDict()
     bound = 0.0
-    for name, shape, kind in unet_entries(in_channels, out_channels, init_features, depth):
+    if entries is None:
+        entries = unet_entries(in_channels, out_channels, init_features, depth)
+    for name, shape, kind in entries:
         if kind == "conv_w":
             w = torch.empty(shape)
             torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
@@ -90,20 +92,18 @@ def default_init_state(in_channels, out_channels, init_features, depth=4):
 
 
 # ------------------------------------------------------------------ the model
-class UNet:
-    """MI355X-native U-Net; same constructor signature as the reference (unet.py:42)."""
+class HipSegmenter:
+    """Everything the models share: device binding, state_dict, forward, the optimisation step.
+    A subclass supplies ``_entries`` (reference-order parameter table), ``_init`` (initial state),
+    ``_create(ctx)`` (the C-ABI constructor) and ``_first_key`` (to recognise wrapped checkpoints)."""
 
-    _DEPTH = 4
+    _first_key = ""
 
-    def __init__(self, in_channels=1, out_channels=1, init_features=32, *, device=None, depth=None):
-        for v, nm in ((in_channels, "in_channels"), (out_channels, "out_channels"), (init_features, "init_features")):
-            if not isinstance(v, (int, np.integer)) or v <= 0:
-                raise ValueError(f"{nm} must be a positive integer, got {v!r}")
-        self.in_channels, self.out_channels, self.init_features = int(in_channels), int(out_channels), int(init_features)
-        self.depth = int(depth if depth is not None else self._DEPTH)
+    def _create(self, ctx):          # -> c_void_p model handle
+        raise NotImplementedError
+
+    def _setup(self, device):
         self.training = True
-        self._entries = unet_entries(self.in_channels, self.out_channels, self.init_features, self.depth)
-        self._init = default_init_state(self.in_channels, self.out_channels, self.init_features, self.depth)
         self._h = None
         self.ctx = None
         self._bind(device)
@@ -111,9 +111,7 @@ class UNet:
     # ---- device binding
     def _bind(self, device):
         ctx = Context.get(device)
-        h = C.c_void_p()
-        check(lib.rfi_unet_create(ctx.handle, self.in_channels, self.out_channels, self.init_features,
-                                  self.depth, C.byref(h)))
+        h = self._create(ctx)
         old_state = self.state_dict() if self._h is not None else self._init
         self._release()
         self.ctx, self._h = ctx, h
@@ -178,13 +176,13 @@ class UNet:
 
     def load_state_dict(self, state_dict, strict=True):
         # accept the wrapped checkpoint train_model.py:177-183 writes as well as a bare state_dict
-        if "model_state_dict" in state_dict and "encoder1.conv.conv.0.weight" not in state_dict:
+        if "model_state_dict" in state_dict and self._first_key not in state_dict:
             state_dict = state_dict["model_state_dict"]
         names = [e[0] for e in self._entries]
         missing = [n for n in names if n not in state_dict]
         unexpected = [k for k in state_dict if k not in set(names)]
         if strict and (missing or unexpected):
-            raise RuntimeError(f"Error(s) in loading state_dict for UNet: Missing key(s): {missing}; "
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: Missing key(s): {missing}; "
                                f"Unexpected key(s): {unexpected}")
         for name, shape, kind in self._entries:
             if name not in state_dict:
@@ -382,6 +380,29 @@ class UNet:
         f, s = C.c_double(), C.c_double()
         check(lib.rfi_model_algorithmic_flops(self._h, n, h, w, C.byref(f), C.byref(s)))
         return f.value, s.value
+
+
+class UNet(HipSegmenter):
+    """MI355X-native U-Net; same constructor signature as the reference (unet.py:42)."""
+
+    _DEPTH = 4
+    _first_key = "encoder1.conv.conv.0.weight"
+
+    def __init__(self, in_channels=1, out_channels=1, init_features=32, *, device=None, depth=None):
+        for v, nm in ((in_channels, "in_channels"), (out_channels, "out_channels"), (init_features, "init_features")):
+            if not isinstance(v, (int, np.integer)) or v <= 0:
+                raise ValueError(f"{nm} must be a positive integer, got {v!r}")
+        self.in_channels, self.out_channels, self.init_features = int(in_channels), int(out_channels), int(init_features)
+        self.depth = int(depth if depth is not None else self._DEPTH)
+        self._entries = unet_entries(self.in_channels, self.out_channels, self.init_features, self.depth)
+        self._init = default_init_state(self.in_channels, self.out_channels, self.init_features, self.depth)
+        self._setup(device)
+
+    def _create(self, ctx):
+        h = C.c_void_p()
+        check(lib.rfi_unet_create(ctx.handle, self.in_channels, self.out_channels, self.init_features,
+                                  self.depth, C.byref(h)))
+        return h
 
 
 class UNetBigger(UNet):

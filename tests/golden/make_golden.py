@@ -146,6 +146,9 @@ def run_steps(model, img, lab, steps, lr, wd, record):
     margins, cur = [], []
     hooks = [mod.register_forward_hook(lambda _m, _i, o: cur.append(float(o.detach().abs().min())) if _m.training else None)
              for mod in model.modules() if isinstance(mod, nn.BatchNorm2d)]
+    if not hooks:                         # BN-less model: the ReLU inputs themselves
+        hooks = [mod.register_forward_pre_hook(lambda _m, i: cur.append(float(i[0].detach().abs().min())) if _m.training else None)
+                 for mod in model.modules() if isinstance(mod, nn.ReLU)]
     for s in range(1, steps + 1):
         model.train()
         opt.zero_grad()
@@ -273,6 +276,43 @@ def golden_unet_bigger():
     save("unetbigger_f4_b2_s32.npz", **rec)
 
 
+# ---------------------------------------------------------------- A9: the "3-layer CNN segmenter"
+class SimpleCNN(nn.Module):
+    """NOT a reference class: the reference README's elided custom-model example
+    (README.md:379-398) completed by the build as Conv3x3+ReLU, Conv3x3+ReLU, Conv1x1 -> logits.
+    The data (generator + Preprocessor) and the optimisation step are the reference's."""
+
+    def __init__(self, in_channels=3, out_channels=1, width=64):
+        super().__init__()
+        self.encoder = nn.Sequential(nn.Conv2d(in_channels, width, 3, padding=1), nn.ReLU(),
+                                     nn.Conv2d(width, width, 3, padding=1), nn.ReLU())
+        self.decoder = nn.Sequential(nn.Conv2d(width, out_channels, 1))
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))
+
+
+def golden_cnn3():
+    img, lab = make_batch(4321, 32)
+    for seed in range(77, 140):
+        torch.manual_seed(seed)
+        model = SimpleCNN(3, 1, 16)
+        rec = {"_grad_steps": (1,), "_state_steps": (1, 3), "_adam_steps": (3,)}
+        for k, v in sd_np(model).items():
+            rec[f"state0/{k}"] = v
+        model.eval()
+        with torch.no_grad():
+            rec["logits_eval0"] = model(torch.from_numpy(img).permute(0, 3, 1, 2).contiguous()).numpy()
+        run_steps(model, img, lab, 3, lr=1e-3, wd=1e-5, record=rec)
+        print(f"cnn3 init seed {seed}: relu margins {rec['relu_margin']}")
+        if rec["relu_margin"].min() > 5e-6:
+            break
+    rec = {k: v for k, v in rec.items() if not k.startswith("_")}
+    rec.update(img=img, lab=lab, names=np.array(list(model.state_dict().keys())),
+               hyper=np.array([1e-3, 0.9, 0.999, 1e-8, 1e-5, 1.0]))
+    save("cnn3_c16_b4_s32.npz", **rec)
+
+
 # ---------------------------------------------------------------- G6: metrics
 def golden_metrics():
     rng = np.random.default_rng(3)
@@ -303,4 +343,5 @@ if __name__ == "__main__":
     golden_preprocess()
     golden_unet_small()
     golden_unet_f8()
+    golden_cnn3()
     golden_unet_bigger()

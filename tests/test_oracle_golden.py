@@ -214,3 +214,32 @@ def test_unet_bigger_variant(golden_dir):
     for k in g.files:
         if k.startswith("state1/"):
             np.testing.assert_allclose(st[k[7:]].numpy(), g[k], rtol=0, atol=3e-5, err_msg=k)
+
+
+# ------------------------------------------------------------------ 3-layer CNN
+def test_cnn3_oracle_matches_torch_module_fixture(golden_dir):
+    """The builder-defined 3-layer CNN (no reference class exists): oracle/cnn_ref.py against the
+    fixture produced by an nn.Sequential of the same layers driven by the reference's step."""
+    from oracle import cnn_ref
+    g = _load(golden_dir, "cnn3_c16_b4_s32.npz")
+    st = _state(g, "state0")
+    assert list(st.keys()) == [e[0] for e in cnn_ref.entries(3, 1, 16)] == [str(n) for n in g["names"]]
+    x = unet_ref.nhwc_to_nchw(torch.from_numpy(g["img"]))
+    y = torch.from_numpy(g["lab"]).float().unsqueeze(1)
+    np.testing.assert_allclose(cnn_ref.forward(st, x).numpy(), g["logits_eval0"], rtol=0, atol=1e-6)
+    lr, b1, b2, eps, wd, clip = [float(v) for v in g["hyper"]]
+    adam = cnn_ref.new_adam_state(st)
+    for s in (1, 2, 3):
+        r = cnn_ref.train_step(st, adam, x, y, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, clip=clip)
+        assert r["loss"] == pytest.approx(float(g["losses"][s - 1]), abs=1e-6)
+        assert r["grad_norm"] == pytest.approx(float(g["grad_norms"][s - 1]), rel=1e-5)
+        if s == 1:
+            coef = r["clip_coef"]
+            for k, gr in r["grads"].items():
+                np.testing.assert_allclose((gr * coef).numpy(), g[f"grad1/{k}"], rtol=0, atol=1e-6, err_msg=k)
+        if s in (1, 3):
+            for k, v in st.items():
+                np.testing.assert_allclose(v.numpy(), g[f"state{s}/{k}"], rtol=0, atol=2e-6, err_msg=k)
+    for k in st:
+        np.testing.assert_allclose(adam["m"][k].numpy(), g[f"adam_m3/{k}"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(adam["v"][k].numpy(), g[f"adam_v3/{k}"], rtol=0, atol=1e-9)
