@@ -50,3 +50,66 @@ def test_rccl_world_of_one_allreduce_and_step():
         assert np.isfinite(loss) and np.isfinite(norm)
     finally:
         ctx.comm_destroy()
+
+
+def _flat_grads(model):
+    p, n = C.c_void_p(), C.c_int64()
+    check(lib.rfi_model_grad_buffer(model._h, C.byref(p), C.byref(n)))
+    return p.value, n.value
+
+
+def test_data_parallel_semantics_two_replicas_on_one_gpu():
+    """the N-rank step is 'per-rank forward/backward with LOCAL BatchNorm statistics and
+    local dice, gradients summed and scaled by 1/world, identical clip+Adam on every rank'.  With one
+    GPU the two ranks are two replicas run in turn; the exchange is done by hand on the same flat
+    gradient buffers RCCL all-reduces in place, and the result is checked against the CPU emulation
+    'two micro-batches, grads averaged' built from the oracle."""
+    from collections import OrderedDict
+
+    from oracle import unet_ref
+    ctx = Context.get(0)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 32, 32, 3, generator=g)
+    y = (torch.rand(4, 32, 32, generator=g) > 0.75).to(torch.uint8)
+    shards = [D.shard_range(4, r, 2) for r in range(2)]
+    torch.manual_seed(5)
+    reps = [UNet(3, 1, 8).train()]
+    reps.append(UNet(3, 1, 8).load_state_dict(reps[0].state_dict()).train())
+    st0 = reps[0].state_dict()
+    losses = [m.forward_backward(x[lo:hi], y[lo:hi]) for m, (lo, hi) in zip(reps, shards)]
+    ptrs = [_flat_grads(m) for m in reps]
+    n = ptrs[0][1]
+    host = []
+    for p, _ in ptrs:
+        h = np.empty(n, np.float32)
+        check(lib.rfi_memcpy(ctx.handle, h.ctypes.data_as(C.c_void_p), 0, C.c_void_p(p), 1, h.nbytes))
+        host.append(h)
+    total = host[0] + host[1]                                  # == ncclAllReduce(sum)
+    for p, _ in ptrs:
+        check(lib.rfi_memcpy(ctx.handle, C.c_void_p(p), 1, total.ctypes.data_as(C.c_void_p), 0, total.nbytes))
+    norms = [m.apply_gradients(lr=1e-3, grad_scale=0.5) for m in reps]
+    assert norms[0] == norms[1]
+    sa, sb = reps[0].state_dict(), reps[1].state_dict()
+    for k in sa:                                               # replicas stay identical in the parameters
+        if "running" not in k and "num_batches" not in k:
+            assert torch.equal(sa[k], sb[k]), k
+
+    # CPU emulation from the oracle
+    gsum, bufs0, l_ref = None, None, []
+    for r, (lo, hi) in enumerate(shards):
+        l, _, gr, bufs = unet_ref.loss_and_grads(st0, unet_ref.nhwc_to_nchw(x[lo:hi]), y[lo:hi].float().unsqueeze(1))
+        l_ref.append(float(l))
+        gsum = gr if gsum is None else OrderedDict((k, gsum[k] + gr[k]) for k in gr)
+        if r == 0:
+            bufs0 = bufs
+    avg = OrderedDict((k, v * 0.5) for k, v in gsum.items())
+    total_norm, coef = unet_ref.clip_coefficient(avg, 1.0)
+    assert losses == pytest.approx(l_ref, abs=2e-6)
+    assert norms[0] == pytest.approx(float(total_norm), rel=2e-4)
+    for k in ("encoder1.conv.conv.0.weight", "bottleneck.conv.3.weight", "decoder1.up.weight", "final_conv.weight"):
+        want = avg[k].numpy()
+        got = reps[0].grad(k) * 0.5                            # grad buffer holds the SUM; scale applied in Adam
+        assert np.linalg.norm(got - want) <= 2e-3 * np.linalg.norm(want), k
+    for k, v in bufs0.items():                                 # rank 0's BatchNorm buffers: local statistics
+        if v.dtype.is_floating_point:
+            np.testing.assert_allclose(sa[k].numpy(), v.numpy(), rtol=0, atol=2e-6, err_msg=k)

@@ -247,3 +247,38 @@ def test_step_is_bitwise_reproducible():
         outs.append((losses, m.state_dict()["final_conv.weight"].clone()))
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_unet_1024_waterfall_vs_oracle():
+    """BASELINE configs[2] shape on the reference's U-Net (SURVEY 8a A10 stand-in): one 1024x1024x3
+    sample through forward + loss + backward at the flagship width, fp32, against the CPU oracle."""
+    st = unet_ref.init_state(3, 1, 32, seed=3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 1024, 1024, 3, generator=g)
+    y = (torch.rand(1, 1024, 1024, generator=g) > 0.9).to(torch.uint8)
+    y[:, 300:340, :] = 1
+    xo, yo = unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1)
+    l32, lg32, g32, bufs = unet_ref.loss_and_grads(st, xo, yo)
+    st64 = OrderedDict((k, v.double() if v.dtype.is_floating_point else v.clone()) for k, v in st.items())
+    _, _, g64, _ = unet_ref.loss_and_grads(st64, xo.double(), yo.double())
+    m = UNet(3, 1, 32).load_state_dict(st).train()
+    loss = m.forward_backward(x, y)
+    assert loss == pytest.approx(float(l32), abs=5e-6)
+    got = m.debug_tensor("logits")
+    np.testing.assert_allclose(got, lg32.permute(0, 2, 3, 1).reshape(-1).numpy(), rtol=0, atol=2e-4)
+    ratios = []
+    for k, want64 in g64.items():
+        if _is_prebn_bias(k):
+            continue
+        want64 = want64.numpy().ravel()
+        nrm = np.linalg.norm(want64) + 1e-30
+        rel_ref = np.linalg.norm(g32[k].numpy().ravel() - want64) / nrm
+        rel_hip = np.linalg.norm(m.grad(k).ravel() - want64) / nrm
+        # same criterion as test_flagship_width_vs_oracle: within 4x the fp32 CPU path's own distance
+        # from the float64 result, or 2e-2 where a ReLU-threshold element dominates
+        assert rel_hip <= max(4 * rel_ref, 2e-2), (k, rel_hip, rel_ref)
+        ratios.append(rel_hip / max(rel_ref, 1e-9))
+    assert np.median(ratios) <= 3.0, np.median(ratios)
+    sd = m.state_dict()
+    for k in ("encoder1.conv.conv.1.running_mean", "bottleneck.conv.4.running_var", "decoder1.conv.conv.4.running_var"):
+        np.testing.assert_allclose(sd[k].numpy(), bufs[k].numpy(), rtol=0, atol=2e-6, err_msg=k)
