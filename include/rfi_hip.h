@@ -173,6 +173,25 @@ enum { RFI_C128 = 0, RFI_C64 = 1, RFI_F64 = 2, RFI_F32 = 3 };
 int rfi_preprocess_patches(rfi_ctx* ctx, const void* patches, int patches_mem, int dtype,
                            int n, int ps_h, int ps_w, float* out_nhwc, int out_mem);
 
+/* ---- preprocessing, gather form: the augmentation views (preprocessor.py:413-446), the zero-padded
+ *      tiling (:478-560, patchify :22-42) and the blank-patch test (:746-756) resolved ON DEVICE from
+ *      the waterfall itself.  `planes`: n_planes x C x T (all baselines x polarisations), complex or
+ *      real as above; `flags`: uint8, same shape, non-zero == RFI.  A patch is named by a table entry;
+ *      the host only shuffles / truncates the table (the reference's global-RNG permutation, :758-763). */
+typedef struct rfi_patch_src {
+    int32_t plane;        /* (baseline, polarisation) plane index */
+    int32_t view;         /* 0 plane, 1 plane[::-1,:], 2 plane.T, 3 plane.T[::-1,:] */
+    int32_t row0, col0;   /* tile origin in view coordinates; pixels past the view's edge are zero padding */
+} rfi_patch_src;
+/* any_out[i] = 1 when patch i holds a flagged pixel (host array of n bytes) */
+int rfi_patch_any_flag(rfi_ctx* ctx, const uint8_t* flags, int flags_mem, int n_planes, int c, int t,
+                       const rfi_patch_src* table_host, int n, int ps, uint8_t* any_out_host);
+/* images (n,ps,ps,3) float32 NHWC and, when flags != NULL, labels (n,ps,ps) uint8 of the table's patches */
+int rfi_preprocess_gather(rfi_ctx* ctx, const void* planes, int planes_mem, int dtype, int n_planes,
+                          int c, int t, const uint8_t* flags, int flags_mem,
+                          const rfi_patch_src* table_host, int n, int ps, float* out_nhwc, int out_mem,
+                          uint8_t* out_labels, int labels_mem);
+
 /* ---- metrics: replaces the reductions of evaluation/metrics.py:25-172.  pred/true are
  *      uint8 or float32 arrays of `count` elements, non-zero == positive (:36-37). ---- */
 enum { RFI_U8 = 0, RFI_FLOAT32 = 1 };

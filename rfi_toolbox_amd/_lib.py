@@ -93,6 +93,8 @@ _PROTOS = {
     "rfi_comm_allreduce_sum_f32": (_i, [_vp, _vp, _i64]),
     "rfi_model_allreduce_grads": (_i, [_vp]),
     "rfi_preprocess_patches": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i]),
+    "rfi_patch_any_flag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "rfi_preprocess_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i]),
     "rfi_confusion_counts": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i64, _pi64, _pi64, _pi64]),
     "rfi_threshold_logits": (_i, [_vp, _vp, _i64, _f, _vp]),
     "rfi_op_conv3x3": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),

@@ -901,6 +901,88 @@ int rfi_preprocess_patches(rfi_ctx* ctx, const void* patches, int patches_mem, i
     });
 }
 
+namespace {
+// device copy of `bytes` host bytes (or the pointer itself when already on the device)
+struct Staged {
+    rfi_ctx* ctx; void* dev; bool owned;
+    Staged(rfi_ctx* c, const void* p, int mem, size_t bytes) : ctx(c), dev(const_cast<void*>(p)), owned(false) {
+        if (mem == RFI_HOST && p && bytes) {
+            dev = ctx->alloc(bytes);
+            owned = true;
+            RFI_CHECK_HIP(hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    ~Staged() {
+        if (owned) {
+            (void)hipStreamSynchronize(ctx->stream);
+            try { ctx->release(dev); } catch (...) {}
+        }
+    }
+};
+void check_table(const rfi_patch_src* t, int n, int n_planes, int c, int tt, int ps) {
+    RFI_REQUIRE(n_planes > 0 && c > 0 && tt > 0 && ps > 0, "preprocess_gather: bad shape");
+    RFI_REQUIRE((int64_t)n_planes * c * tt < ((int64_t)1 << 40), "preprocess_gather: waterfall too large");
+    for (int i = 0; i < n; ++i) {
+        const rfi_patch_src& e = t[i];
+        RFI_REQUIRE(e.plane >= 0 && e.plane < n_planes && e.view >= 0 && e.view <= 3 && e.row0 >= 0 && e.col0 >= 0,
+                    "preprocess_gather: bad table entry " + std::to_string(i));
+    }
+}
+}  // namespace
+
+int rfi_patch_any_flag(rfi_ctx* ctx, const uint8_t* flags, int flags_mem, int n_planes, int c, int t,
+                       const rfi_patch_src* table_host, int n, int ps, uint8_t* any_out_host) {
+    return guarded([&] {
+        RFI_REQUIRE(n >= 0 && flags && (n == 0 || (table_host && any_out_host)), "patch_any_flag: null argument");
+        if (n == 0) return;
+        check_table(table_host, n, n_planes, c, t, ps);
+        ctx->activate();
+        Staged fl(ctx, flags, flags_mem, (size_t)n_planes * c * t);
+        Staged tb(ctx, table_host, RFI_HOST, (size_t)n * sizeof(rfi_patch_src));
+        unsigned* d_any = static_cast<unsigned*>(ctx->alloc((size_t)n * sizeof(unsigned)));
+        launch_patch_any_flag(ctx, static_cast<const uint8_t*>(fl.dev), static_cast<const rfi_patch_src*>(tb.dev), c, t,
+                              n, ps, d_any);
+        std::vector<unsigned> h((size_t)n);
+        RFI_CHECK_HIP(hipMemcpyAsync(h.data(), d_any, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->release(d_any);
+        for (int i = 0; i < n; ++i) any_out_host[i] = h[(size_t)i] ? 1 : 0;
+    });
+}
+
+int rfi_preprocess_gather(rfi_ctx* ctx, const void* planes, int planes_mem, int dtype, int n_planes, int c,
+                          int t, const uint8_t* flags, int flags_mem, const rfi_patch_src* table_host, int n,
+                          int ps, float* out_nhwc, int out_mem, uint8_t* out_labels, int labels_mem) {
+    return guarded([&] {
+        RFI_REQUIRE(n >= 0 && planes && (n == 0 || (table_host && out_nhwc)), "preprocess_gather: null argument");
+        RFI_REQUIRE(dtype >= RFI_C128 && dtype <= RFI_F32, "preprocess_gather: unknown dtype");
+        RFI_REQUIRE(!out_labels || flags, "preprocess_gather: labels requested without flags");
+        if (n == 0) return;
+        check_table(table_host, n, n_planes, c, t, ps);
+        ctx->activate();
+        const size_t esz = dtype == RFI_C128 ? 16 : (dtype == RFI_F32 ? 4 : 8);
+        const size_t px = (size_t)n * ps * ps;
+        Staged pl(ctx, planes, planes_mem, (size_t)n_planes * c * t * esz);
+        Staged fl(ctx, flags, flags_mem, (size_t)n_planes * c * t);
+        Staged tb(ctx, table_host, RFI_HOST, (size_t)n * sizeof(rfi_patch_src));
+        float* dout = out_nhwc;
+        uint8_t* dlab = out_labels;
+        void *tmp_out = nullptr, *tmp_lab = nullptr;
+        if (out_mem == RFI_HOST) dout = static_cast<float*>(tmp_out = ctx->alloc(px * 3 * sizeof(float)));
+        if (out_labels && labels_mem == RFI_HOST) dlab = static_cast<uint8_t*>(tmp_lab = ctx->alloc(px));
+        void* mm = ctx->get_scratch((size_t)n * 4 * sizeof(unsigned long long));
+        const auto* table_dev = static_cast<const rfi_patch_src*>(tb.dev);
+        launch_preprocess(ctx, pl.dev, dtype, n, ps, ps, static_cast<float*>(mm), dout, table_dev, c, t);
+        if (out_labels) launch_gather_labels(ctx, static_cast<const uint8_t*>(fl.dev), table_dev, c, t, n, ps, dlab);
+        if (tmp_out)
+            RFI_CHECK_HIP(hipMemcpyAsync(out_nhwc, dout, px * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (tmp_lab) RFI_CHECK_HIP(hipMemcpyAsync(out_labels, dlab, px, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // the staged table dies with this call
+        if (tmp_out) ctx->release(tmp_out);
+        if (tmp_lab) ctx->release(tmp_lab);
+    });
+}
+
 int rfi_confusion_counts(rfi_ctx* ctx, const void* pred, int pred_dtype, int pred_mem, const void* truth,
                          int truth_dtype, int truth_mem, int64_t count, int64_t* tp, int64_t* fp,
                          int64_t* fn) {

@@ -171,7 +171,14 @@ void launch_adam(rfi_ctx* ctx, const AdamArgs& a);
 
 // ---------------------------------------------------------------- preprocessing / metrics
 void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int ph, int pw,
-                       float* minmax_ws, float* out_nhwc);
+                       float* minmax_ws, float* out_nhwc, const rfi_patch_src* table_dev = nullptr, int C = 0,
+                       int T = 0);
+// gather form (table_dev != null): `patches` are the n_planes x C x T waterfall planes and patch i is
+// the ph x pw tile table_dev[i] names; the same map serves the labels and the blank-patch test
+void launch_gather_labels(rfi_ctx* ctx, const uint8_t* flags, const rfi_patch_src* table_dev, int C, int T, int n,
+                          int ps, uint8_t* out);
+void launch_patch_any_flag(rfi_ctx* ctx, const uint8_t* flags, const rfi_patch_src* table_dev, int C, int T, int n,
+                           int ps, unsigned* any_out);
 void launch_confusion(rfi_ctx* ctx, const void* pred, int pred_dtype, const void* truth,
                       int truth_dtype, int64_t count, unsigned long long* counts3);
 void launch_threshold(rfi_ctx* ctx, const float* logits, int64_t count, float threshold,

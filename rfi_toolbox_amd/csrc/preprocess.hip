@@ -15,9 +15,30 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Where pixel (y, x) of output patch `e` lives in the waterfall planes (C x T each), or -1 for the
+// zero padding beyond a view's edge (preprocessor.py:478-560).  Views (:413-446): 0 plane,
+// 1 plane[::-1, :], 2 plane.T, 3 plane.T[::-1, :].
+struct GatherMap {
+    const rfi_patch_src* table;     // device copy, one entry per output patch
+    int C, T;
+};
+__device__ __forceinline__ int64_t gather_index(const GatherMap& g, const rfi_patch_src& e, int y, int x) {
+    const int vy = e.row0 + y, vx = e.col0 + x;
+    const bool tr = e.view >= 2;
+    const int Hv = tr ? g.T : g.C, Wv = tr ? g.C : g.T;
+    if (vy >= Hv || vx >= Wv) return -1;
+    const int fy = (e.view & 1) ? Hv - 1 - vy : vy;            // rows flipped
+    const int sy = tr ? vx : fy, sx = tr ? fy : vx;            // transpose: view[a][b] = plane[b][a]
+    return ((int64_t)e.plane * g.C + sy) * g.T + sx;
+}
+
 template <typename T>
 __device__ __forceinline__ T load_amp(const void* p, int dtype, int64_t i, T* phase) {
-    // returns |z| (or |x| for real input) and the phase in *phase
+    // returns |z| (or |x| for real input) and the phase in *phase; i < 0 is a padded zero
+    if (i < 0) {
+        *phase = (T)0;
+        return (T)0;
+    }
     if (dtype == RFI_C128) {
         const double re = reinterpret_cast<const double*>(p)[2 * i];
         const double im = reinterpret_cast<const double*>(p)[2 * i + 1];
@@ -61,8 +82,8 @@ template <typename T> struct LogAmp;
 template <> struct LogAmp<double> { static __device__ double f(double a) { return log10(a + 1e-10); } };
 template <> struct LogAmp<float> { static __device__ float f(float a) { return log10f(a + 1e-10f); } };
 
-template <typename T>
-__global__ void prep_pass1_kernel(const void* __restrict__ src, int dtype, int ph, int pw, int NPB,
+template <typename T, bool GATHER>
+__global__ void prep_pass1_kernel(const void* __restrict__ src, int dtype, int ph, int pw, int NPB, GatherMap gm,
                                   unsigned long long* __restrict__ mm, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* s_la = reinterpret_cast<T*>(smem_raw);                      // [pw + NPB]
@@ -70,12 +91,16 @@ __global__ void prep_pass1_kernel(const void* __restrict__ src, int dtype, int p
     const int p0 = blockIdx.x * NPB;
     const int64_t base = (int64_t)patch * npix;
     const bool is_complex = dtype == RFI_C128 || dtype == RFI_C64;
+    rfi_patch_src ent{};
+    if constexpr (GATHER) ent = gm.table[patch];
     // log-amp of [p0 - pw, p0 + NPB) ∩ [0, npix); channels 1/2 of the block's own pixels
     for (int k = threadIdx.x; k < pw + NPB; k += blockDim.x) {
         const int p = p0 - pw + k;
         if (p < 0 || p >= npix) continue;
         T phs;
-        const T la = LogAmp<T>::f(load_amp<T>(src, dtype, base + p, &phs));
+        int64_t si = base + p;
+        if constexpr (GATHER) si = gather_index(gm, ent, p / pw, p % pw);
+        const T la = LogAmp<T>::f(load_amp<T>(src, dtype, si, &phs));
         s_la[k] = la;
         if (p >= p0) {
             float* o = out + (base + p) * 3;
@@ -149,6 +174,30 @@ __global__ void prep_init_mm64_kernel(unsigned long long* mm, int n) {
     }
 }
 
+// labels of the gathered patches: the same index map applied to the uint8 flag planes (padding = 0)
+__global__ void gather_labels_kernel(const uint8_t* __restrict__ flags, GatherMap gm, int ps,
+                                     uint8_t* __restrict__ out) {
+    const int patch = blockIdx.y, npix = ps * ps;
+    const rfi_patch_src ent = gm.table[patch];
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const int64_t si = gather_index(gm, ent, p / ps, p % ps);
+        out[(int64_t)patch * npix + p] = si >= 0 && flags[si] != 0 ? 1 : 0;
+    }
+}
+// any_out[patch] = 1 when the patch holds a flagged pixel (blank-patch removal, preprocessor.py:746-756);
+// any_out must be zeroed before the launch
+__global__ void patch_any_flag_kernel(const uint8_t* __restrict__ flags, GatherMap gm, int ps,
+                                      unsigned* __restrict__ any_out) {
+    const int patch = blockIdx.y, npix = ps * ps;
+    const rfi_patch_src ent = gm.table[patch];
+    bool any = false;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const int64_t si = gather_index(gm, ent, p / ps, p % ps);
+        any |= si >= 0 && flags[si] != 0;
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&any_out[patch], 1u);
+}
+
 // ------------------------------------------------------------------ metrics
 __device__ __forceinline__ bool nz(const void* p, int dtype, int64_t i) {
     return dtype == RFI_U8 ? reinterpret_cast<const uint8_t*>(p)[i] != 0
@@ -187,7 +236,7 @@ __global__ void threshold_kernel(const float* __restrict__ logits, int64_t count
 
 // minmax_ws: n*4 64-bit words
 void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int ph, int pw,
-                       float* minmax_ws, float* out_nhwc) {
+                       float* minmax_ws, float* out_nhwc, const rfi_patch_src* table_dev, int C, int T) {
     RFI_REQUIRE(dtype >= RFI_C128 && dtype <= RFI_F32, "preprocess: unknown dtype");
     const int per = ph * pw;
     const double in_b = dtype == RFI_C128 ? 16 : (dtype == RFI_F32 ? 4 : 8);
@@ -208,12 +257,22 @@ void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int 
         RFI_REQUIRE(npb >= pw, "preprocess: patch rows this long are not supported");
         const dim3 grid((unsigned)cdiv(per, npb), n);
         const size_t lds = (size_t)(pw + npb) * esz;
-        if (wide)
-            hipLaunchKernelGGL(prep_pass1_kernel<double>, grid, dim3(kBlock), lds, ctx->stream, patches, dtype, ph, pw,
-                               npb, mm, out_nhwc);
-        else
-            hipLaunchKernelGGL(prep_pass1_kernel<float>, grid, dim3(kBlock), lds, ctx->stream, patches, dtype, ph, pw,
-                               npb, mm, out_nhwc);
+        const GatherMap gm{table_dev, C, T};
+        if (table_dev) {
+            if (wide)
+                hipLaunchKernelGGL((prep_pass1_kernel<double, true>), grid, dim3(kBlock), lds, ctx->stream, patches,
+                                   dtype, ph, pw, npb, gm, mm, out_nhwc);
+            else
+                hipLaunchKernelGGL((prep_pass1_kernel<float, true>), grid, dim3(kBlock), lds, ctx->stream, patches,
+                                   dtype, ph, pw, npb, gm, mm, out_nhwc);
+        } else {
+            if (wide)
+                hipLaunchKernelGGL((prep_pass1_kernel<double, false>), grid, dim3(kBlock), lds, ctx->stream, patches,
+                                   dtype, ph, pw, npb, gm, mm, out_nhwc);
+            else
+                hipLaunchKernelGGL((prep_pass1_kernel<float, false>), grid, dim3(kBlock), lds, ctx->stream, patches,
+                                   dtype, ph, pw, npb, gm, mm, out_nhwc);
+        }
         check_launch("prep_pass1");
     }
     {
@@ -226,6 +285,24 @@ void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int 
                            out_nhwc);
         check_launch("prep_pass2");
     }
+}
+
+void launch_gather_labels(rfi_ctx* ctx, const uint8_t* flags, const rfi_patch_src* table_dev, int C, int T, int n,
+                          int ps, uint8_t* out) {
+    ProfScope ps_(ctx, FAM_PREPROCESS, 0, (double)n * ps * ps * 2);
+    int bx = (int)cdiv((int64_t)ps * ps, kBlock * 4);
+    hipLaunchKernelGGL(gather_labels_kernel, dim3(bx, n), dim3(kBlock), 0, ctx->stream, flags, GatherMap{table_dev, C, T},
+                       ps, out);
+    check_launch("gather_labels");
+}
+void launch_patch_any_flag(rfi_ctx* ctx, const uint8_t* flags, const rfi_patch_src* table_dev, int C, int T, int n,
+                           int ps, unsigned* any_out) {
+    ProfScope ps_(ctx, FAM_PREPROCESS, 0, (double)n * ps * ps);
+    RFI_CHECK_HIP(hipMemsetAsync(any_out, 0, (size_t)n * sizeof(unsigned), ctx->stream));
+    int bx = (int)cdiv((int64_t)ps * ps, kBlock * 4);
+    hipLaunchKernelGGL(patch_any_flag_kernel, dim3(bx, n), dim3(kBlock), 0, ctx->stream, flags,
+                       GatherMap{table_dev, C, T}, ps, any_out);
+    check_launch("patch_any_flag");
 }
 
 void launch_confusion(rfi_ctx* ctx, const void* pred, int pred_dtype, const void* truth,

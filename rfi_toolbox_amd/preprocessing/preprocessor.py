@@ -1,15 +1,19 @@
 """``Preprocessor`` with the reference's constructor and ``create_dataset`` signature
 (rfi_toolbox/preprocessing/preprocessor.py:175-211).
 
-Split of work:
-* host (NumPy views, no per-pixel arithmetic): the 4-way views (:413-446), zero-padded tiling
-  (:478-560, ``patchify`` :22-42), blank-patch removal (:746-756), the global-RNG shuffle
-  (:758-763) and ``num_patches`` truncation -- index bookkeeping over whole patches;
-  for REAL input also the median-normalise / stretch / MAD-flag steps (:646-745), which need
-  order statistics and are outside this round's device scope.
-* MI355X (librfi_hip.so ``rfi_preprocess_patches``): the hot loop (:366-384) -- per patch
-  log-amplitude, phase, forward-difference gradient magnitude with per-patch min-max,
-  fixed-range log-amp scaling, float32 cast and ImageNet normalisation -> NHWC float32.
+Split of work for the training path (complex visibilities + caller-supplied flags):
+* MI355X, from the waterfall itself (librfi_hip.so ``rfi_patch_any_flag`` +
+  ``rfi_preprocess_gather``): the 4-way views (:413-446), the zero-padded tiling (:478-560,
+  ``patchify`` :22-42), the blank-patch test (:746-756), the labels, and the hot loop (:366-384) --
+  per patch log-amplitude, phase, forward-difference gradient magnitude with per-patch min-max,
+  fixed-range log-amp scaling, float32 cast and ImageNet normalisation -> NHWC float32.  The
+  waterfall and its flags are uploaded once; no patch is ever materialised on the host.
+* host: a table with one 16-byte entry per patch (plane, view, tile origin) -- its construction in
+  the reference's patch order, the keep filter, the global-RNG shuffle (:758-763, so datasets are
+  reproducible against the reference under ``np.random.seed``) and ``num_patches`` truncation.
+Other inputs keep the host bookkeeping + ``rfi_preprocess_patches`` form: REAL input (median
+normalise / stretch, :646-706) and flag-less input (MAD flags, :708-745) need order statistics over
+each patch, which stay on the host this round.
 """
 from __future__ import annotations
 
@@ -64,6 +68,28 @@ def _to_patches(wfs, ps):
     return np.concatenate([_tile(np.asarray(w), ps) for w in wfs], axis=0), [w.shape for w in wfs]
 
 
+def _patch_table(n_planes, C, T, rot, ps):
+    """One (plane, view, row0, col0) entry per patch, in the reference's order: plane-major, then
+    view (:413-446), then row-major tiles of the zero-padded view (:478-560)."""
+    views = (0,) if rot < 2 else ((0, 1) if rot < 4 else (0, 1, 2, 3))
+    whole = C <= ps and T <= ps          # small waterfalls are used whole, unpadded (:340-347)
+    rows = []
+    for plane in range(n_planes):
+        for v in views:
+            hv, wv = (T, C) if v >= 2 else (C, T)
+            if whole:
+                rows.append((plane, v, 0, 0))
+                continue
+            for r0 in range(0, max(hv, ps), ps):
+                if r0 >= hv and r0 > 0:
+                    break
+                for c0 in range(0, max(wv, ps), ps):
+                    if c0 >= wv and c0 > 0:
+                        break
+                    rows.append((plane, v, r0, c0))
+    return np.asarray(rows, dtype=np.int32).reshape(-1, 4)
+
+
 def _mad(v):
     v = v[~np.isnan(v)]
     return np.median(np.abs(v - np.median(v)))
@@ -100,13 +126,99 @@ class Preprocessor:
                                              pw, out.ctypes.data_as(C.c_void_p), HOST))
         return out
 
+    # ---- device path: views, tiling, blank-patch test, labels and channels straight from the waterfall
+    def _create_on_device(self, patch_size, rot, num_patches, inference_mode, metadata):
+        data = self.data
+        B, P, Cn, Tn = data.shape
+        whole = Cn <= patch_size and Tn <= patch_size
+        if whole and Cn != Tn and rot >= 4:
+            return None                       # ragged views of a small non-square waterfall: host path
+        ps_h, ps_w = (Cn, Tn) if whole else (patch_size, patch_size)
+        if ps_h != ps_w:
+            return None
+        ps = ps_h
+        code = {np.dtype(np.complex128): C128, np.dtype(np.complex64): C64}.get(data.dtype)
+        if code is None:
+            data, code = data.astype(np.complex128), C128
+        planes = np.ascontiguousarray(data.reshape(B * P, Cn, Tn))
+        fl = np.asarray(self.flags)
+        fl = fl[np.newaxis, ...] if fl.ndim == 3 else fl
+        if fl.shape != self.data.shape:
+            return None
+        flags = np.ascontiguousarray(fl.reshape(B * P, Cn, Tn) != 0).view(np.uint8)
+        ctx = Context.get(self._device)
+        d_planes, d_flags = ctx.to_device(planes), ctx.to_device(flags)
+        table = _patch_table(B * P, Cn, Tn, rot, ps)
+        if not whole:
+            self.original_shapes = [((Tn, Cn) if v >= 2 else (Cn, Tn)) for v in
+                                    ((0,) if rot < 2 else ((0, 1) if rot < 4 else (0, 1, 2, 3)))] * (B * P)
+        if not inference_mode:
+            keep = np.zeros(len(table), dtype=np.uint8)
+            if len(table):
+                check(lib.rfi_patch_any_flag(ctx.handle, C.c_void_p(d_flags.ptr), DEVICE, B * P, Cn, Tn,
+                                             table.ctypes.data_as(C.c_void_p), len(table), ps,
+                                             keep.ctypes.data_as(C.c_void_p)))
+            keep = keep.astype(bool)
+            if keep.any():
+                table = table[keep]
+            table = table[np.random.permutation(len(table))]        # global RNG, as the reference (:760)
+        if num_patches and num_patches < len(table):
+            table = table[:num_patches]
+        table = np.ascontiguousarray(table)
+        n = len(table)
+        images = np.empty((n, ps, ps, 3), dtype=np.float32)
+        labels = np.zeros((n, ps, ps), dtype=np.uint8)
+        if n:
+            want_labels = not inference_mode
+            check(lib.rfi_preprocess_gather(
+                ctx.handle, C.c_void_p(d_planes.ptr), DEVICE, code, B * P, Cn, Tn, C.c_void_p(d_flags.ptr), DEVICE,
+                table.ctypes.data_as(C.c_void_p), n, ps, images.ctypes.data_as(C.c_void_p), HOST,
+                labels.ctypes.data_as(C.c_void_p) if want_labels else None, HOST))
+        self._table, self._rot, self._ps = table, rot, ps
+        self.patches = self.patch_flags = None      # not materialised; see materialise_patches()
+        metadata["original_shapes"] = getattr(self, "original_shapes", None)
+        self.dataset = TorchDataset(torch.from_numpy(images), torch.from_numpy(labels), metadata)
+        return self.dataset
+
+    def materialise_patches(self):
+        """Host copies of the complex patches / flag patches of the last device-path dataset, in
+        dataset order (the reference keeps them as ``self.patches`` / ``self.patch_flags``)."""
+        if getattr(self, "_table", None) is None:
+            return self.patches, self.patch_flags
+        B, P, Cn, Tn = self.data.shape
+        planes = self.data.reshape(B * P, Cn, Tn)
+        fl = np.asarray(self.flags)
+        fl = (fl[np.newaxis, ...] if fl.ndim == 3 else fl).reshape(B * P, Cn, Tn)
+        ps = self._ps
+
+        def cut(src, e):
+            plane, v, r0, c0 = (int(x) for x in e)
+            view = src[plane]
+            view = view[::-1, :] if v == 1 else (view.T if v == 2 else (view.T[::-1, :] if v == 3 else view))
+            out = np.zeros((ps, ps), dtype=src.dtype)
+            blk = view[r0:r0 + ps, c0:c0 + ps]
+            out[:blk.shape[0], :blk.shape[1]] = blk
+            return out
+        self.patches = np.array([cut(planes, e) for e in self._table])
+        self.patch_flags = np.array([cut(fl, e) for e in self._table])
+        return self.patches, self.patch_flags
+
     def create_dataset(self, patch_size=128, stretch=None, flag_sigma=5, use_custom_flags=True,
                        num_patches=None, normalize_before_stretch=True, normalize_after_stretch=False,
                        num_workers=4, enable_augmentation=True, augmentation_rotations=4,
-                       inference_mode=False):
+                       inference_mode=False, on_device_tiling=True):
         del num_workers                       # the hot loop runs on the GPU, no worker pool
         rot = augmentation_rotations if (enable_augmentation and augmentation_rotations > 1) else 1
         have_flags = use_custom_flags and self.flags is not None
+        self._table = None
+        if on_device_tiling and have_flags and np.iscomplexobj(self.data):
+            metadata = {"patch_size": patch_size, "stretch": stretch, "flag_sigma": flag_sigma,
+                        "normalize_before_stretch": normalize_before_stretch,
+                        "normalize_after_stretch": normalize_after_stretch,
+                        "augmentation_rotations": augmentation_rotations}
+            ds = self._create_on_device(patch_size, rot, num_patches, inference_mode, metadata)
+            if ds is not None:
+                return ds
         patches, shapes = _to_patches(_views(self.data, rot), patch_size)
         if shapes is not None:
             self.original_shapes = shapes

@@ -102,3 +102,42 @@ def test_metrics_large_and_empty():
                                                               "f1": 1.0, "dice": 1.0}
     with pytest.raises(ValueError):
         confusion_counts(np.zeros(3), np.zeros(4))
+
+
+# ------------------------------------------------------------------ views / tiling / blank-patch test on device
+def _wf(shape, dtype, seed, frac=0.02):
+    rng = np.random.default_rng(seed)
+    z = (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(dtype)
+    fl = rng.random(shape) < frac
+    fl[..., : shape[-2] // 3, :] = False           # leaves some tiles blank
+    return z, fl
+
+
+@pytest.mark.parametrize("shape,dtype,ps,kw", [
+    ((1, 1, 128, 128), np.complex128, 128, {}),
+    ((2, 2, 200, 300), np.complex64, 128, {}),
+    ((1, 3, 256, 130), np.complex128, 64, {"augmentation_rotations": 2}),
+    ((1, 1, 256, 256), np.complex128, 128, {"enable_augmentation": False}),
+    ((1, 2, 300, 200), np.complex128, 128, {"num_patches": 5}),
+    ((1, 1, 64, 64), np.complex128, 128, {}),
+    ((1, 1, 256, 256), np.complex128, 128, {"inference_mode": True}),
+])
+def test_device_tiling_equals_host_bookkeeping(shape, dtype, ps, kw):
+    """The gather form (views, zero-padded tiling, blank-patch removal and labels resolved on the GPU
+    from the waterfall) must give the very dataset the host-bookkeeping form gives -- same patch
+    order under the same global-RNG seed, bit-identical images and labels."""
+    z, fl = _wf(shape, dtype, seed=sum(shape) + ps)
+    np.random.seed(99)
+    a = Preprocessor(z, flags=fl).create_dataset(patch_size=ps, num_workers=0, on_device_tiling=False, **kw)
+    np.random.seed(99)
+    pre = Preprocessor(z, flags=fl)
+    b = pre.create_dataset(patch_size=ps, num_workers=0, **kw)
+    assert pre._table is not None                                       # the device path really ran
+    assert tuple(a.images.shape) == tuple(b.images.shape) and len(a) > 0
+    assert torch.equal(a.labels, b.labels)
+    assert torch.equal(a.images, b.images)
+    assert a.metadata == b.metadata
+    patches, pflags = pre.materialise_patches()
+    if not kw.get("inference_mode"):
+        np.testing.assert_array_equal(pflags.astype(np.uint8), b.labels.numpy())
+    assert patches.shape == tuple(b.labels.shape)
