@@ -107,7 +107,7 @@ def main():
 
     from rfi_toolbox_amd import distributed as D
     from rfi_toolbox_amd._lib import Hyper
-    from rfi_toolbox_amd.data_generation import make_training_patches
+    from rfi_toolbox_amd.data_generation import make_training_patches_device
     from rfi_toolbox_amd.models import SimpleCNN, UNet
     from rfi_toolbox_amd.runtime import Context
 
@@ -126,10 +126,10 @@ def main():
     model.train()
     log("model built")
     B, S = args.batch, args.size
-    imgs, labs = make_training_patches(B, S, seed=1234 + rank, device=local_rank)
-    d_x, d_y = ctx.to_device(imgs), ctx.to_device(labs)
+    # synthetic waterfalls -> views/tiling -> 3-channel patches + labels, generated and kept in HBM
+    d_x, d_y = make_training_patches_device(B, S, seed=1234 + rank, device=local_rank)
     hp = Hyper(1e-4, 0.9, 0.999, 1e-8, 1e-5, 1.0)   # train_model.py:89,95,130,149 defaults
-    log(f"inputs resident: {imgs.shape} {labs.shape}, label fraction {labs.mean():.3f}")
+    log(f"inputs resident: {d_x.shape} {d_y.shape}, label fraction {d_y.numpy().mean():.3f}")
 
     for _ in range(args.warmup):
         model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)

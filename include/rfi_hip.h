@@ -192,6 +192,23 @@ int rfi_preprocess_gather(rfi_ctx* ctx, const void* planes, int planes_mem, int 
                           const rfi_patch_src* table_host, int n, int ps, float* out_nhwc, int out_mem,
                           uint8_t* out_labels, int labels_mem);
 
+/* ---- synthetic data on device (the step in front of the path): the sample model of
+ *      SyntheticDataGenerator._generate_single_sample (data_generation/synthetic_generator.py:520-815)
+ *      with a counter-based per-pixel random stream (Philox4x32-10) instead of NumPy's sequential global
+ *      one -- distribution-level parity, exact for bandpass / signal / mask given the event table.
+ *      Events are drawn by the host (a few dozen per sample); kind 0 fills channels [r0,r1) x times
+ *      [c0,c1) with `amp`; kind 1 is a frequency sweep from channel r0 to r1 of width c0 and power-law
+ *      order c1 (1 or 2).  Output: planes (n_samples, n_pol, C, T) complex128/complex64 and uint8 flags. */
+typedef struct rfi_event {
+    int32_t kind, r0, r1, c0, c1;
+    int32_t pad_;
+    double amp;
+} rfi_event;
+int rfi_generate_waterfalls(rfi_ctx* ctx, uint64_t seed, int n_samples, int n_pol, int c, int t,
+                            double noise_mjy, int bandpass, int bandpass_order, double pol_corr,
+                            const rfi_event* events_host, const int32_t* event_offsets_host,
+                            int out_dtype, void* planes_out, int planes_mem, uint8_t* flags_out, int flags_mem);
+
 /* ---- metrics: replaces the reductions of evaluation/metrics.py:25-172.  pred/true are
  *      uint8 or float32 arrays of `count` elements, non-zero == positive (:36-37). ---- */
 enum { RFI_U8 = 0, RFI_FLOAT32 = 1 };

@@ -1,6 +1,7 @@
 // extern "C" surface of librfi_hip.so (declared in include/rfi_hip.h).
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <random>
 
@@ -980,6 +981,40 @@ int rfi_preprocess_gather(rfi_ctx* ctx, const void* planes, int planes_mem, int 
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // the staged table dies with this call
         if (tmp_out) ctx->release(tmp_out);
         if (tmp_lab) ctx->release(tmp_lab);
+    });
+}
+
+int rfi_generate_waterfalls(rfi_ctx* ctx, uint64_t seed, int n_samples, int n_pol, int c, int t, double noise_mjy,
+                            int bandpass, int bandpass_order, double pol_corr, const rfi_event* events_host,
+                            const int32_t* event_offsets_host, int out_dtype, void* planes_out, int planes_mem,
+                            uint8_t* flags_out, int flags_mem) {
+    return guarded([&] {
+        RFI_REQUIRE(n_samples >= 0 && n_pol > 0 && c > 0 && t > 0, "generate_waterfalls: bad shape");
+        RFI_REQUIRE(out_dtype == RFI_C128 || out_dtype == RFI_C64, "generate_waterfalls: output must be complex128/64");
+        RFI_REQUIRE(planes_out && flags_out && event_offsets_host, "generate_waterfalls: null argument");
+        if (n_samples == 0) return;
+        const int n_events = event_offsets_host[n_samples];
+        RFI_REQUIRE(event_offsets_host[0] == 0 && n_events >= 0 && (n_events == 0 || events_host),
+                    "generate_waterfalls: bad event table");
+        for (int s = 0; s < n_samples; ++s)
+            RFI_REQUIRE(event_offsets_host[s] <= event_offsets_host[s + 1], "generate_waterfalls: offsets must ascend");
+        ctx->activate();
+        const size_t px = (size_t)n_samples * n_pol * c * t, esz = out_dtype == RFI_C128 ? 16 : 8;
+        Staged ev(ctx, events_host, RFI_HOST, (size_t)std::max(n_events, 1) * sizeof(rfi_event));
+        Staged of(ctx, event_offsets_host, RFI_HOST, (size_t)(n_samples + 1) * sizeof(int32_t));
+        void* dpl = planes_out;
+        uint8_t* dfl = flags_out;
+        void *tmp_p = nullptr, *tmp_f = nullptr;
+        if (planes_mem == RFI_HOST) dpl = tmp_p = ctx->alloc(px * esz);
+        if (flags_mem == RFI_HOST) dfl = static_cast<uint8_t*>(tmp_f = ctx->alloc(px));
+        launch_synth(ctx, seed, n_samples, n_pol, c, t, noise_mjy, bandpass, bandpass_order, pol_corr,
+                     static_cast<const rfi_event*>(n_events ? ev.dev : nullptr), static_cast<const int*>(of.dev),
+                     out_dtype, dpl, dfl);
+        if (tmp_p) RFI_CHECK_HIP(hipMemcpyAsync(planes_out, dpl, px * esz, hipMemcpyDeviceToHost, ctx->stream));
+        if (tmp_f) RFI_CHECK_HIP(hipMemcpyAsync(flags_out, dfl, px, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (tmp_p) ctx->release(tmp_p);
+        if (tmp_f) ctx->release(tmp_f);
     });
 }
 

@@ -175,6 +175,9 @@ void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int 
                        int T = 0);
 // gather form (table_dev != null): `patches` are the n_planes x C x T waterfall planes and patch i is
 // the ph x pw tile table_dev[i] names; the same map serves the labels and the blank-patch test
+void launch_synth(rfi_ctx* ctx, unsigned long long seed, int n_samples, int n_pol, int C, int T, double noise,
+                  int bandpass, int order, double corr, const rfi_event* events_dev, const int* offsets_dev,
+                  int out_dtype, void* planes, uint8_t* flags);
 void launch_gather_labels(rfi_ctx* ctx, const uint8_t* flags, const rfi_patch_src* table_dev, int C, int T, int n,
                           int ps, uint8_t* out);
 void launch_patch_any_flag(rfi_ctx* ctx, const uint8_t* flags, const rfi_patch_src* table_dev, int C, int T, int n,

@@ -90,6 +90,44 @@ def _patch_table(n_planes, C, T, rot, ps):
     return np.asarray(rows, dtype=np.int32).reshape(-1, 4)
 
 
+def select_patches(ctx, d_flags, n_planes, Cn, Tn, rot, ps, num_patches=None, inference_mode=False):
+    """Patch table of a device-resident flag stack after the blank-patch test (GPU) and the
+    global-RNG shuffle (host, the reference's ``np.random.permutation``, :758-763)."""
+    table = _patch_table(n_planes, Cn, Tn, rot, ps)
+    if not inference_mode:
+        keep = np.zeros(len(table), dtype=np.uint8)
+        if len(table):
+            check(lib.rfi_patch_any_flag(ctx.handle, C.c_void_p(d_flags.ptr), DEVICE, n_planes, Cn, Tn,
+                                         table.ctypes.data_as(C.c_void_p), len(table), ps,
+                                         keep.ctypes.data_as(C.c_void_p)))
+        keep = keep.astype(bool)
+        if keep.any():
+            table = table[keep]
+        table = table[np.random.permutation(len(table))]
+    if num_patches and num_patches < len(table):
+        table = table[:num_patches]
+    return np.ascontiguousarray(table)
+
+
+def gather_patches(ctx, d_planes, d_flags, code, n_planes, Cn, Tn, table, ps, images, labels):
+    """Run the gather kernels for `table`; `images` / `labels` are NumPy arrays (host results) or
+    DeviceArrays (results stay in HBM); labels may be None."""
+    from ..runtime import DeviceArray
+
+    def ptr_mem(a):
+        if a is None:
+            return None, HOST
+        if isinstance(a, DeviceArray):
+            return C.c_void_p(a.ptr), DEVICE
+        return a.ctypes.data_as(C.c_void_p), HOST
+    ip, im = ptr_mem(images)
+    lp, lm = ptr_mem(labels)
+    if len(table):
+        check(lib.rfi_preprocess_gather(ctx.handle, C.c_void_p(d_planes.ptr), DEVICE, code, n_planes, Cn, Tn,
+                                        C.c_void_p(d_flags.ptr), DEVICE, table.ctypes.data_as(C.c_void_p), len(table),
+                                        ps, ip, im, lp, lm))
+
+
 def _mad(v):
     v = v[~np.isnan(v)]
     return np.median(np.abs(v - np.median(v)))
@@ -148,32 +186,15 @@ class Preprocessor:
         flags = np.ascontiguousarray(fl.reshape(B * P, Cn, Tn) != 0).view(np.uint8)
         ctx = Context.get(self._device)
         d_planes, d_flags = ctx.to_device(planes), ctx.to_device(flags)
-        table = _patch_table(B * P, Cn, Tn, rot, ps)
         if not whole:
             self.original_shapes = [((Tn, Cn) if v >= 2 else (Cn, Tn)) for v in
                                     ((0,) if rot < 2 else ((0, 1) if rot < 4 else (0, 1, 2, 3)))] * (B * P)
-        if not inference_mode:
-            keep = np.zeros(len(table), dtype=np.uint8)
-            if len(table):
-                check(lib.rfi_patch_any_flag(ctx.handle, C.c_void_p(d_flags.ptr), DEVICE, B * P, Cn, Tn,
-                                             table.ctypes.data_as(C.c_void_p), len(table), ps,
-                                             keep.ctypes.data_as(C.c_void_p)))
-            keep = keep.astype(bool)
-            if keep.any():
-                table = table[keep]
-            table = table[np.random.permutation(len(table))]        # global RNG, as the reference (:760)
-        if num_patches and num_patches < len(table):
-            table = table[:num_patches]
-        table = np.ascontiguousarray(table)
+        table = select_patches(ctx, d_flags, B * P, Cn, Tn, rot, ps, num_patches, inference_mode)
         n = len(table)
         images = np.empty((n, ps, ps, 3), dtype=np.float32)
         labels = np.zeros((n, ps, ps), dtype=np.uint8)
-        if n:
-            want_labels = not inference_mode
-            check(lib.rfi_preprocess_gather(
-                ctx.handle, C.c_void_p(d_planes.ptr), DEVICE, code, B * P, Cn, Tn, C.c_void_p(d_flags.ptr), DEVICE,
-                table.ctypes.data_as(C.c_void_p), n, ps, images.ctypes.data_as(C.c_void_p), HOST,
-                labels.ctypes.data_as(C.c_void_p) if want_labels else None, HOST))
+        gather_patches(ctx, d_planes, d_flags, code, B * P, Cn, Tn, table, ps, images,
+                       None if inference_mode else labels)
         self._table, self._rot, self._ps = table, rot, ps
         self.patches = self.patch_flags = None      # not materialised; see materialise_patches()
         metadata["original_shapes"] = getattr(self, "original_shapes", None)
