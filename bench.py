@@ -150,18 +150,27 @@ def main():
     if not np.isfinite(loss):
         raise SystemExit(f"non-finite loss {loss}")
 
-    # ---- per-kernel-family HIP-event profile (separate steps so events do not sit in the timed region)
-    fam = {}
+    # ---- per-kernel-family HIP-event profile (separate steps so events do not sit in the timed region).
+    # Two passes: SERIAL (side-stream overlap off: every kernel alone on the chip -> the per-kernel
+    # durations the roofline is computed from, comparable with `RFI_NO_OVERLAP=1 rocprofv3 --stats`)
+    # and OVERLAPPED (the mode the timed region ran in; durations of co-running kernels stretch).
+    fam, fam_ov = {}, {}
     if args.profile_steps > 0:
-        ctx.profile_reset()
-        ctx.profile(True)
-        for _ in range(args.profile_steps):
-            model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
-        ctx.synchronize()
-        ctx.profile(False)
-        fam = ctx.profile_report()
-        if args.launch_csv and rank == 0:
-            ctx.profile_dump(args.launch_csv)
+        for serial in (False, True):
+            ctx.set_overlap(not serial and not os.environ.get("RFI_NO_OVERLAP") == "1")
+            ctx.profile_reset()
+            ctx.profile(True)
+            for _ in range(args.profile_steps):
+                model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+            ctx.synchronize()
+            ctx.profile(False)
+            if serial:
+                fam = ctx.profile_report()
+                if args.launch_csv and rank == 0:
+                    ctx.profile_dump(args.launch_csv)
+            else:
+                fam_ov = ctx.profile_report()
+        ctx.set_overlap(not os.environ.get("RFI_NO_OVERLAP") == "1")
     D.barrier()
 
     if rank != 0:
@@ -171,14 +180,17 @@ def main():
     fwd_flops, step_flops = model.algorithmic_flops(B, S, S)
     roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
             "traffic": None}
-    fam_out = {}
-    for name, f in fam.items():
-        per = {"launches_per_step": f["launches"] / args.profile_steps, "ms_per_step": f["ms"] / args.profile_steps}
-        if f["flops"]:
-            per["tflops"] = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] else None
-        if f["bytes"]:
-            per["gbs"] = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else None
-        fam_out[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in per.items()}
+    def per_family(report):
+        out_ = {}
+        for name, f in report.items():
+            per = {"launches_per_step": f["launches"] / args.profile_steps, "ms_per_step": f["ms"] / args.profile_steps}
+            if f["flops"]:
+                per["tflops"] = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] else None
+            if f["bytes"]:
+                per["gbs"] = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else None
+            out_[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in per.items()}
+        return out_
+    fam_out = per_family(fam)
     # the kernel family the step spends most time in (conv_igemm_mfma for the U-Net)
     mfma_fams = [k for k in ("conv_igemm_mfma", "wgrad_igemm_mfma") if k in fam and fam[k]["ms"]]
     dom = max(mfma_fams, key=lambda k: fam[k]["ms"]) if mfma_fams else "conv_igemm_mfma"
@@ -196,7 +208,9 @@ def main():
             pass
     if dom in fam and fam[dom]["ms"]:
         ach = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3) / 1e12
-        roof.update(achieved=round(ach, 3), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), kernel=dom,
+        roof.update(mode="serial profile steps (side-stream overlap off, each kernel alone); the timed region "
+                         "runs with the weight-gradient kernels overlapped on a side stream",
+                    achieved=round(ach, 3), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), kernel=dom,
                     avg_launch_ms=round(fam[dom]["ms"] / fam[dom]["launches"], 5),
                     launches_per_step=fam[dom]["launches"] / args.profile_steps,
                     algorithmic_flops_per_launch=fam[dom]["flops"] / fam[dom]["launches"])
@@ -223,6 +237,7 @@ def main():
                  "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
                  "hip_event_ms_per_step": round(ev_ms / args.steps, 4), "final_loss": round(float(loss), 6)},
         "families": fam_out,
+        "families_overlapped": per_family(fam_ov),
     }
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline ...")

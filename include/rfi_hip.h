@@ -42,6 +42,10 @@ const char* rfi_last_error(void);
 int rfi_device_count(int* count);
 int rfi_ctx_create(int device_id, rfi_ctx** out);
 int rfi_ctx_destroy(rfi_ctx* ctx);
+/* backward-pass overlap (weight-gradient kernels on a side stream next to the dgrad / batch-norm
+ * chain; results are bit-identical either way).  On by default; off = every kernel alone on the
+ * main stream, which is what per-kernel timings and rocprofv3 comparisons want. */
+int rfi_ctx_set_overlap(rfi_ctx* ctx, int enabled);
 int rfi_ctx_synchronize(rfi_ctx* ctx);
 /* the hipStream_t every kernel of this ctx is launched on (for event timing / interop) */
 int rfi_ctx_stream(rfi_ctx* ctx, void** hip_stream);

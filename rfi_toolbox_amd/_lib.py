@@ -46,6 +46,7 @@ _PROTOS = {
     "rfi_ctx_create": (_i, [_i, _pvp]),
     "rfi_ctx_destroy": (_i, [_vp]),
     "rfi_ctx_synchronize": (_i, [_vp]),
+    "rfi_ctx_set_overlap": (_i, [_vp, _i]),
     "rfi_ctx_stream": (_i, [_vp, _pvp]),
     "rfi_ctx_device_name": (_i, [_vp, _cp, _sz]),
     "rfi_malloc": (_i, [_vp, _sz, _pvp]),

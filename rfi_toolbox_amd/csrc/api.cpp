@@ -95,7 +95,16 @@ int rfi_ctx_create(int device_id, rfi_ctx** out) {
         c->device = device_id;
         c->activate();
         RFI_CHECK_HIP(hipGetDeviceProperties(&c->prop, device_id));
-        RFI_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // the main stream carries the dependent chain: highest priority; the side stream fills in
+        int pr_least = 0, pr_greatest = 0;
+        RFI_CHECK_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        RFI_CHECK_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr_greatest));
+        c->main_stream = c->stream;
+        RFI_CHECK_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, pr_least));
+        RFI_CHECK_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+        c->side_done.resize(4);
+        for (auto& e : c->side_done) RFI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (const char* e = getenv("RFI_NO_OVERLAP")) c->overlap = !(e[0] == '1');
         RFI_CHECK_HIP(hipEventCreate(&c->t0));
         RFI_CHECK_HIP(hipEventCreate(&c->t1));
         RFI_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 4096, hipHostMallocDefault));
@@ -114,11 +123,23 @@ int rfi_ctx_destroy(rfi_ctx* ctx) {
         if (ctx->pinned) hipHostFree(ctx->pinned);
         hipEventDestroy(ctx->t0);
         hipEventDestroy(ctx->t1);
-        hipStreamDestroy(ctx->stream);
+        hipStreamSynchronize(ctx->side_stream);
+        hipEventDestroy(ctx->fork_ev);
+        for (auto e : ctx->side_done) hipEventDestroy(e);
+        hipStreamDestroy(ctx->side_stream);
+        hipStreamDestroy(ctx->main_stream);
         delete ctx;
     });
 }
 
+int rfi_ctx_set_overlap(rfi_ctx* ctx, int enabled) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->main_stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->side_stream));
+        ctx->overlap = enabled != 0;
+    });
+}
 int rfi_ctx_synchronize(rfi_ctx* ctx) {
     return guarded([&] {
         ctx->activate();

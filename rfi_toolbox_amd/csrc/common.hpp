@@ -103,6 +103,12 @@ struct rfi_ctx {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     void* get_scratch(size_t bytes);
+    // side stream: weight-gradient GEMMs of the backward pass run here, next to the main stream's
+    // dgrad / batch-norm chain (model.cpp); `stream` is swapped to it for those launches
+    hipStream_t main_stream = nullptr, side_stream = nullptr;
+    hipEvent_t fork_ev = nullptr;
+    std::vector<hipEvent_t> side_done;   // ring, one per in-flight side launch
+    bool overlap = true;
     // RCCL
     void* nccl_comm = nullptr;
     int rank = 0, world = 1;

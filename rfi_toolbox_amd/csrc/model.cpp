@@ -425,6 +425,34 @@ void rfi_model::loss_forward(const uint8_t* labels_dev, int n, int h, int w) {
 }
 
 // ------------------------------------------------------------------------------------ backward
+// Weight-gradient GEMMs have no consumer before the optimiser step, so they run on a SIDE stream
+// while the main stream carries the dependent chain (BN backward -> dgrad -> next layer's BN
+// backward ...).  The memory-bound BN / pooling / slab-reduce kernels then share the chip with an
+// MFMA-bound kernel instead of running alone, and the one-wave-per-SIMD wgrad kernel gets co-resident
+// waves.  Ordering: side waits on an event recorded after the producer of dY; the main stream may
+// run at most 2 side launches ahead (gA/gB of a decoder level are rewritten by the encoder phase
+// no sooner than 3 layers later); all side work is joined before clip+Adam / the all-reduce.
+void rfi_model::side_begin() {
+    if (!ctx->overlap) return;
+    RFI_CHECK_HIP(hipEventRecord(ctx->fork_ev, ctx->main_stream));
+    RFI_CHECK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->fork_ev, 0));
+    ctx->stream = ctx->side_stream;
+}
+void rfi_model::side_end() {
+    if (!ctx->overlap) return;
+    const int ring = (int)ctx->side_done.size();
+    RFI_CHECK_HIP(hipEventRecord(ctx->side_done[side_seq % ring], ctx->side_stream));
+    ctx->stream = ctx->main_stream;
+    if (side_seq >= 2) RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->side_done[(side_seq - 2) % ring], 0));
+    ++side_seq;
+}
+void rfi_model::side_join() {
+    if (!ctx->overlap || side_seq == 0) return;
+    const int ring = (int)ctx->side_done.size();
+    RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->side_done[(side_seq - 1) % ring], 0));
+    side_seq = 0;
+}
+
 namespace {
 
 // given dA (grad w.r.t. the ACTIVATED output of conv c, overwritten with dY), produce dW/db/dgamma/
@@ -452,7 +480,9 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
     wa.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
     wa.slab = m->buf(m->ws_slab);
     wa.slab_floats = m->bufs[m->ws_slab].n;
+    m->side_begin();
     launch_wgrad(ctx, wa);
+    m->side_end();
     if (dx) {
         ConvArgs a;
         a.x = View{dA, c.cout};
@@ -512,7 +542,9 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         wa.sy = 1; wa.sx = u.cin;          // -> [tap][cout][cin]
         wa.slab = buf(ws_slab);
         wa.slab_floats = bufs[ws_slab].n;
+        side_begin();
         launch_wgrad(ctx, wa);
+        side_end();
         ConvArgs a;
         a.x = dUp;
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = s.H; a.Win = s.W;
@@ -549,6 +581,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         backward_conv_bn(this, c1, buf(gB[l]), buf(encY1[l]), in, InXform{}, s,
                          (l == 1) ? nullptr : buf(dpool[l - 1]), 0);
     }
+    side_join();
 }
 
 // ------------------------------------------------------------------------------------ optimiser

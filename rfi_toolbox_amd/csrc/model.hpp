@@ -105,6 +105,11 @@ struct rfi_model {
     float* buf(int i) { return bufs[i].p; }
     int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
 
+    // backward-pass overlap: wgrad launches go to the context's side stream (see model.cpp)
+    int side_seq = 0;
+    void side_begin();                // side stream waits for everything enqueued on the main stream so far
+    void side_end();                  // marks the side launch; bounds the main stream's run-ahead
+    void side_join();                 // main stream waits for all side work
     void refresh_dgrad_weights();
     rfi::View network_input(const float* x_dev, int n, int h, int w);
     void forward(const float* x_dev, int n, int h, int w, bool train_mode);

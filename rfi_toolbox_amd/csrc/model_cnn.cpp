@@ -188,7 +188,9 @@ void rfi_model::backward_cnn3(const float* x_dev, const uint8_t* labels_dev, int
         wa.algo_flops = 2.0 * M * 9.0 * c.cin * c.cout;
         wa.slab = buf(ws_slab);
         wa.slab_floats = bufs[ws_slab].n;
+        side_begin();                      // wgrad on the side stream, next to the dgrad / ReLU chain
         launch_wgrad(ctx, wa);
+        side_end();
         if (dx) {
             ConvArgs a = conv3x3(c, View{dA, c.cout}, InXform{}, c.wd, nullptr, dx, c.cout, c.cin, n, h, w);
             launch_conv(ctx, a);
@@ -197,4 +199,5 @@ void rfi_model::backward_cnn3(const float* x_dev, const uint8_t* labels_dev, int
     conv_backward(c2, buf(cG2), buf(cY2), View{buf(cY1), c1.cout}, relu_xf(c1), buf(cG1));
     View x = c1.cin_p == in_ch ? View{x_dev, in_ch} : View{buf(x_pad), c1.cin_p};
     conv_backward(c1, buf(cG1), buf(cY1), x, InXform{}, nullptr);
+    side_join();
 }

@@ -68,6 +68,10 @@ class Context:
     def synchronize(self):
         check(lib.rfi_ctx_synchronize(self.handle))
 
+    def set_overlap(self, on: bool):
+        """Backward-pass overlap of the weight-gradient kernels (side stream); default on."""
+        check(lib.rfi_ctx_set_overlap(self.handle, 1 if on else 0))
+
     def stream_ptr(self) -> int:
         s = C.c_void_p()
         check(lib.rfi_ctx_stream(self.handle, C.byref(s)))

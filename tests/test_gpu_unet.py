@@ -282,3 +282,28 @@ def test_unet_1024_waterfall_vs_oracle():
     sd = m.state_dict()
     for k in ("encoder1.conv.conv.1.running_mean", "bottleneck.conv.4.running_var", "decoder1.conv.conv.4.running_var"):
         np.testing.assert_allclose(sd[k].numpy(), bufs[k].numpy(), rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_side_stream_overlap_is_bitwise_neutral():
+    """Weight-gradient kernels on the side stream (default) vs everything serial on the main stream:
+    same kernels, same reduction orders -> identical weights, moments and loss after two steps."""
+    from rfi_toolbox_amd.runtime import Context
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(4, 64, 64, 3, generator=g)
+    y = (torch.rand(4, 64, 64, generator=g) > 0.7).to(torch.uint8)
+    ctx = Context.get(0)
+    out = []
+    try:
+        for on in (True, False):
+            ctx.set_overlap(on)
+            torch.manual_seed(17)
+            m = UNet(3, 1, 16)
+            losses = [m.train_step(x, y, lr=1e-3) for _ in range(2)]
+            out.append((losses, m.state_dict(), m.adam_state("bottleneck.conv.3.weight")))
+    finally:
+        ctx.set_overlap(True)
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    np.testing.assert_array_equal(out[0][2][0], out[1][2][0])
+    np.testing.assert_array_equal(out[0][2][1], out[1][2][1])
