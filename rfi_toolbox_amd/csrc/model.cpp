@@ -208,6 +208,11 @@ void rfi_model::reset_channel_state() {
 // ------------------------------------------------------------------------------------ prepare
 void rfi_model::prepare(int n, int h, int w) {
     RFI_REQUIRE(n > 0 && h > 0 && w > 0, "forward: empty batch or image");
+    if (ctx->stream != ctx->main_stream) {      // a side-stream launch threw last time: rejoin first
+        ctx->stream = ctx->main_stream;
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->side_stream));
+        side_seq = 0;
+    }
     if (arch == 1) return prepare_cnn3(n, h, w);
     const int div = 1 << depth;
     RFI_REQUIRE(h % div == 0 && w % div == 0,

@@ -26,7 +26,7 @@ def family(name):
 
 
 def fold(d):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*counter_collection.csv") + glob.glob(f"{d}/*/*counter_collection.csv"))[0]
     tot, n = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         fam = family(r["Kernel_Name"])
