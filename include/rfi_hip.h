@@ -82,6 +82,12 @@ int rfi_unet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_fe
  * encoder.2.weight/bias, decoder.0.weight/bias.  Every rfi_model_* / rfi_train_* call below applies. */
 int rfi_cnn3_create(rfi_ctx* ctx, int in_channels, int out_channels, int width, rfi_model** out);
 int rfi_model_destroy(rfi_model* m);
+/* variants of models/unet.py:120-268 on the same graph: UNetDifferentActivation's activation
+ * (0 = ReLU, 0 < s < 1 = LeakyReLU(negative_slope=s), after every BatchNorm) and UNetOverfit's head
+ * (forward returns sigmoid(logits), :196; the training step then applies BCE-with-logits + dice to THAT
+ * output, as scripts/train_model.py:120,146 does with whatever the model returns). */
+int rfi_model_set_activation(rfi_model* m, float negative_slope);
+int rfi_model_set_head_sigmoid(rfi_model* m, int enabled);
 /* deterministic init with torch's default distributions (kaiming-uniform(a=sqrt5) conv
  * weights/biases, BN gamma=1 beta=0, running stats 0/1) from a 64-bit seed */
 int rfi_model_init(rfi_model* m, uint64_t seed);

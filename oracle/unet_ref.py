@@ -192,7 +192,7 @@ def _bn(x, st, prefix, training, ema_repeats, buffer_updates, tape, tag):
         + beta[None, :, None, None]
 
 
-def _double_conv(x, st, prefix, training, ema_repeats, buffer_updates, tape):
+def _double_conv(x, st, prefix, training, ema_repeats, buffer_updates, tape, negative_slope=0.0):
     for conv_idx, bn_idx in ((0, 1), (3, 4)):
         x = F.conv2d(x, st[f"{prefix}.{conv_idx}.weight"], st[f"{prefix}.{conv_idx}.bias"],
                      padding=1)
@@ -200,30 +200,42 @@ def _double_conv(x, st, prefix, training, ema_repeats, buffer_updates, tape):
             tape[f"{prefix}.{conv_idx}.out"] = x
         x = _bn(x, st, f"{prefix}.{bn_idx}", training, ema_repeats, buffer_updates, tape,
                 f"{prefix}.{bn_idx}")
-        x = torch.relu(x)
+        x = F.leaky_relu(x, negative_slope) if negative_slope else torch.relu(x)
         if tape is not None:
             tape[f"{prefix}.{bn_idx}.act"] = x
     return x
 
 
-def forward(state, x_nchw, training=False, buffer_updates=None, tape=None):
-    """Logits (N,out,H,W).  ``buffer_updates`` (dict) receives new BN buffers in train mode."""
+def forward(state, x_nchw, training=False, buffer_updates=None, tape=None, negative_slope=0.0,
+            head_sigmoid=False):
+    """Logits (N,out,H,W).  ``buffer_updates`` (dict) receives new BN buffers in train mode.
+    ``negative_slope`` > 0: UNetDifferentActivation with LeakyReLU (models/unet.py:198-268);
+    ``head_sigmoid``: UNetOverfit, which returns sigmoid(final_conv(.)) (models/unet.py:196)."""
     _, _, _, depth = infer_config(state)
     skips = []
     h = x_nchw
+    ns = negative_slope
     for lvl in range(1, depth + 1):
-        a = _double_conv(h, state, f"encoder{lvl}.conv.conv", training, 2, buffer_updates, tape)
+        a = _double_conv(h, state, f"encoder{lvl}.conv.conv", training, 2, buffer_updates, tape, ns)
         skips.append(a)
         h = F.max_pool2d(a, kernel_size=2, stride=2)
-    h = _double_conv(h, state, "bottleneck.conv", training, 1, buffer_updates, tape)
+    h = _double_conv(h, state, "bottleneck.conv", training, 1, buffer_updates, tape, ns)
     for lvl in range(depth, 0, -1):
         up = F.conv_transpose2d(h, state[f"decoder{lvl}.up.weight"], state[f"decoder{lvl}.up.bias"],
                                 stride=2)
         if tape is not None:
             tape[f"decoder{lvl}.up.out"] = up
         h = torch.cat([up, skips[lvl - 1]], dim=1)
-        h = _double_conv(h, state, f"decoder{lvl}.conv.conv", training, 1, buffer_updates, tape)
-    return F.conv2d(h, state["final_conv.weight"], state["final_conv.bias"])
+        h = _double_conv(h, state, f"decoder{lvl}.conv.conv", training, 1, buffer_updates, tape, ns)
+    out = F.conv2d(h, state["final_conv.weight"], state["final_conv.bias"])
+    return torch.sigmoid(out) if head_sigmoid else out
+
+
+def variant_forward(negative_slope=0.0, head_sigmoid=False):
+    """``forward_fn`` for loss_and_grads / train_step of a U-Net variant."""
+    def fn(state, x_nchw, training=False, buffer_updates=None, tape=None):
+        return forward(state, x_nchw, training, buffer_updates, tape, negative_slope, head_sigmoid)
+    return fn
 
 
 # --------------------------------------------------------------------------

@@ -63,6 +63,8 @@ _PROTOS = {
     "rfi_profile_dump": (_i, [_vp, _cp]),
     "rfi_unet_create": (_i, [_vp, _i, _i, _i, _i, _pvp]),
     "rfi_cnn3_create": (_i, [_vp, _i, _i, _i, _pvp]),
+    "rfi_model_set_activation": (_i, [_vp, _f]),
+    "rfi_model_set_head_sigmoid": (_i, [_vp, _i]),
     "rfi_model_destroy": (_i, [_vp]),
     "rfi_model_init": (_i, [_vp, C.c_uint64]),
     "rfi_model_entry_count": (_i, [_vp, _pi]),

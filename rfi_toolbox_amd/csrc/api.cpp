@@ -533,6 +533,19 @@ int rfi_model_set_adam_step(rfi_model* m, int64_t step) {
 int rfi_model_set_training(rfi_model* m, int training) {
     return guarded([&] { m->training = training != 0; });
 }
+int rfi_model_set_activation(rfi_model* m, float negative_slope) {
+    return guarded([&] {
+        RFI_REQUIRE(m->arch == 0, "set_activation: U-Net models only");
+        RFI_REQUIRE(negative_slope >= 0.0f && negative_slope < 1.0f, "set_activation: negative_slope must be in [0, 1)");
+        m->act_slope = negative_slope;
+    });
+}
+int rfi_model_set_head_sigmoid(rfi_model* m, int enabled) {
+    return guarded([&] {
+        RFI_REQUIRE(m->arch == 0, "set_head_sigmoid: U-Net models only");
+        m->head_sigmoid = enabled != 0;
+    });
+}
 
 namespace {
 
@@ -558,7 +571,7 @@ const uint8_t* stage_labels(rfi_model* m, const uint8_t* y, int y_mem, int n, in
 }
 void emit_logits(rfi_model* m, float* out, int out_mem, int n, int h, int w, bool nchw) {
     const size_t cnt = (size_t)n * h * w * m->out_ch;
-    const float* src = m->buf(m->logits);
+    const float* src = m->buf(m->head_sigmoid ? m->probs : m->logits);   // the model's OUTPUT
     if (nchw && m->out_ch > 1) {
         launch_nhwc_to_nchw(m->ctx, src, n, m->out_ch, h, w, m->buf(m->out_stage));
         src = m->buf(m->out_stage);
@@ -695,7 +708,8 @@ int rfi_model_eval_batch(rfi_model* m, const float* x, int x_mem, const uint8_t*
         m->forward(xd, n, h, w, m->training);
         const int64_t cnt = (int64_t)n * h * w;
         uint8_t* mask = reinterpret_cast<uint8_t*>(m->buf(m->out_stage));      // cnt bytes fit (cnt floats)
-        launch_threshold(m->ctx, m->buf(m->logits), cnt, threshold, mask);
+        // evaluate_model.py:44-47 thresholds sigmoid(model output), whatever the model returns
+        launch_threshold(m->ctx, m->buf(m->head_sigmoid ? m->probs : m->logits), cnt, threshold, mask);
         auto* d3 = reinterpret_cast<unsigned long long*>(m->d_sums + 5);      // 3 spare 64-bit words
         launch_confusion(m->ctx, mask, RFI_U8, yd, RFI_U8, cnt, d3);
         unsigned long long h3[3];

@@ -34,7 +34,7 @@ __global__ void conv_direct_kernel(ConvArgs a) {
             if (a.xf.scale) {
                 for (int ci = 0; ci < a.Cin; ++ci) {
                     float v = xp[ci] * a.xf.scale[ci] + a.xf.shift[ci];
-                    if (a.xf.relu) v = v > 0.0f ? v : 0.0f;
+                    if (a.xf.relu) v = v > 0.0f ? v : v * a.xf.slope;
                     acc = fmaf(v, wp[ci], acc);
                 }
             } else {
@@ -73,12 +73,12 @@ __global__ void wgrad_direct_kernel(WgradArgs a, int64_t pix_per_split, int64_t 
             float xv = a.xop.p[(((int64_t)n * a.Hx + iy) * a.Wx + ix) * a.xop.pstride + cx];
             if (a.xf_x.scale) {
                 xv = xv * sxs + sxh;
-                if (a.xf_x.relu) xv = xv > 0.0f ? xv : 0.0f;
+                if (a.xf_x.relu) xv = xv > 0.0f ? xv : xv * a.xf_x.slope;
             }
             float yv = a.yop.p[m * a.yop.pstride + cy];
             if (a.xf_y.scale) {
                 yv = yv * sys + syh;
-                if (a.xf_y.relu) yv = yv > 0.0f ? yv : 0.0f;
+                if (a.xf_y.relu) yv = yv > 0.0f ? yv : yv * a.xf_y.slope;
             }
             acc = fmaf(xv, yv, acc);
         }

@@ -101,6 +101,10 @@ __device__ __forceinline__ void row_lane_reduce(double (&acc)[NQ][V], double* re
     }
 }
 
+// ReLU (slope == 0) / LeakyReLU and their derivative factor, as torch defines them (x > 0 ? x : x*slope)
+__device__ __forceinline__ float act_f(float a, float slope) { return a > 0.0f ? a : (slope != 0.0f ? a * slope : 0.0f); }
+__device__ __forceinline__ float dact_f(float z, float g, float slope) { return z > 0.0f ? g : g * slope; }
+
 // ------------------------------------------------------------------ batch-norm statistics
 // partial[(rb*C + c)*2 + {0,1}] = sum x, sum x^2 over the block's rows (double)
 template <int V>
@@ -202,7 +206,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* 
                                      int64_t M, int C, int CL, int64_t rows_per_block,
                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
-                                     double* __restrict__ partial) {
+                                     double* __restrict__ partial, float slope) {
     __shared__ double red[2 * V * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -222,7 +226,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* 
             ldv<V>(da + r * C + c, dv);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                const float dz = (yv[v] * sc[v] + sh[v] > 0.0f) ? dv[v] : 0.0f;
+                const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
                 const float xh = (yv[v] - mu[v]) * is[v];
                 acc[0][v] += (double)dz;
                 acc[1][v] += (double)dz * (double)xh;
@@ -269,7 +273,7 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restr
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ c1,
-                                    const float* __restrict__ c2, double* __restrict__ partial) {
+                                    const float* __restrict__ c2, double* __restrict__ partial, float slope) {
     __shared__ double red[V * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -292,7 +296,7 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restr
             ldv<V>(da + r * C + c, dv);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                const float dz = (yv[v] * sc[v] + sh[v] > 0.0f) ? dv[v] : 0.0f;
+                const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
                 const float xh = (yv[v] - mu[v]) * is[v];
                 o[v] = g[v] * (dz - k1[v] - xh * k2[v]);
                 acc[0][v] += (double)o[v];
@@ -351,7 +355,7 @@ __global__ void channel_sum_kernel(const float* __restrict__ v_, int pstride, in
 // ------------------------------------------------------------------ pool
 __global__ void bn_relu_pool_kernel(const float* __restrict__ y, int N, int H, int W, int C,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                    float* __restrict__ skip, int skip_ps, float* __restrict__ pooled) {
+                                    float* __restrict__ skip, int skip_ps, float* __restrict__ pooled, float slope) {
     const int Hp = H >> 1, Wp = W >> 1;
     const int64_t total = (int64_t)N * Hp * Wp * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -368,7 +372,7 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ y, int N, int H, i
         for (int k = 0; k < 4; ++k) {
             const int64_t pix = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
             float a = y[pix * C + c] * sc + sh;
-            a = a > 0.0f ? a : 0.0f;
+            a = act_f(a, slope);
             skip[pix * skip_ps + c] = a;
             best = (k == 0 || a > best) ? a : best;
         }
@@ -379,7 +383,7 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ y, int N, int H, i
 // rows/cols of an odd-sized map that the floor-mode pool does not cover still need their skip
 __global__ void bn_relu_edge_kernel(const float* __restrict__ y, int N, int H, int W, int C,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                    float* __restrict__ skip, int skip_ps) {
+                                    float* __restrict__ skip, int skip_ps, float slope) {
     const int64_t total = (int64_t)N * H * W * C;
     const int He = H & ~1, We = W & ~1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -390,7 +394,7 @@ __global__ void bn_relu_edge_kernel(const float* __restrict__ y, int N, int H, i
         const int yy = (int)((pix / W) % H);
         if (yy >= He || x >= We) {
             float a = y[pix * C + c] * scale[c] + shift[c];
-            skip[pix * skip_ps + c] = a > 0.0f ? a : 0.0f;
+            skip[pix * skip_ps + c] = act_f(a, slope);
         }
     }
 }
@@ -398,7 +402,7 @@ __global__ void bn_relu_edge_kernel(const float* __restrict__ y, int N, int H, i
 __global__ void pool_bwd_merge_kernel(const float* __restrict__ y, int N, int H, int W, int C,
                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                       const float* __restrict__ dskip, int dskip_ps,
-                                      const float* __restrict__ dpool, float* __restrict__ da) {
+                                      const float* __restrict__ dpool, float* __restrict__ da, float slope) {
     const int Hp = H >> 1, Wp = W >> 1;
     const int64_t total = (int64_t)N * Hp * Wp * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -417,7 +421,7 @@ __global__ void pool_bwd_merge_kernel(const float* __restrict__ y, int N, int H,
         for (int k = 0; k < 4; ++k) {
             pixk[k] = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
             float a = y[pixk[k] * C + c] * sc + sh;
-            a = a > 0.0f ? a : 0.0f;
+            a = act_f(a, slope);
             if (k == 0 || a > best) {
                 best = a;
                 arg = k;
@@ -448,7 +452,7 @@ __global__ void copy_edge_kernel(int N, int H, int W, int C, const float* __rest
 __global__ void head_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                 const float* __restrict__ w, const float* __restrict__ b, int Cout,
-                                float* __restrict__ logits) {
+                                float* __restrict__ logits, float slope) {
     // one wave-quarter (16 lanes) per pixel: lanes stride over channels, shuffle-reduce
     const int lane16 = threadIdx.x & 15;
     const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -457,7 +461,7 @@ __global__ void head_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
         float acc = 0.0f;
         for (int c = lane16; c < C; c += 16) {
             float a = y[m * C + c] * scale[c] + shift[c];
-            a = a > 0.0f ? a : 0.0f;
+            a = act_f(a, slope);
             acc += a * w[o * C + c];
         }
 #pragma unroll
@@ -544,12 +548,26 @@ __global__ void loss_bwd_kernel(const float* __restrict__ logits, const uint8_t*
     }
 }
 
+// UNetOverfit's head (models/unet.py:196): the model RETURNS sigmoid(logits), and train_model.py:120 still
+// feeds that to BCE-with-logits + dice -- the loss kernels then see x = sigmoid(z) as their "logits"
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ z, int64_t n, float* __restrict__ x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = sigmoidf_(z[i]);
+}
+// dz = dx * x (1 - x), in place on dx
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = x[i];
+        d[i] = d[i] * (p * (1.0f - p));
+    }
+}
+
 // da[m][c] = sum_o dl[m][o] * w[o][c];  partial dw/db per block (double)
 __global__ void head_bwd_kernel(const float* __restrict__ y, int64_t M, int C, int CL,
                                 int64_t rows_per_block, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const float* __restrict__ w, int Cout,
                                 const float* __restrict__ dl, float* __restrict__ da,
-                                double* __restrict__ partial) {
+                                double* __restrict__ partial, float slope) {
     // partial layout per row block: [Cout][C] dw then [Cout] db  (stride Cout*C + Cout)
     __shared__ double red[kBlock];
     const int RL = kBlock / CL;
@@ -566,7 +584,7 @@ __global__ void head_bwd_kernel(const float* __restrict__ y, int64_t M, int C, i
             for (int64_t r = r0 + rl; r < r1; r += RL) {
                 const float d = dl[r * Cout + o];
                 float a = y[r * C + c] * sc + sh;
-                a = a > 0.0f ? a : 0.0f;
+                a = act_f(a, slope);
                 sw += (double)d * (double)a;
                 sb += (double)d;
                 if (o == 0) da[r * C + c] = d * wv;
@@ -819,18 +837,18 @@ size_t bn_bwd_ws_floats(int64_t M, int C) {
 void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t M, int C,
                           const float* scale, const float* shift, const float* mean,
                           const float* invstd, float* partial_ws, float* c1, float* c2,
-                          float* dgamma, float* dbeta) {
+                          float* dgamma, float* dbeta, float slope) {
     ChanGeom g = geom_rows(M, C);
     {
         ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 8);
         if (g.V == 4)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
                                ctx->stream, da, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
-                               reinterpret_cast<double*>(partial_ws));
+                               reinterpret_cast<double*>(partial_ws), slope);
         else
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
                                ctx->stream, da, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
-                               reinterpret_cast<double*>(partial_ws));
+                               reinterpret_cast<double*>(partial_ws), slope);
         check_launch("bn_bwd_reduce");
     }
     {
@@ -845,18 +863,18 @@ void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t
 void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t M, int C,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
-                         float* partial_ws, float* dbias) {
+                         float* partial_ws, float* dbias, float slope) {
     ChanGeom g = geom_rows(M, C);
     {
         ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 12);
         if (g.V == 4)
             hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
                                da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
-                               c1, c2, reinterpret_cast<double*>(partial_ws));
+                               c1, c2, reinterpret_cast<double*>(partial_ws), slope);
         else
             hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
                                da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
-                               c1, c2, reinterpret_cast<double*>(partial_ws));
+                               c1, c2, reinterpret_cast<double*>(partial_ws), slope);
         check_launch("bn_bwd_apply");
     }
     if (dbias) {
@@ -896,30 +914,30 @@ void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_w
 }
 
 void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
-                         const float* scale, const float* shift, MutView skip, float* pooled) {
+                         const float* scale, const float* shift, MutView skip, float* pooled, float slope) {
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
     {
         ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 8 + (double)total * 4);
         hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
-                           N, H, W, C, scale, shift, skip.p, skip.pstride, pooled);
+                           N, H, W, C, scale, shift, skip.p, skip.pstride, pooled, slope);
         check_launch("bn_relu_pool");
     }
     if ((H & 1) || (W & 1)) {
         ProfScope ps(ctx, FAM_ELEMWISE);
         hipLaunchKernelGGL(bn_relu_edge_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(kBlock), 0,
-                           ctx->stream, y, N, H, W, C, scale, shift, skip.p, skip.pstride);
+                           ctx->stream, y, N, H, W, C, scale, shift, skip.p, skip.pstride, slope);
         check_launch("bn_relu_edge");
     }
 }
 
 void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
                            const float* scale, const float* shift, View dskip, const float* dpool,
-                           float* da) {
+                           float* da, float slope) {
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
     {
         ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 12 + (double)total * 4);
         hipLaunchKernelGGL(pool_bwd_merge_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
-                           N, H, W, C, scale, shift, dskip.p, dskip.pstride, dpool, da);
+                           N, H, W, C, scale, shift, dskip.p, dskip.pstride, dpool, da, slope);
         check_launch("pool_bwd_merge");
     }
     if ((H & 1) || (W & 1)) {
@@ -931,11 +949,11 @@ void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, in
 }
 
 void launch_head_fwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
-                     const float* shift, const float* w, const float* b, int Cout, float* logits) {
+                     const float* shift, const float* w, const float* b, int Cout, float* logits, float slope) {
     ProfScope ps(ctx, FAM_ELEMWISE, 2.0 * M * C * Cout, (double)M * C * 4 + (double)M * Cout * 4);
     const int64_t threads = M * 16;
     hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)cdiv(threads, kBlock)), dim3(kBlock), 0,
-                       ctx->stream, y, M, C, scale, shift, w, b, Cout, logits);
+                       ctx->stream, y, M, C, scale, shift, w, b, Cout, logits, slope);
     check_launch("head_fwd");
 }
 
@@ -967,19 +985,30 @@ void launch_loss_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, i
     check_launch("loss_bwd");
 }
 
+void launch_sigmoid_fwd(rfi_ctx* ctx, const float* z, int64_t n, float* x) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * 8);
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, z, n, x);
+    check_launch("sigmoid_fwd");
+}
+void launch_sigmoid_bwd(rfi_ctx* ctx, const float* x, int64_t n, float* d_inout) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * 12);
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, x, n, d_inout);
+    check_launch("sigmoid_bwd");
+}
+
 size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
     (void)M;
     return (size_t)kMaxRowBlocks * ((size_t)Cout * C + Cout) * 2;
 }
 void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
                      const float* shift, const float* w, int Cout, const float* dlogits, float* da,
-                     float* partial_ws, float* dw, float* db) {
+                     float* partial_ws, float* dw, float* db, float slope) {
     ChanGeom g = geom_rows(M, C, false);   // the head kernel is one channel per lane
     {
         ProfScope ps(ctx, FAM_ELEMWISE, 4.0 * M * C * Cout, (double)M * C * 8);
         hipLaunchKernelGGL(head_bwd_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
                            M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
-                           reinterpret_cast<double*>(partial_ws));
+                           reinterpret_cast<double*>(partial_ws), slope);
         check_launch("head_bwd");
     }
     {

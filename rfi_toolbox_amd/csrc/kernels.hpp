@@ -11,8 +11,12 @@ namespace rfi {
 struct InXform {
     const float* scale = nullptr;
     const float* shift = nullptr;
-    int relu = 0;
+    int relu = 0;          // 0: none, 1: ReLU, 2: LeakyReLU(slope)
+    float slope = 0.0f;
 };
+static inline InXform act_xform(const float* scale, const float* shift, float slope) {
+    return InXform{scale, shift, slope != 0.0f ? 2 : 1, slope};
+}
 
 // A [N,H,W,C] activation view: `pstride` floats between consecutive pixels (>= C; a
 // channel slice of a wider concat buffer is a view with pstride = total channels).
@@ -100,26 +104,30 @@ void launch_bn_eval_coeffs(rfi_ctx* ctx, int C, const float* gamma, const float*
 void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t M, int C,
                           const float* scale, const float* shift, const float* mean,
                           const float* invstd, float* partial_ws, float* c1, float* c2,
-                          float* dgamma, float* dbeta);
+                          float* dgamma, float* dbeta, float slope = 0.0f);
 size_t bn_bwd_ws_floats(int64_t M, int C);
 // backward, pass 2 (in place on da): dy = gamma*invstd * (dz - c1 - xhat*c2); also per-channel
 // sum(dy) -> dbias_conv (partials in ws, finished by the same launch pair)
 void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t M, int C,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
-                         float* partial_ws, float* dbias);
+                         float* partial_ws, float* dbias, float slope = 0.0f);
 
 // ---------------------------------------------------------------- pool / head / loss
 // a = relu(y*scale+shift) -> skip view (full res) and 2x2 max-pooled p
 void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
-                         const float* scale, const float* shift, MutView skip, float* pooled);
+                         const float* scale, const float* shift, MutView skip, float* pooled, float slope = 0.0f);
 // da[n,y,x,c] = dskip[n,y,x,c] + (argmax of the 2x2 window of a == (y,x) ? dpool : 0)
 void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
                            const float* scale, const float* shift, View dskip, const float* dpool,
-                           float* da);
+                           float* da, float slope = 0.0f);
 // logits[m,o] = b[o] + sum_c relu(y*scale+shift)[m,c] * w[o][c]
 void launch_head_fwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
-                     const float* shift, const float* w, const float* b, int Cout, float* logits);
+                     const float* shift, const float* w, const float* b, int Cout, float* logits,
+                     float slope = 0.0f);
+// x = sigmoid(z); d *= x (1 - x)  (UNetOverfit's sigmoid head, models/unet.py:196)
+void launch_sigmoid_fwd(rfi_ctx* ctx, const float* z, int64_t n, float* x);
+void launch_sigmoid_bwd(rfi_ctx* ctx, const float* x, int64_t n, float* d_inout);
 // loss sums over all logits: [0]=sum bce, [1]=sum sig*y, [2]=sum sig, [3]=sum y  (double)
 void launch_loss_reduce(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count,
                         double* partial_ws, double* sums4, float* loss_out);
@@ -131,7 +139,7 @@ void launch_loss_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, i
 // dw[o][c] = sum_m dlogits[m,o]*act[m,c]; db[o] = sum_m dlogits[m,o]
 void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
                      const float* shift, const float* w, int Cout, const float* dlogits, float* da,
-                     float* partial_ws, float* dw, float* db);
+                     float* partial_ws, float* dw, float* db, float slope = 0.0f);
 size_t head_bwd_ws_floats(int64_t M, int C, int Cout);
 // per-channel sum over pixels of a view (convT bias grad)
 void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out);

@@ -227,7 +227,7 @@ void rfi_model::prepare(int n, int h, int w) {
         mk(encY1); mk(encY2); mk(concat); mk(pool); mk(decY1); mk(decY2);
         mk(gA); mk(gB); mk(dconcat); mk(dpool);
         bottY1 = new_buf(); bottY2 = new_buf(); gBottA = new_buf(); gBottB = new_buf();
-        logits = new_buf(); dlogits = new_buf();
+        logits = new_buf(); dlogits = new_buf(); probs = new_buf();
         x_stage = new_buf(); x_stage2 = new_buf(); x_pad = new_buf(); out_stage = new_buf();
         ws_red = new_buf(); ws_slab = new_buf(); lab_stage = new_buf();
     }
@@ -250,6 +250,7 @@ void rfi_model::prepare(int n, int h, int w) {
     const size_t M1 = (size_t)n * h * w;
     bufs[logits].ensure(ctx, M1 * out_ch);
     bufs[dlogits].ensure(ctx, M1 * out_ch);
+    bufs[probs].ensure(ctx, M1 * out_ch);
     bufs[x_stage].ensure(ctx, M1 * in_ch);
     bufs[x_stage2].ensure(ctx, M1 * in_ch);
     bufs[x_pad].ensure(ctx, M1 * convs[0].cin_p);
@@ -355,7 +356,9 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
     }
 }
 
-InXform bn_xf(const ConvBN& c) { return InXform{c.scale(), c.shift(), 1}; }
+// BN-apply + activation as a load transform; the slope is the model's (0 = ReLU)
+float g_slope = 0.0f;   // set at the top of forward()/backward() of the model being run (one host thread per ctx)
+InXform bn_xf(const ConvBN& c) { return act_xform(c.scale(), c.shift(), g_slope); }
 
 }  // namespace
 
@@ -371,6 +374,7 @@ rfi::View rfi_model::network_input(const float* x_dev, int n, int h, int w) {
 void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode) {
     prepare(n, h, w);
     if (arch == 1) return forward_cnn3(x_dev, n, h, w);
+    g_slope = act_slope;
     const int D = depth;
     View cur = network_input(x_dev, n, h, w);
     for (int l = 1; l <= D; ++l) {
@@ -380,7 +384,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         run_conv_bn(this, c1, cur, InXform{}, s, buf(encY1[l]), train_mode);
         run_conv_bn(this, c2, View{buf(encY1[l]), c1.cout}, bn_xf(c1), s, buf(encY2[l]), train_mode);
         launch_bn_relu_pool(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
-                            MutView{buf(concat[l]) + c2.cout, 2 * c2.cout}, buf(pool[l]));
+                            MutView{buf(concat[l]) + c2.cout, 2 * c2.cout}, buf(pool[l]), act_slope);
         cur = View{buf(pool[l]), c2.cout};
     }
     {
@@ -419,14 +423,16 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
     }
     const int64_t M1 = (int64_t)n * h * w;
     launch_head_fwd(ctx, prevY, M1, feat, prevBN->scale(), prevBN->shift(), params + head_w_off,
-                    params + head_b_off, out_ch, buf(logits));
+                    params + head_b_off, out_ch, buf(logits), act_slope);
+    if (head_sigmoid) launch_sigmoid_fwd(ctx, buf(logits), M1 * out_ch, buf(probs));
 }
 
 void rfi_model::loss_forward(const uint8_t* labels_dev, int n, int h, int w) {
     RFI_REQUIRE(out_ch == 1, "loss: the reference's BCE+dice step is defined for out_channels == 1");
     const int64_t cnt = (int64_t)n * h * w;
-    launch_loss_reduce(ctx, buf(logits), labels_dev, cnt, reinterpret_cast<double*>(buf(ws_red)), d_sums,
-                       d_scalars);
+    // UNetOverfit: BCE-with-logits + dice are applied to the model OUTPUT, i.e. to sigmoid(logits)
+    launch_loss_reduce(ctx, buf(head_sigmoid ? probs : logits), labels_dev, cnt,
+                       reinterpret_cast<double*>(buf(ws_red)), d_sums, d_scalars);
 }
 
 // ------------------------------------------------------------------------------------ backward
@@ -469,9 +475,9 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
     const int64_t M = (int64_t)s.N * s.H * s.W;
     float* ws = m->buf(m->ws_red);
     launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(),
-                         c.c2(), m->grads + c.g_off, m->grads + c.be_off);
+                         c.c2(), m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
     launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
-                        m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off);
+                        m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope);
     WgradArgs wa;
     wa.xop = in;
     wa.yop = View{dA, c.cout};
@@ -508,14 +514,16 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     if (arch == 1) return backward_cnn3(x_dev, labels_dev, n, h, w);
     const int D = depth;
     const int64_t M1 = (int64_t)n * h * w;
+    g_slope = act_slope;
     refresh_dgrad_weights();
     // loss -> dlogits -> head
-    launch_loss_bwd(ctx, buf(logits), labels_dev, M1, d_sums, buf(dlogits));
+    launch_loss_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, d_sums, buf(dlogits));
+    if (head_sigmoid) launch_sigmoid_bwd(ctx, buf(probs), M1 * out_ch, buf(dlogits));
     {
         ConvBN& last = convs[2 * D + 2 + 2 * (D - 1) + 1];
         launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off,
                         out_ch, buf(dlogits), buf(gA[1]), buf(ws_red), grads + head_w_off,
-                        grads + head_b_off);
+                        grads + head_b_off, act_slope);
     }
     // decoders, shallow to deep
     for (int l = 1; l <= D; ++l) {
@@ -578,7 +586,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
         launch_pool_bwd_merge(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
-                              View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]));
+                              View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
         backward_conv_bn(this, c2, buf(gA[l]), buf(encY2[l]), View{buf(encY1[l]), c1.cout}, bn_xf(c1), s,
                          buf(gB[l]), 0);
         View in = (l == 1) ? (c1.cin_p == in_ch ? View{x_dev, in_ch} : View{buf(x_pad), c1.cin_p})

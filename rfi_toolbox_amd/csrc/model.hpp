@@ -64,6 +64,9 @@ struct rfi_model {
     int in_ch = 0, out_ch = 0, feat = 0, depth = 0;
     int arch = 0;                     // 0: U-Net (models/unet.py), 1: 3-layer CNN (depth == 0)
     bool training = true;
+    float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
+    bool head_sigmoid = false;        // UNetOverfit: forward returns sigmoid(logits); the loss sees that too
+    int probs = -1;                   // buffer index of sigmoid(logits) when head_sigmoid
 
     std::vector<rfi::ConvBN> convs;   // enc1.c1, enc1.c2, ..., encD.c2, bott.c1, bott.c2, decD.c1, decD.c2, ..., dec1.c2
     std::vector<rfi::UpConv> ups;     // decD.up ... dec1.up   (index 0 = deepest)

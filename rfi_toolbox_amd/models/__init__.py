@@ -1,7 +1,8 @@
 """Drop-in for ``rfi_toolbox.models`` (reference: rfi_toolbox/models/__init__.py:12-14 exports
 ``UNet``; ``UNetBigger`` is models/unet.py:79-118) running on MI355X through librfi_hip.so."""
 from .simple_cnn import SimpleCNN, simple_cnn_entries
-from .unet import HipSegmenter, UNet, UNetBigger, default_init_state, unet_entries
+from .unet import (HipSegmenter, UNet, UNetBigger, UNetDifferentActivation, UNetOverfit, default_init_state,
+                   unet_entries)
 
-__all__ = ["UNet", "UNetBigger", "SimpleCNN", "HipSegmenter", "default_init_state", "unet_entries",
+__all__ = ["UNet", "UNetBigger", "UNetOverfit", "UNetDifferentActivation", "SimpleCNN", "HipSegmenter", "default_init_state", "unet_entries",
            "simple_cnn_entries"]

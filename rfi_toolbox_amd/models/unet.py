@@ -398,13 +398,69 @@ class UNet(HipSegmenter):
         self._init = default_init_state(self.in_channels, self.out_channels, self.init_features, self.depth)
         self._setup(device)
 
+    _NEGATIVE_SLOPE = 0.0      # activation after every BatchNorm: 0 = ReLU
+    _HEAD_SIGMOID = False
+
     def _create(self, ctx):
         h = C.c_void_p()
         check(lib.rfi_unet_create(ctx.handle, self.in_channels, self.out_channels, self.init_features,
                                   self.depth, C.byref(h)))
+        slope = float(getattr(self, "negative_slope", self._NEGATIVE_SLOPE))
+        if slope:
+            check(lib.rfi_model_set_activation(h, slope))
+        if self._HEAD_SIGMOID:
+            check(lib.rfi_model_set_head_sigmoid(h, 1))
         return h
 
 
 class UNetBigger(UNet):
     """5-level variant (reference models/unet.py:79-118)."""
     _DEPTH = 5
+
+
+class UNetOverfit(UNet):
+    """Reference models/unet.py:156-196: five levels, ``init_features=128`` by default, and the forward
+    returns ``sigmoid(final_conv(.))``.  ``train_step`` feeds that output to BCE-with-logits + dice, as
+    scripts/train_model.py:120,146 does with whatever the model returns."""
+    _DEPTH = 5
+    _HEAD_SIGMOID = True
+
+    def __init__(self, in_channels=1, out_channels=1, init_features=128, *, device=None):
+        super().__init__(in_channels, out_channels, init_features, device=device)
+
+
+def _slope_of(activation):
+    """negative_slope of the activation the reference would build with ``activation(inplace=True)``."""
+    if activation is None:
+        return 0.0
+    if isinstance(activation, (int, float)):
+        return float(activation)
+    import functools
+    nn = torch.nn
+    if isinstance(activation, functools.partial):
+        if activation.func is nn.LeakyReLU:
+            return float(activation.keywords.get("negative_slope", activation.args[0] if activation.args else 0.01))
+        activation = activation.func
+    if isinstance(activation, nn.Module):
+        if isinstance(activation, nn.LeakyReLU):
+            return float(activation.negative_slope)
+        if isinstance(activation, nn.ReLU):
+            return 0.0
+    if activation is nn.ReLU:
+        return 0.0
+    if activation is nn.LeakyReLU:
+        return 0.01
+    raise ValueError(f"activation {activation!r} is not available on the device path "
+                     "(ReLU and LeakyReLU are)")
+
+
+class UNetDifferentActivation(UNet):
+    """Reference models/unet.py:198-268: the U-Net with ``activation(inplace=True)`` after every
+    BatchNorm.  ``activation``: ``torch.nn.ReLU`` (default), ``torch.nn.LeakyReLU`` (slope 0.01), a
+    ``functools.partial(nn.LeakyReLU, negative_slope=s)``, an instance of either, or the slope itself."""
+
+    def __init__(self, in_channels=1, out_channels=1, init_features=32, activation=None, *, device=None):
+        self.negative_slope = _slope_of(activation)
+        if not 0.0 <= self.negative_slope < 1.0:
+            raise ValueError("negative_slope must be in [0, 1)")
+        super().__init__(in_channels, out_channels, init_features, device=device)

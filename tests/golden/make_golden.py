@@ -30,7 +30,7 @@ from rfi_toolbox.config.loader import DataConfig                      # noqa: E4
 from rfi_toolbox.data_generation.synthetic_generator import SyntheticDataGenerator  # noqa: E402
 from rfi_toolbox.evaluation.metrics import evaluate_segmentation      # noqa: E402
 from rfi_toolbox.models import UNet                                   # noqa: E402
-from rfi_toolbox.models.unet import UNetBigger                        # noqa: E402
+from rfi_toolbox.models.unet import UNetBigger, UNetDifferentActivation, UNetOverfit   # noqa: E402
 from rfi_toolbox.preprocessing.preprocessor import Preprocessor, patchify  # noqa: E402
 
 torch.set_num_threads(4)
@@ -276,6 +276,35 @@ def golden_unet_bigger():
     save("unetbigger_f4_b2_s32.npz", **rec)
 
 
+# ---------------------------------------------------------------- N4: UNetOverfit / UNetDifferentActivation
+def golden_unet_variants():
+    """Reference variants (models/unet.py:120-268) through the reference's step: eval/train outputs,
+    loss, step-1 gradients of a few tensors and the state after one step."""
+    # UNetOverfit has five levels: 64 x 64 keeps 2 x 2 pixels (8 BatchNorm samples) at the bottleneck
+    for tag, size, ctor, seed0 in (("overfit_f4_b2_s64", 64, lambda: UNetOverfit(in_channels=3, out_channels=1, init_features=4), 40),
+                                   ("leaky_f4_b2_s32", 32, lambda: UNetDifferentActivation(in_channels=3, out_channels=1,
+                                                                                        init_features=4,
+                                                                                        activation=nn.LeakyReLU), 60)):
+        img, lab = make_batch(777, size, n_views=2)
+        for seed in range(seed0, seed0 + 40):
+            torch.manual_seed(seed)
+            model = ctor()
+            rec = {"_grad_steps": (1,), "_state_steps": (1,), "_adam_steps": ()}
+            for k, v in sd_np(model).items():
+                rec[f"state0/{k}"] = v
+            model.eval()
+            with torch.no_grad():
+                rec["logits_eval0"] = model(torch.from_numpy(img).permute(0, 3, 1, 2).contiguous()).numpy()
+            run_steps(model, img, lab, 1, lr=1e-3, wd=1e-5, record=rec)
+            print(f"{tag} init seed {seed}: activation margins {rec['relu_margin']}")
+            if rec["relu_margin"].min() > 1e-5:
+                break
+        rec = {k: v for k, v in rec.items() if not k.startswith("_")}
+        rec.update(img=img, lab=lab, names=np.array(list(model.state_dict().keys())),
+                   hyper=np.array([1e-3, 0.9, 0.999, 1e-8, 1e-5, 1.0]))
+        save(f"unet_{tag}.npz", **rec)
+
+
 # ---------------------------------------------------------------- A9: the "3-layer CNN segmenter"
 class SimpleCNN(nn.Module):
     """NOT a reference class: the reference README's elided custom-model example
@@ -343,5 +372,6 @@ if __name__ == "__main__":
     golden_preprocess()
     golden_unet_small()
     golden_unet_f8()
+    golden_unet_variants()
     golden_cnn3()
     golden_unet_bigger()

@@ -307,3 +307,63 @@ def test_side_stream_overlap_is_bitwise_neutral():
         assert torch.equal(out[0][1][k], out[1][1][k]), k
     np.testing.assert_array_equal(out[0][2][0], out[1][2][0])
     np.testing.assert_array_equal(out[0][2][1], out[1][2][1])
+
+
+# ------------------------------------------------------------------ variants
+@pytest.mark.parametrize("name,make", [
+    ("unet_overfit_f4_b2_s64.npz", lambda: __import__("rfi_toolbox_amd.models", fromlist=["x"]).UNetOverfit(3, 1, 4)),
+    ("unet_leaky_f4_b2_s32.npz", lambda: __import__("rfi_toolbox_amd.models", fromlist=["x"]).UNetDifferentActivation(
+        3, 1, 4, activation=torch.nn.LeakyReLU)),
+])
+def test_unet_variants_golden(golden_dir, name, make):
+    """UNetOverfit (5 levels, sigmoid output, loss applied to that output) and
+    UNetDifferentActivation(LeakyReLU) against vectors captured from the reference classes
+    (models/unet.py:156-268) driven by the reference's optimisation step."""
+    g = _load(golden_dir, name)
+    assert g["relu_margin"].min() > 1e-5
+    m = make().load_state_dict(_state(g, "state0"))
+    assert list(m.state_dict().keys()) == [str(n) for n in g["names"]]
+    x_nchw = torch.from_numpy(g["img"]).permute(0, 3, 1, 2).contiguous()
+    np.testing.assert_allclose(m.eval()(x_nchw).numpy(), g["logits_eval0"], rtol=0, atol=5e-6)
+    m.train()
+    lr, b1, b2, eps, wd, clip = [float(v) for v in g["hyper"]]
+    loss = m.forward_backward(g["img"], g["lab"])
+    assert loss == pytest.approx(float(g["losses"][0]), abs=2e-6)
+    gn = float(g["grad_norms"][0])
+    coef = min(1.0, clip / (gn + 1e-6))
+    for k in [k[6:] for k in g.files if k.startswith("grad1/")]:
+        if _is_prebn_bias(k):
+            continue
+        want = g[f"grad1/{k}"]
+        rel = np.linalg.norm(m.grad(k) * coef - want) / (np.linalg.norm(want) + 1e-30)
+        assert rel <= 1e-4, (k, rel)
+    norm = m.apply_gradients(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, max_grad_norm=clip)
+    assert norm == pytest.approx(gn, rel=1e-5)
+    for k, v in m.state_dict().items():
+        want = g[f"state1/{k}"]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(want), k
+        else:
+            # step 1 of Adam moves every weight by lr * sign(g): an element whose gradient is at the
+            # rounding-noise level may go either way (|d| up to 2 lr); all others agree to 1e-4
+            d = np.abs(v.numpy() - want)
+            assert d.max() <= 2.2 * lr, (k, d.max())
+            if not _is_prebn_bias(k):
+                assert (d > 1e-4).sum() <= max(1, d.size // 1000), (k, int((d > 1e-4).sum()))
+    ev = m.eval()(x_nchw).numpy()
+    np.testing.assert_allclose(ev, g["logits_eval1"], rtol=0, atol=1e-3)
+
+
+def test_variant_constructors():
+    from rfi_toolbox_amd.models import UNetDifferentActivation, UNetOverfit
+    import functools
+    assert UNetDifferentActivation(3, 1, 4).negative_slope == 0.0
+    assert UNetDifferentActivation(3, 1, 4, activation=torch.nn.LeakyReLU).negative_slope == pytest.approx(0.01)
+    assert UNetDifferentActivation(3, 1, 4, activation=functools.partial(torch.nn.LeakyReLU, negative_slope=0.2)
+                                   ).negative_slope == pytest.approx(0.2)
+    with pytest.raises(ValueError):
+        UNetDifferentActivation(3, 1, 4, activation=torch.nn.GELU)
+    m = UNetOverfit(3, 1, 4)
+    assert m.depth == 5 and m.init_features == 4
+    out = m.eval()(torch.zeros(1, 3, 32, 32)).numpy()
+    assert out.min() >= 0.0 and out.max() <= 1.0                      # sigmoid output

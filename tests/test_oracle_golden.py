@@ -243,3 +243,26 @@ def test_cnn3_oracle_matches_torch_module_fixture(golden_dir):
     for k in st:
         np.testing.assert_allclose(adam["m"][k].numpy(), g[f"adam_m3/{k}"], rtol=0, atol=1e-7)
         np.testing.assert_allclose(adam["v"][k].numpy(), g[f"adam_v3/{k}"], rtol=0, atol=1e-9)
+
+
+# ------------------------------------------------------------------ U-Net variants
+@pytest.mark.parametrize("name,kw", [("unet_overfit_f4_b2_s64.npz", {"head_sigmoid": True}),
+                                     ("unet_leaky_f4_b2_s32.npz", {"negative_slope": 0.01})])
+def test_unet_variants_oracle_matches_reference(golden_dir, name, kw):
+    g = _load(golden_dir, name)
+    st = _state(g, "state0")
+    fn = unet_ref.variant_forward(**kw)
+    x = unet_ref.nhwc_to_nchw(torch.from_numpy(g["img"]))
+    y = torch.from_numpy(g["lab"]).float().unsqueeze(1)
+    np.testing.assert_allclose(fn(st, x, training=False).numpy(), g["logits_eval0"], rtol=0, atol=2e-6)
+    lr, b1, b2, eps, wd, clip = [float(v) for v in g["hyper"]]
+    adam = unet_ref.new_adam_state(st)
+    r = unet_ref.train_step(st, adam, x, y, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, clip=clip, forward_fn=fn)
+    assert r["loss"] == pytest.approx(float(g["losses"][0]), abs=2e-6)
+    np.testing.assert_allclose(r["logits"].numpy(), g["logits_train1"], rtol=0, atol=1e-5)
+    for k, gr in r["grads"].items():
+        if k.endswith(".0.bias") or k.endswith(".3.bias"):
+            continue
+        want = g[f"grad1/{k}"]
+        got = (gr * r["clip_coef"]).numpy()
+        assert np.linalg.norm(got - want) <= 1e-4 * np.linalg.norm(want) + 1e-9, k
