@@ -367,3 +367,20 @@ def test_variant_constructors():
     assert m.depth == 5 and m.init_features == 4
     out = m.eval()(torch.zeros(1, 3, 32, 32)).numpy()
     assert out.min() >= 0.0 and out.max() <= 1.0                      # sigmoid output
+
+
+def test_legacy_eight_channel_input():
+    """The reference's default ``in_channels=8`` (train_model.py:92, the legacy 8-channel dataset of
+    rfi_mask_dataset.py:125-156): stem with Cin = 8 on the MFMA path, forward and gradients vs the oracle."""
+    st = unet_ref.init_state(8, 1, 8, seed=21)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 32, 32, 8, generator=g)
+    y = (torch.rand(2, 32, 32, generator=g) > 0.6).to(torch.uint8)
+    l32, lg32, g32, _ = unet_ref.loss_and_grads(st, unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1))
+    m = UNet(8, 1, 8).load_state_dict(st).train()
+    assert m.forward_backward(x, y) == pytest.approx(float(l32), abs=2e-6)
+    np.testing.assert_allclose(m.debug_tensor("logits"), lg32.permute(0, 2, 3, 1).reshape(-1).numpy(), rtol=0,
+                               atol=1e-5)
+    for k in ("encoder1.conv.conv.0.weight", "encoder1.conv.conv.1.weight", "decoder1.up.weight"):
+        want = g32[k].numpy()
+        assert np.linalg.norm(m.grad(k) - want) <= 2e-2 * np.linalg.norm(want), k
