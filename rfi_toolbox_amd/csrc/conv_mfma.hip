@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             f32x4 v = hreg[it];
             if (a.xf.scale) {
                 v = v * screg + shreg;
-                if (a.xf.relu == 1) v = __builtin_elementwise_max(v, zero);
-                else if (a.xf.relu == 2) v = __builtin_elementwise_max(v, v * a.xf.slope);   // 0 < slope < 1
+                // ReLU / LeakyReLU in one branch-free form: max(v, slope*v), slope in [0, 1) (0 = ReLU)
+                if (a.xf.relu) v = __builtin_elementwise_max(v, v * a.xf.slope);
             }
             v = (((h_mask >> it) & 1u) && cv_l) ? v : zero;      // zero padding AFTER the transform
             if (tid + it * 256 < C::HP * 4) *reinterpret_cast<f32x4*>(s_halo + lds_item0 + it * 64 * KCP) = v;

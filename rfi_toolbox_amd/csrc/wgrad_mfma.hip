@@ -136,12 +136,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
             f32x4 v = yreg[it];
             if (a.xf_y.scale) {
                 v = v * ysc + ysh;
-                if (a.xf_y.relu == 1) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                } else if (a.xf_y.relu == 2) {
-                    v = __builtin_elementwise_max(v, v * a.xf_y.slope);
-                }
+                if (a.xf_y.relu) v = __builtin_elementwise_max(v, v * a.xf_y.slope);   // slope 0 = ReLU
             }
             v = ((yvalid >> it) & 1u) ? v : zero;
             if ((it + 1) * 256 <= C::BM * YQ || tid + it * 256 < C::BM * YQ)
@@ -152,12 +147,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
             f32x4 v = xreg[it];
             if (a.xf_x.scale) {
                 v = v * xsc + xsh;
-                if (a.xf_x.relu == 1) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                } else if (a.xf_x.relu == 2) {
-                    v = __builtin_elementwise_max(v, v * a.xf_x.slope);
-                }
+                if (a.xf_x.relu) v = __builtin_elementwise_max(v, v * a.xf_x.slope);   // slope 0 = ReLU
             }
             v = ((xvalid >> it) & 1u) ? v : zero;
             if ((it + 1) * 256 <= C::HP * XQ || tid + it * 256 < C::HP * XQ)
