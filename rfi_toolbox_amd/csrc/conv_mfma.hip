@@ -49,7 +49,9 @@ struct Cfg {
     static constexpr int W_ITEMS = (NTAP * BN * 4 + 255) / 256;
     static constexpr int STAGE_FLOATS = HP * KCP + NTAP * BN * KCP;
     static constexpr int EPI_FLOATS = 4 * 32 * 36;            // epilogue transpose scratch (4 waves)
-    static constexpr int LDS_FLOATS = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
+    static constexpr int LDS_FLOATS0 = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
+    static constexpr int LDS_FLOATS = (LDS_FLOATS0 + 1) & ~1;          // the fp64 statistics area follows, 8-byte aligned
+    static constexpr int STAT_DOUBLES = 4 * NTL * 32 * 2;              // [wave][n-tile][channel][sum, sumsq]
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
     static_assert(32 % TW == 0 || TW % 32 == 0, "TW must divide or be a multiple of 32");
@@ -84,8 +86,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         j = blockIdx.x; gx = G; t_begin = 0; t_count = ntiles;
     }
     const int my_tiles = (j < t_count) ? (t_count - j + gx - 1) / gx : 0;
-    if (my_tiles == 0) return;                       // uniform for the workgroup, before any barrier
     const int n0 = blockIdx.y * BN;
+    // BatchNorm statistics of the output (forward convs of the model): every workgroup leaves ONE
+    // fp64 (sum, sumsq) record per channel of its channel tile, merged by bn_finalize in record order
+    double* const st_out = a.stats ? a.stats + ((size_t)blockIdx.x * a.Cout + n0) * 2 : nullptr;
+    if (my_tiles == 0) {                             // uniform for the workgroup, before any barrier
+        if (st_out && tid < BN && n0 + tid < a.Cout) st_out[tid * 2] = st_out[tid * 2 + 1] = 0.0;
+        return;
+    }
+    double* const s_stat = reinterpret_cast<double*>(smem + C::LDS_FLOATS);
+    if (st_out)
+        for (int i = tid; i < C::STAT_DOUBLES; i += 256) s_stat[i] = 0.0;   // visible after the first barrier below
     const int z = blockIdx.z;
     const float* __restrict__ wbase = a.w + (a.zgroups > 1 ? (size_t)z * a.Cout * a.Cin : 0);
     const int ooy = a.zgroups > 1 ? (z >> 1) : a.ooy;
@@ -275,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < C::NTL; ++nt) {
                 const int co0 = n0 + wn * (BN / WN) + nt * 32;
+                f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = p1;                // this lane's share of sum y, sum y^2
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt) {
                     constexpr int ROWS = (32 + TW - 1) / TW;            // image rows per 32-pixel m-tile
@@ -292,10 +304,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                             const int pp = ps * 8 + (lane >> 3);        // pixel of the m-tile
                             const f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pp * 36 + g4) + b4;
                             const int oy = oyb + pp / TW, ox = ctile.ox0 + pp % TW;
-                            if (co < a.Cout && oy < a.H && ox < a.W)
+                            if (co < a.Cout && oy < a.H && ox < a.W) {
                                 *reinterpret_cast<f32x4*>(
                                     a.y.p + (unsigned)(((ctile.n * a.Hout + oy * a.osy + ooy) * a.Wout + ox * a.osx + oox) *
                                                            a.y.pstride + co)) = v;
+                                if (st_out) {
+                                    p1 += v;
+                                    p2 += v * v;
+                                }
+                            }
                         }
                     } else {
                         const int co = co0 + li;
@@ -320,6 +337,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
                 }
+                if (st_out && vec_out) {
+                    // lanes l, l^8, l^16, l^32 hold the same 4 channels of different pixels: fold them
+                    // (<= 128 fp32 terms per channel), then continue in fp64 in this wave's LDS slots
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int o = 8; o < 64; o <<= 1) {
+                            p1[e] += __shfl_xor(p1[e], o, 64);
+                            p2[e] += __shfl_xor(p2[e], o, 64);
+                        }
+                    }
+                    if (lane < 8) {
+                        double* d = s_stat + ((wave * C::NTL + nt) * 32 + lane * 4) * 2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            d[e * 2] += (double)p1[e];
+                            d[e * 2 + 1] += (double)p2[e];
+                        }
+                    }
+                }
             }
             __syncthreads();          // the staging LDS is about to be overwritten by the next item
             ctile = ltile;
@@ -331,6 +368,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             RFI_ACC(5, t5, t6);
         }
 #endif
+    }
+    if (st_out) {
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Cout) {          // channel tid of the tile: waves (wm, wn_c) cover it
+            const int wn_c = tid / (BN / WN), nt_c = (tid % (BN / WN)) / 32, cl = tid % 32;
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                const double* d = s_stat + (((m * WN + wn_c) * C::NTL + nt_c) * 32 + cl) * 2;
+                t1 += d[0];
+                t2 += d[1];
+            }
+            st_out[tid * 2] = t1;
+            st_out[tid * 2 + 1] = t2;
+        }
     }
 #ifdef RFI_DIAG_STAMPS
     if (a.stamps && (tid & 63) == 0) {
@@ -348,11 +400,11 @@ static int occupancy_for(size_t lds_bytes) {
 }
 
 template <int R, int S, int TH, int TW, int BN, int WM, int WN>
-void launch_cfg(rfi_ctx* ctx, const ConvArgs& a) {
+void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
     using C = Cfg<R, S, TH, TW, BN, WM, WN>;
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
     const int ychunks = (int)cdiv(a.Cout, BN);
-    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + (size_t)C::STAT_DOUBLES * sizeof(double);
     // persistent grid: about (256 CUs x occupancy) workgroups in total, a multiple of 8 along x,
     // tiles spread evenly over the workgroups of each XCD
     const int gmax = std::max(8, (256 * occupancy_for(lds)) / (ychunks * a.zgroups));
@@ -361,6 +413,10 @@ void launch_cfg(rfi_ctx* ctx, const ConvArgs& a) {
     int gx = (int)cdiv(tx, per);
     int G = 8 * gx;
     if (ntiles < 8) G = ntiles;                                // tiny problems: one tile per workgroup
+    // fused output statistics need the 16-byte store path and one channel-tile column per record
+    const bool vec_out = (a.Cout & 3) == 0 && (a.y.pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y.p) & 15) == 0;
+    if (a.stats && vec_out && a.zgroups == 1 && G <= a.stats_max_records) a.stats_records = G;
+    else a.stats = nullptr;
     dim3 grid(G, ychunks, a.zgroups);
     static bool attr_set = false;
     if (!attr_set) {
@@ -403,7 +459,7 @@ void launch_cfg(rfi_ctx* ctx, const ConvArgs& a) {
 // Where the grid stays >= 2 workgroups per CU, a workgroup takes twice the pixels (wave tile 64x64 or
 // 128x32): twice the MFMAs between barriers and half the filter staging per output.
 template <int R, int S>
-void dispatch_tiles(rfi_ctx* ctx, const ConvArgs& a) {
+void dispatch_tiles(rfi_ctx* ctx, ConvArgs& a) {
     const int ychunks64 = (int)cdiv(a.Cout, 64) * a.zgroups;
     auto big_ok = [&](int th, int tw, int ych) {
         return (int64_t)a.N * cdiv(a.H, th) * cdiv(a.W, tw) * ych >= 512;

@@ -811,11 +811,11 @@ void launch_bn_stats(rfi_ctx* ctx, const float* y, int64_t M, int C, float* part
 void launch_bn_finalize(rfi_ctx* ctx, const float* partial, int64_t M, int C, const float* gamma,
                           const float* beta, float* running_mean, float* running_var,
                           int ema_repeats, float* mean, float* invstd, float* scale, float* shift,
-                          float* var_out) {
+                          float* var_out, int records) {
     ChanGeom g = geom_rows(M, C);
     ProfScope ps(ctx, FAM_BN);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0, ctx->stream,
-                       reinterpret_cast<const double*>(partial), g.rblocks, C, (double)M, gamma, beta,
+                       reinterpret_cast<const double*>(partial), records > 0 ? records : g.rblocks, C, (double)M, gamma, beta,
                        running_mean, running_var, ema_repeats, mean, invstd, scale, shift, var_out);
     check_launch("bn_finalize");
 }

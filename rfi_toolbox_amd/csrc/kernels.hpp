@@ -52,6 +52,12 @@ struct ConvArgs {
     int zgroups = 1;                  // convT fwd: 4 (a,b) groups: w += z*Cout*Cin, (ooy,oox) = (z/2, z%2)
     InXform xf;
     double algo_flops = -1;           // algorithmic FLOPs for the profile (default: from the shape)
+    // optional: per-channel (sum, sumsq) of the OUTPUT in the epilogue (BatchNorm statistics).  in: stats
+    // = [records][Cout][2] doubles with room for stats_max_records; out: stats_records = records written
+    // (0 and stats = null when the launch could not provide them: direct kernel, unaligned output)
+    double* stats = nullptr;
+    int stats_max_records = 0;
+    int stats_records = 0;
 #ifdef RFI_DIAG_STAMPS
     unsigned long long* stamps = nullptr;   // diagnostic build only: per-workgroup phase cycle sums
 #endif
@@ -94,7 +100,7 @@ void launch_bn_stats(rfi_ctx* ctx, const float* y, int64_t M, int C, float* part
 void launch_bn_finalize(rfi_ctx* ctx, const float* partial_ws, int64_t M, int C, const float* gamma,
                         const float* beta, float* running_mean, float* running_var,
                         int ema_repeats, float* mean, float* invstd, float* scale, float* shift,
-                        float* var_out);
+                        float* var_out, int records = 0);   // records > 0: partials came from a conv epilogue
 // eval mode: scale/shift from running statistics
 void launch_bn_eval_coeffs(rfi_ctx* ctx, int C, const float* gamma, const float* beta,
                            const float* running_mean, const float* running_var, float* scale,

@@ -341,14 +341,18 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
     a.R = 3; a.S = 1; a.pad = 1;
     a.xf = xf;
     a.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
+    float* ws = m->buf(m->ws_red);
+    if (train) {            // batch statistics come out of the conv epilogue (no second pass over Y)
+        a.stats = reinterpret_cast<double*>(ws);
+        a.stats_max_records = (int)(bn_stats_ws_floats(c.cout) / ((size_t)c.cout * 4));
+    }
     launch_conv(m->ctx, a);
     const int64_t M = (int64_t)s.N * s.H * s.W;
     if (train) {
-        float* ws = m->buf(m->ws_red);
-        launch_bn_stats(m->ctx, Y, M, c.cout, ws);
+        if (a.stats_records == 0) launch_bn_stats(m->ctx, Y, M, c.cout, ws);   // direct-kernel fallback
         launch_bn_finalize(m->ctx, ws, M, c.cout, m->params + c.g_off, m->params + c.be_off,
                            c.running_mean(), c.running_var(), c.ema_repeats, c.mean(), c.invstd(),
-                           c.scale(), c.shift(), nullptr);
+                           c.scale(), c.shift(), nullptr, a.stats_records);
         c.nbt += c.ema_repeats;
     } else {
         launch_bn_eval_coeffs(m->ctx, c.cout, m->params + c.g_off, m->params + c.be_off, c.running_mean(),
