@@ -64,6 +64,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     float* s_halo = smem;
     float* s_w = smem + C::HP * KCP;
 
+    // the conv kernels carry the dependent chain of the step; when a weight-gradient kernel of the side
+    // stream shares the SIMD, the arbiter should prefer these waves
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;

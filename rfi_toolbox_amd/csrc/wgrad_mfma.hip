@@ -172,13 +172,19 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         // ---- MFMA over this wave's share of the tile's pixels.  Operands of k-step ks+1 are read
         // from LDS into a second register set before the MFMAs of k-step ks are issued, so the
         // matrix pipe never waits on an LDS round trip (one wave per SIMD here: nobody else hides it)
-        const int a_col = by * 32 + li, b_col = bx * 32 + li;
+        // Every operand address is `per-lane base + compile-time offset` (the k-loop is fully unrolled and
+        // a wave's pixel range starts on a tile row), so the 10 ds_reads of a k-step carry immediate
+        // offsets and cost no VALU work: they issue inside the 16 quad-cycles the last MFMA of the
+        // previous k-step still occupies the pipe.
+        static_assert((C::BM / C::WP) % TW == 0 && TW % 2 == 0, "a wave's pixels must start on a tile row");
+        const int pw0 = ps * C::KSTEPS * 2;                          // first pixel of this wave
+        const float* ya = s_y + (pw0 + lh) * C::BYP + by * 32 + li;
+        const float* xb0 = s_x + (((pw0 / TW) * S) * C::HW + lh * S) * C::BXP + bx * 32 + li;
         float av[2], bv[2][C::NTAP];
         auto lds_operands = [&](int ks, float& a_, float (&b_)[C::NTAP]) {
-            const int p = (ps * C::KSTEPS + ks) * 2 + lh;          // pixel within the tile
-            const int ty = p / TW, tx = p % TW;
-            a_ = s_y[p * C::BYP + a_col];
-            const float* xb = s_x + ((ty * S) * C::HW + tx * S) * C::BXP + b_col;
+            const int pk = ks * 2;                                     // pixel pair of this k-step (lane half adds 1)
+            a_ = ya[pk * C::BYP];
+            const float* xb = xb0 + (((pk / TW) * S) * C::HW + (pk % TW) * S) * C::BXP;
 #pragma unroll
             for (int tap = 0; tap < C::NTAP; ++tap) b_[tap] = xb[((tap / R) * C::HW + (tap % R)) * C::BXP];
         };
