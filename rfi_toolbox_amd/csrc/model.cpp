@@ -360,9 +360,7 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
     }
 }
 
-// BN-apply + activation as a load transform; the slope is the model's (0 = ReLU)
-float g_slope = 0.0f;   // set at the top of forward()/backward() of the model being run (one host thread per ctx)
-InXform bn_xf(const ConvBN& c) { return act_xform(c.scale(), c.shift(), g_slope); }
+
 
 }  // namespace
 
@@ -378,7 +376,6 @@ rfi::View rfi_model::network_input(const float* x_dev, int n, int h, int w) {
 void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode) {
     prepare(n, h, w);
     if (arch == 1) return forward_cnn3(x_dev, n, h, w);
-    g_slope = act_slope;
     const int D = depth;
     View cur = network_input(x_dev, n, h, w);
     for (int l = 1; l <= D; ++l) {
@@ -518,7 +515,6 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     if (arch == 1) return backward_cnn3(x_dev, labels_dev, n, h, w);
     const int D = depth;
     const int64_t M1 = (int64_t)n * h * w;
-    g_slope = act_slope;
     refresh_dgrad_weights();
     // loss -> dlogits -> head
     launch_loss_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, d_sums, buf(dlogits));

@@ -113,6 +113,8 @@ struct rfi_model {
     void side_begin();                // side stream waits for everything enqueued on the main stream so far
     void side_end();                  // marks the side launch; bounds the main stream's run-ahead
     void side_join();                 // main stream waits for all side work
+    // BN-apply + activation of layer c as a load transform for its consumers (slope 0 = ReLU)
+    rfi::InXform bn_xf(const rfi::ConvBN& c) const { return rfi::act_xform(c.scale(), c.shift(), act_slope); }
     void refresh_dgrad_weights();
     rfi::View network_input(const float* x_dev, int n, int h, int w);
     void forward(const float* x_dev, int n, int h, int w, bool train_mode);
