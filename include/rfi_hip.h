@@ -202,6 +202,19 @@ int rfi_preprocess_gather(rfi_ctx* ctx, const void* planes, int planes_mem, int 
                           const rfi_patch_src* table_host, int n, int ps, float* out_nhwc, int out_mem,
                           uint8_t* out_labels, int labels_mem);
 
+/* ---- preprocessing, order-statistic branches (preprocessor.py:646-745) on device, for a stack of
+ *      patches (n, ps_h, ps_w) already cut by the host:
+ *      rfi_preprocess_real: REAL float64 input: optional median normalise (:646-670), stretch
+ *      (0 none, 1 SQRT, 2 LOG10; infinities <- MAD of the patch's finite values, :672-706), optional second
+ *      normalise, then the 3-channel extraction of :608-644 + ImageNet normalisation -> out_nhwc; when
+ *      flags_out != NULL also the MAD flags of the PROCESSED patches (:708-745, |x - med| > sigma * MAD).
+ *      rfi_mad_flags: the same flags for any input dtype (complex: of |z|), nothing else. ---- */
+int rfi_preprocess_real(rfi_ctx* ctx, const void* patches, int patches_mem, int dtype, int n, int ps_h,
+                        int ps_w, int stretch, int normalize_before, int normalize_after, double flag_sigma,
+                        float* out_nhwc, int out_mem, uint8_t* flags_out, int flags_mem);
+int rfi_mad_flags(rfi_ctx* ctx, const void* patches, int patches_mem, int dtype, int n, int ps_h, int ps_w,
+                  double flag_sigma, uint8_t* flags_out, int flags_mem);
+
 /* ---- synthetic data on device (the step in front of the path): the sample model of
  *      SyntheticDataGenerator._generate_single_sample (data_generation/synthetic_generator.py:520-815)
  *      with a counter-based per-pixel random stream (Philox4x32-10) instead of NumPy's sequential global

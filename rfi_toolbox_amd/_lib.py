@@ -98,6 +98,8 @@ _PROTOS = {
     "rfi_preprocess_patches": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i]),
     "rfi_generate_waterfalls": (_i, [_vp, C.c_uint64, _i, _i, _i, _i, C.c_double, _i, _i, C.c_double, _vp, _vp, _i,
                                      _vp, _i, _vp, _i]),
+    "rfi_preprocess_real": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_double, _vp, _i, _vp, _i]),
+    "rfi_mad_flags": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.c_double, _vp, _i]),
     "rfi_patch_any_flag": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "rfi_preprocess_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i]),
     "rfi_confusion_counts": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i64, _pi64, _pi64, _pi64]),

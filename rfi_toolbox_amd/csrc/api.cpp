@@ -1019,6 +1019,91 @@ int rfi_preprocess_gather(rfi_ctx* ctx, const void* planes, int planes_mem, int 
     });
 }
 
+namespace {
+// med / mad of every patch of w (n x per doubles) over its non-NaN values -> d_med, d_mad
+void median_and_mad(rfi_ctx* ctx, const double* w, int n, int per, bool finite_only, double* d_med, double* d_mad,
+                    int* d_cnt) {
+    launch_patch_median(ctx, w, n, per, false, nullptr, finite_only, d_med, d_cnt);
+    launch_patch_median(ctx, w, n, per, true, d_med, finite_only, d_mad, nullptr);
+}
+}  // namespace
+
+int rfi_preprocess_real(rfi_ctx* ctx, const void* patches, int patches_mem, int dtype, int n, int ps_h, int ps_w,
+                        int stretch, int normalize_before, int normalize_after, double flag_sigma, float* out_nhwc,
+                        int out_mem, uint8_t* flags_out, int flags_mem) {
+    return guarded([&] {
+        RFI_REQUIRE(dtype == RFI_F64, "preprocess_real: input must be float64 (NumPy keeps float32 input in float32 "
+                                      "arithmetic; that case stays with the caller)");
+        RFI_REQUIRE(stretch >= 0 && stretch <= 2, "preprocess_real: stretch must be 0 (none), 1 (SQRT) or 2 (LOG10)");
+        RFI_REQUIRE(n >= 0 && ps_h > 0 && ps_w > 0 && (n == 0 || (patches && out_nhwc)), "preprocess_real: bad argument");
+        if (n == 0) return;
+        ctx->activate();
+        const int per = ps_h * ps_w;
+        const size_t px = (size_t)n * per, esz = dtype == RFI_F64 ? 8 : 4;
+        Staged in(ctx, patches, patches_mem, px * esz);
+        double* w = static_cast<double*>(ctx->alloc(px * sizeof(double)));
+        double* stat = static_cast<double*>(ctx->alloc((size_t)n * 2 * sizeof(double) + (size_t)n * sizeof(int)));
+        double *d_med = stat, *d_mad = stat + n;
+        int* d_cnt = reinterpret_cast<int*>(stat + 2 * (size_t)n);
+        launch_to_abs_f64(ctx, in.dev, dtype, (int64_t)px, w);            // real dtypes: widening copy
+        auto normalise = [&] {
+            launch_patch_median(ctx, w, n, per, false, nullptr, false, d_med, nullptr);
+            launch_scale_by_median(ctx, w, n, per, d_med);
+        };
+        if (normalize_before) normalise();
+        if (stretch) {
+            launch_stretch(ctx, w, (int64_t)px, stretch);
+            median_and_mad(ctx, w, n, per, true, d_med, d_mad, d_cnt);
+            launch_replace_inf(ctx, w, n, per, d_mad, d_cnt);
+        }
+        if (normalize_after) normalise();
+        float* dout = out_nhwc;
+        uint8_t* dfl = flags_out;
+        void *tmp_out = nullptr, *tmp_fl = nullptr;
+        if (out_mem == RFI_HOST) dout = static_cast<float*>(tmp_out = ctx->alloc(px * 3 * sizeof(float)));
+        if (flags_out && flags_mem == RFI_HOST) dfl = static_cast<uint8_t*>(tmp_fl = ctx->alloc(px));
+        if (flags_out) {
+            median_and_mad(ctx, w, n, per, false, d_med, d_mad, nullptr);
+            launch_mad_flags(ctx, w, n, per, d_med, d_mad, flag_sigma, dfl);
+        }
+        void* mm = ctx->get_scratch((size_t)n * 4 * sizeof(unsigned long long));
+        launch_preprocess(ctx, w, RFI_F64, n, ps_h, ps_w, static_cast<float*>(mm), dout);
+        if (tmp_out) RFI_CHECK_HIP(hipMemcpyAsync(out_nhwc, dout, px * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (tmp_fl) RFI_CHECK_HIP(hipMemcpyAsync(flags_out, dfl, px, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->release(w);
+        ctx->release(stat);
+        if (tmp_out) ctx->release(tmp_out);
+        if (tmp_fl) ctx->release(tmp_fl);
+    });
+}
+
+int rfi_mad_flags(rfi_ctx* ctx, const void* patches, int patches_mem, int dtype, int n, int ps_h, int ps_w,
+                  double flag_sigma, uint8_t* flags_out, int flags_mem) {
+    return guarded([&] {
+        RFI_REQUIRE(dtype >= RFI_C128 && dtype <= RFI_F32, "mad_flags: unknown dtype");
+        RFI_REQUIRE(n >= 0 && ps_h > 0 && ps_w > 0 && (n == 0 || (patches && flags_out)), "mad_flags: bad argument");
+        if (n == 0) return;
+        ctx->activate();
+        const int per = ps_h * ps_w;
+        const size_t px = (size_t)n * per, esz = dtype == RFI_C128 ? 16 : (dtype == RFI_F32 ? 4 : 8);
+        Staged in(ctx, patches, patches_mem, px * esz);
+        double* w = static_cast<double*>(ctx->alloc(px * sizeof(double)));
+        double* stat = static_cast<double*>(ctx->alloc((size_t)n * 2 * sizeof(double)));
+        uint8_t* dfl = flags_out;
+        void* tmp_fl = nullptr;
+        if (flags_mem == RFI_HOST) dfl = static_cast<uint8_t*>(tmp_fl = ctx->alloc(px));
+        launch_to_abs_f64(ctx, in.dev, dtype, (int64_t)px, w);
+        median_and_mad(ctx, w, n, per, false, stat, stat + n, nullptr);
+        launch_mad_flags(ctx, w, n, per, stat, stat + n, flag_sigma, dfl);
+        if (tmp_fl) RFI_CHECK_HIP(hipMemcpyAsync(flags_out, dfl, px, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->release(w);
+        ctx->release(stat);
+        if (tmp_fl) ctx->release(tmp_fl);
+    });
+}
+
 int rfi_generate_waterfalls(rfi_ctx* ctx, uint64_t seed, int n_samples, int n_pol, int c, int t, double noise_mjy,
                             int bandpass, int bandpass_order, double pol_corr, const rfi_event* events_host,
                             const int32_t* event_offsets_host, int out_dtype, void* planes_out, int planes_mem,

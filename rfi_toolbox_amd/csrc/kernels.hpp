@@ -189,6 +189,15 @@ void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int 
                        int T = 0);
 // gather form (table_dev != null): `patches` are the n_planes x C x T waterfall planes and patch i is
 // the ph x pw tile table_dev[i] names; the same map serves the labels and the blank-patch test
+// order statistics / real-input branch (order_stats.hip); v: [n][per] doubles on the device
+void launch_patch_median(rfi_ctx* ctx, const double* v, int n, int per, bool absdev, const double* centre,
+                         bool finite_only, double* out, int* cnt_out);
+void launch_scale_by_median(rfi_ctx* ctx, double* v, int n, int per, const double* med);
+void launch_stretch(rfi_ctx* ctx, double* v, int64_t total, int kind);          // 1 SQRT, 2 LOG10 of |v|
+void launch_replace_inf(rfi_ctx* ctx, double* v, int n, int per, const double* mad, const int* nfinite);
+void launch_mad_flags(rfi_ctx* ctx, const double* v, int n, int per, const double* med, const double* mad,
+                      double sigma, uint8_t* flags);
+void launch_to_abs_f64(rfi_ctx* ctx, const void* src, int dtype, int64_t total, double* dst);
 void launch_synth(rfi_ctx* ctx, unsigned long long seed, int n_samples, int n_pol, int C, int T, double noise,
                   int bandpass, int order, double corr, const rfi_event* events_dev, const int* offsets_dev,
                   int out_dtype, void* planes, uint8_t* flags);

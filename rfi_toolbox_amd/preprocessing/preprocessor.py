@@ -11,9 +11,11 @@ Split of work for the training path (complex visibilities + caller-supplied flag
 * host: a table with one 16-byte entry per patch (plane, view, tile origin) -- its construction in
   the reference's patch order, the keep filter, the global-RNG shuffle (:758-763, so datasets are
   reproducible against the reference under ``np.random.seed``) and ``num_patches`` truncation.
-Other inputs keep the host bookkeeping + ``rfi_preprocess_patches`` form: REAL input (median
-normalise / stretch, :646-706) and flag-less input (MAD flags, :708-745) need order statistics over
-each patch, which stay on the host this round.
+Other inputs are tiled by the host (NumPy views) and processed per patch stack on the GPU: REAL
+input goes through ``rfi_preprocess_real`` (median normalise :646-670, SQRT/LOG10 stretch with the
+MAD of the finite values replacing infinities :672-706, MAD flags :708-745, channels :608-644), and
+flag-less complex input gets its MAD flags from ``rfi_mad_flags``; the order statistics are exact
+(radix selection on the ordered 64-bit image of the doubles).
 """
 from __future__ import annotations
 
@@ -250,22 +252,43 @@ class Preprocessor:
             pflags, _ = _to_patches(_views(fl, rot), patch_size)
         if stretch not in (None, "", "SQRT", "LOG10") and not np.iscomplexobj(patches):
             raise ValueError(f"Invalid stretch '{stretch}'. Use 'SQRT' or 'LOG10'")
-        if not np.iscomplexobj(patches):
-            patches = self._real_pipeline(patches, stretch, normalize_before_stretch, normalize_after_stretch)
+        is_real = not np.iscomplexobj(patches)
+        need_mad = pflags is None and not inference_mode
+        images = None
+        # float32 real input keeps NumPy's float32 arithmetic (host); the device branch computes in float64
+        if on_device_tiling and len(patches) and not (is_real and patches.dtype != np.float64):
+            # order-statistic branches on the GPU: the real-input pipeline (median normalise, stretch,
+            # MAD flags, channels) in one call; for flag-less complex input the MAD flags of |z|
+            if is_real:
+                images, mad = self._real_on_device(patches, stretch, normalize_before_stretch,
+                                                   normalize_after_stretch, flag_sigma if need_mad else None)
+                if need_mad:
+                    pflags = mad
+            elif need_mad:
+                pflags = self._mad_flags_on_device(patches, flag_sigma)
+        else:
+            if is_real:
+                patches = self._real_pipeline(patches, stretch, normalize_before_stretch, normalize_after_stretch)
+            if need_mad:
+                pflags = self._mad_flags(patches, flag_sigma)
         if inference_mode:
             pflags = np.zeros(patches.shape, dtype=np.uint8)
-        elif pflags is None:
-            pflags = self._mad_flags(patches, flag_sigma)
+        sel = np.arange(len(patches))
         if not inference_mode:
             keep = pflags.reshape(len(pflags), -1).any(axis=1)
             if keep.any():
-                patches, pflags = patches[keep], pflags[keep]
-            perm = np.random.permutation(len(patches))         # global RNG, as the reference (:760)
-            patches, pflags = patches[perm], pflags[perm]
-        if num_patches and num_patches < len(patches):
-            patches, pflags = patches[:num_patches], pflags[:num_patches]
-        self.patches, self.patch_flags = patches, pflags
-        images = self._channels_on_device(patches)
+                sel = sel[keep]
+            sel = sel[np.random.permutation(len(sel))]         # global RNG, as the reference (:760)
+        if num_patches and num_patches < len(sel):
+            sel = sel[:num_patches]
+        pflags = pflags[sel]
+        if images is not None:                                  # channels already computed for every patch
+            images = np.ascontiguousarray(images[sel])
+            self.patches, self.patch_flags = None, pflags       # processed real patches stay on the device
+        else:
+            patches = patches[sel]
+            self.patches, self.patch_flags = patches, pflags
+            images = self._channels_on_device(patches)
         labels = np.ascontiguousarray(pflags).astype(np.uint8)
         metadata = {"patch_size": patch_size, "stretch": stretch, "flag_sigma": flag_sigma,
                     "normalize_before_stretch": normalize_before_stretch,
@@ -274,6 +297,34 @@ class Preprocessor:
                     "original_shapes": getattr(self, "original_shapes", None)}
         self.dataset = TorchDataset(torch.from_numpy(images), torch.from_numpy(labels), metadata)
         return self.dataset
+
+    # ---- order-statistic branches on the GPU (librfi_hip.so rfi_preprocess_real / rfi_mad_flags)
+    def _real_on_device(self, patches, stretch, before, after, sigma):
+        n, ph, pw = patches.shape
+        code = F64
+        patches = np.ascontiguousarray(patches, dtype=np.float64)
+        images = np.empty((n, ph, pw, 3), dtype=np.float32)
+        flags = np.empty((n, ph, pw), dtype=np.uint8) if sigma is not None else None
+        ctx = Context.get(self._device)
+        check(lib.rfi_preprocess_real(ctx.handle, patches.ctypes.data_as(C.c_void_p), HOST, code, n, ph, pw,
+                                      {None: 0, "": 0, "SQRT": 1, "LOG10": 2}[stretch], 1 if before else 0,
+                                      1 if after else 0, float(sigma if sigma is not None else 0.0),
+                                      images.ctypes.data_as(C.c_void_p), HOST,
+                                      flags.ctypes.data_as(C.c_void_p) if flags is not None else None, HOST))
+        return images, (flags.astype(bool) if flags is not None else None)
+
+    def _mad_flags_on_device(self, patches, sigma):
+        n, ph, pw = patches.shape
+        code = {np.dtype(np.complex128): C128, np.dtype(np.complex64): C64, np.dtype(np.float64): F64,
+                np.dtype(np.float32): F32}.get(patches.dtype)
+        if code is None:
+            patches, code = patches.astype(np.complex128), C128
+        patches = np.ascontiguousarray(patches)
+        flags = np.empty((n, ph, pw), dtype=np.uint8)
+        ctx = Context.get(self._device)
+        check(lib.rfi_mad_flags(ctx.handle, patches.ctypes.data_as(C.c_void_p), HOST, code, n, ph, pw, float(sigma),
+                                flags.ctypes.data_as(C.c_void_p), HOST))
+        return flags.astype(bool)
 
     # ---- real-valued branch (host, order statistics)
     @staticmethod

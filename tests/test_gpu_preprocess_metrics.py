@@ -141,3 +141,49 @@ def test_device_tiling_equals_host_bookkeeping(shape, dtype, ps, kw):
     if not kw.get("inference_mode"):
         np.testing.assert_array_equal(pflags.astype(np.uint8), b.labels.numpy())
     assert patches.shape == tuple(b.labels.shape)
+
+
+# ------------------------------------------------------------------ order-statistic branches on the GPU
+@pytest.mark.parametrize("kw", [dict(stretch="SQRT"), dict(stretch="LOG10", normalize_after_stretch=True),
+                                dict(stretch=None), dict(stretch="LOG10", normalize_before_stretch=False)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_real_input_branch_on_device_equals_host(kw, dtype):
+    """Median normalise / stretch / MAD flags / channels for REAL input on the GPU (exact order statistics
+    by radix selection) against the NumPy form of the same steps -- with zeros (log10 -> -inf, replaced by
+    the MAD of the finite values), NaNs (skipped by nanmedian) and negative values in the data."""
+    rng = np.random.default_rng(5)
+    x = rng.lognormal(0.0, 1.0, size=(1, 2, 96, 64)).astype(dtype)
+    x[0, 0, 3:5, 10:40] = 0.0
+    x[0, 1, 50, 7] = np.nan
+    x[0, 1, 20:22, :] *= -1.0
+    x[0, 0, 70:72, 30:34] *= 500.0
+    np.random.seed(3)
+    a = Preprocessor(x).create_dataset(patch_size=32, flag_sigma=4, on_device_tiling=False, **kw)
+    np.random.seed(3)
+    b = Preprocessor(x).create_dataset(patch_size=32, flag_sigma=4, **kw)      # float32: NumPy float32 math, host
+    assert len(a) == len(b) > 0
+    np.testing.assert_array_equal(a.labels.numpy(), b.labels.numpy())
+    np.testing.assert_allclose(a.images.numpy(), b.images.numpy(), rtol=0, atol=2e-6, equal_nan=True)
+    # with caller-supplied flags the MAD step is skipped and the labels are the tiled flags
+    fl = np.zeros(x.shape, bool)
+    fl[0, :, 10:20, 10:20] = True
+    np.random.seed(4)
+    c = Preprocessor(x, flags=fl).create_dataset(patch_size=32, on_device_tiling=False, **kw)
+    np.random.seed(4)
+    d = Preprocessor(x, flags=fl).create_dataset(patch_size=32, **kw)
+    np.testing.assert_array_equal(c.labels.numpy(), d.labels.numpy())
+    np.testing.assert_allclose(c.images.numpy(), d.images.numpy(), rtol=0, atol=2e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_mad_flags_of_complex_input_on_device(dtype):
+    rng = np.random.default_rng(6)
+    z = (rng.normal(size=(1, 1, 128, 64)) + 1j * rng.normal(size=(1, 1, 128, 64))).astype(dtype)
+    z[0, 0, 40:44, :] *= 30.0
+    np.random.seed(8)
+    a = Preprocessor(z).create_dataset(patch_size=64, flag_sigma=5, on_device_tiling=False)
+    np.random.seed(8)
+    b = Preprocessor(z).create_dataset(patch_size=64, flag_sigma=5)
+    assert b.labels.numpy().any()
+    np.testing.assert_array_equal(a.labels.numpy(), b.labels.numpy())
+    np.testing.assert_allclose(a.images.numpy(), b.images.numpy(), rtol=0, atol=2e-6)
