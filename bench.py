@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
+PEAK_BF16_1K_MFMA_TFLOPS = 1258.0  # v_mfma_f32_32x32x8_bf16 (the instruction the bf16 mode uses): 8x the fp32 rate
 PEAK_HBM_GBS = 8000.0
 
 
@@ -91,6 +92,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="patches per GPU per step")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--features", type=int, default=None)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32: float32 MFMA, the parity-pinned path (default); bf16: MFMA operands rounded to "
+                         "bfloat16 in registers, float32 accumulate/storage (the reference's autocast mode on a GPU)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-csv", default=None, help="write the per-launch HIP-event profile here")
@@ -124,6 +128,8 @@ def main():
     else:
         model = UNet(3, 1, args.features, device=local_rank)
     model.train()
+    if args.dtype == "bf16":
+        model.set_compute_dtype("bfloat16")
     log("model built")
     B, S = args.batch, args.size
     # synthetic waterfalls -> views/tiling -> 3-channel patches + labels, generated and kept in HBM
@@ -178,7 +184,8 @@ def main():
     ms_per_step = wall * 1e3 / args.steps
     value = world * B * args.steps / wall
     fwd_flops, step_flops = model.algorithmic_flops(B, S, S)
-    roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
+    peak = PEAK_BF16_1K_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    roof = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,
             "traffic": None}
     def per_family(report):
         out_ = {}
@@ -198,7 +205,7 @@ def main():
     # same command (bench.py cannot run under the profiler and time itself at once)
     import glob
     traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if traffic_files and args.workload == "unet":
+    if traffic_files and args.workload == "unet" and args.dtype == "f32":
         try:
             tj = json.load(open(traffic_files[-1]))["families"].get(dom)
             if tj:
@@ -210,7 +217,7 @@ def main():
         ach = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3) / 1e12
         roof.update(mode="serial profile steps (side-stream overlap off, each kernel alone); the timed region "
                          "runs with the weight-gradient kernels overlapped on a side stream",
-                    achieved=round(ach, 3), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), kernel=dom,
+                    achieved=round(ach, 3), frac=round(ach / peak, 4), kernel=dom,
                     avg_launch_ms=round(fam[dom]["ms"] / fam[dom]["launches"], 5),
                     launches_per_step=fam[dom]["launches"] / args.profile_steps,
                     algorithmic_flops_per_launch=fam[dom]["flops"] / fam[dom]["launches"])
@@ -219,7 +226,7 @@ def main():
         "metric": ("training patches/sec (128x128x3)" if S == 128 else f"training samples/sec ({S}x{S}x3)"),
         "value": round(value, 2), "unit": "patches/s" if S < 512 else "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": {
             "unet": f"UNet(3,1,{args.features}) train step (fwd+BCE/dice+bwd+clip+Adam), "
                     f"batch {B}/GPU x {S}x{S}x3 NHWC fp32, BASELINE configs[1] shape on the "

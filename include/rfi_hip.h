@@ -87,6 +87,11 @@ int rfi_model_destroy(rfi_model* m);
  * (forward returns sigmoid(logits), :196; the training step then applies BCE-with-logits + dice to THAT
  * output, as scripts/train_model.py:120,146 does with whatever the model returns). */
 int rfi_model_set_activation(rfi_model* m, float negative_slope);
+/* arithmetic of the conv / transposed-conv / weight-gradient contractions: 0 = float32 MFMA (default; the
+ * parity-pinned path), 1 = operands rounded to bfloat16 (RNE) in registers, float32 accumulate -- the
+ * mixed-precision mode the reference gets from torch.autocast on a GPU (scripts/train_model.py:131,144).
+ * Tensors in HBM, BatchNorm, loss and the optimiser stay float32 in both modes. */
+int rfi_model_set_compute_dtype(rfi_model* m, int dtype);
 int rfi_model_set_head_sigmoid(rfi_model* m, int enabled);
 /* deterministic init with torch's default distributions (kaiming-uniform(a=sqrt5) conv
  * weights/biases, BN gamma=1 beta=0, running stats 0/1) from a 64-bit seed */

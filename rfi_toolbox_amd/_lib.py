@@ -64,6 +64,7 @@ _PROTOS = {
     "rfi_unet_create": (_i, [_vp, _i, _i, _i, _i, _pvp]),
     "rfi_cnn3_create": (_i, [_vp, _i, _i, _i, _pvp]),
     "rfi_model_set_activation": (_i, [_vp, _f]),
+    "rfi_model_set_compute_dtype": (_i, [_vp, _i]),
     "rfi_model_set_head_sigmoid": (_i, [_vp, _i]),
     "rfi_model_destroy": (_i, [_vp]),
     "rfi_model_init": (_i, [_vp, C.c_uint64]),

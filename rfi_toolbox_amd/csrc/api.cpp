@@ -540,6 +540,12 @@ int rfi_model_set_activation(rfi_model* m, float negative_slope) {
         m->act_slope = negative_slope;
     });
 }
+int rfi_model_set_compute_dtype(rfi_model* m, int dtype) {
+    return guarded([&] {
+        RFI_REQUIRE(dtype == 0 || dtype == 1, "set_compute_dtype: 0 (float32) or 1 (bfloat16 MFMA operands)");
+        m->compute_bf16 = dtype == 1;
+    });
+}
 int rfi_model_set_head_sigmoid(rfi_model* m, int enabled) {
     return guarded([&] {
         RFI_REQUIRE(m->arch == 0, "set_head_sigmoid: U-Net models only");

@@ -32,6 +32,19 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// 4 floats (one lane's k-quad of a fragment) -> 4 bf16, round-to-nearest-even (2 x v_cvt_pk_bf16_f32)
+__device__ __forceinline__ s16x4 pack_bf16(f32x4 x) {
+    const f32x2 lo = {x.x, x.y}, hi = {x.z, x.w};
+    u32x2 r;
+    r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+    r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+    return __builtin_bit_cast(s16x4, r);
+}
 
 constexpr int KC = 16;    // channels per K-chunk
 constexpr int KCP = 20;   // padded LDS row (floats)
@@ -57,7 +70,10 @@ struct Cfg {
     static_assert(32 % TW == 0 || TW % 32 == 0, "TW must divide or be a multiple of 32");
 };
 
-template <int R, int S, int TH, int TW, int BN, int WM, int WN>
+// BF: bf16 compute mode -- the SAME fp32 tiles in HBM and LDS; each lane's k-quad of an operand fragment is
+// rounded to bf16 in registers and ONE v_mfma_f32_32x32x8_bf16 (fp32 accumulate) replaces the four
+// fp32 32x32x2 MFMAs of that quad (identical k-to-lane mapping: lane half lh holds k = 4 lh .. 4 lh + 3).
+template <int R, int S, int TH, int TW, int BN, int WM, int WN, bool BF>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     using C = Cfg<R, S, TH, TW, BN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -263,14 +279,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < C::NTL; ++nt)
                     bf[nt] = *reinterpret_cast<const f32x4*>(s_w + b_base[nt] + tap * BN * KCP + kb * 8);
+                if constexpr (BF) {
+                    s16x4 ah[C::MT], bh[C::NTL];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int mt = 0; mt < C::MT; ++mt) ah[mt] = pack_bf16(af[mt]);
+#pragma unroll
+                    for (int nt = 0; nt < C::NTL; ++nt) bh[nt] = pack_bf16(bf[nt]);
 #pragma unroll
                     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < C::NTL; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t],
-                                                                              acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < C::NTL; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t],
+                                                                                  acc[mt][nt], 0, 0, 0);
+                }
             }
         }
         RFI_T(t4);
@@ -402,8 +431,11 @@ static int occupancy_for(size_t lds_bytes) {
     return o < 1 ? 1 : (o > 3 ? 3 : o);   // VGPRs: <= 215 for the 72 KB tiles (2 waves/SIMD), <= 151 for the others (3)
 }
 
-template <int R, int S, int TH, int TW, int BN, int WM, int WN>
+template <int R, int S, int TH, int TW, int BN, int WM, int WN, bool BF = false>
 void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
+    if constexpr (!BF) {
+        if (a.bf16) return launch_cfg<R, S, TH, TW, BN, WM, WN, true>(ctx, a);
+    }
     using C = Cfg<R, S, TH, TW, BN, WM, WN>;
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
     const int ychunks = (int)cdiv(a.Cout, BN);
@@ -424,7 +456,7 @@ void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
         RFI_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_kernel<R, S, TH, TW, BN, WM, WN>),
+            reinterpret_cast<const void*>(&conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, BF>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -434,7 +466,7 @@ void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
         const size_t nw = (size_t)G * ychunks * a.zgroups * 32;
         RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&b.stamps), nw * 8));
         RFI_CHECK_HIP(hipMemsetAsync(b.stamps, 0, nw * 8, ctx->stream));
-        hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN>), grid, dim3(256), lds, ctx->stream, b);
+        hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, BF>), grid, dim3(256), lds, ctx->stream, b);
         std::vector<unsigned long long> h(nw);
         RFI_CHECK_HIP(hipMemcpyAsync(h.data(), b.stamps, nw * 8, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -453,7 +485,7 @@ void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
         return;
     }
 #endif
-    hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN>), grid, dim3(256), lds, ctx->stream,
+    hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, BF>), grid, dim3(256), lds, ctx->stream,
                        a);
     check_launch("conv_igemm");
 }
@@ -518,7 +550,8 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     if (ctx->profiling)
         label = "conv R" + std::to_string(a.R) + "S" + std::to_string(a.S) + " N" + std::to_string(a.N) + " " +
                 std::to_string(a.H) + "x" + std::to_string(a.W) + " " + std::to_string(a.Cin) + "->" +
-                std::to_string(a.Cout) + (a.xf.scale ? " xf" : "") + (a.zgroups > 1 ? " z4" : "");
+                std::to_string(a.Cout) + (a.xf.scale ? " xf" : "") + (a.zgroups > 1 ? " z4" : "") +
+                (a.bf16 ? " bf16" : "");
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0, label);
     if (a.R == 3) dispatch_tiles<3, 1>(ctx, a);
     else if (a.R == 1) dispatch_tiles<1, 1>(ctx, a);

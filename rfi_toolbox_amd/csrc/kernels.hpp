@@ -52,6 +52,7 @@ struct ConvArgs {
     int zgroups = 1;                  // convT fwd: 4 (a,b) groups: w += z*Cout*Cin, (ooy,oox) = (z/2, z%2)
     InXform xf;
     double algo_flops = -1;           // algorithmic FLOPs for the profile (default: from the shape)
+    bool bf16 = false;                // MFMA kernels: operands rounded to bf16 in registers, fp32 accumulate
     // optional: per-channel (sum, sumsq) of the OUTPUT in the epilogue (BatchNorm statistics).  in: stats
     // = [records][Cout][2] doubles with room for stats_max_records; out: stats_records = records written
     // (0 and stats = null when the launch could not provide them: direct kernel, unaligned output)
@@ -86,6 +87,7 @@ struct WgradArgs {
     float* slab = nullptr;            // workspace for split partials
     size_t slab_floats = 0;
     double algo_flops = -1;
+    bool bf16 = false;                // MFMA kernel: operands rounded to bf16 in registers, fp32 accumulate
 };
 size_t wgrad_slab_floats(const WgradArgs& a, int impl);
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);

@@ -346,6 +346,7 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
         a.stats = reinterpret_cast<double*>(ws);
         a.stats_max_records = (int)(bn_stats_ws_floats(c.cout) / ((size_t)c.cout * 4));
     }
+    a.bf16 = m->compute_bf16;
     launch_conv(m->ctx, a);
     const int64_t M = (int64_t)s.N * s.H * s.W;
     if (train) {
@@ -414,6 +415,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         a.R = 1; a.S = 1; a.pad = 0;
         a.zgroups = 4;
         a.xf = bn_xf(*prevBN);
+        a.bf16 = compute_bf16;
         launch_conv(ctx, a);
         ConvBN& c1 = convs[2 * D + 2 + 2 * k];
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
@@ -493,6 +495,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
     wa.slab = m->buf(m->ws_slab);
     wa.slab_floats = m->bufs[m->ws_slab].n;
     m->side_begin();
+    wa.bf16 = m->compute_bf16;
     launch_wgrad(ctx, wa);
     m->side_end();
     if (dx) {
@@ -505,6 +508,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
         a.y = MutView{dx, c.cin};
         a.Hout = s.H; a.Wout = s.W;
         a.R = 3; a.S = 1; a.pad = 1;
+        a.bf16 = m->compute_bf16;
         launch_conv(ctx, a);
     }
 }
@@ -556,6 +560,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         wa.slab = buf(ws_slab);
         wa.slab_floats = bufs[ws_slab].n;
         side_begin();
+        wa.bf16 = compute_bf16;
         launch_wgrad(ctx, wa);
         side_end();
         ConvArgs a;
@@ -568,6 +573,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         a.y = MutView{dprev, u.cin};
         a.Hout = sin.H; a.Wout = sin.W;
         a.R = 2; a.S = 2; a.pad = 0;
+        a.bf16 = compute_bf16;
         launch_conv(ctx, a);
     }
     // bottleneck

@@ -65,6 +65,7 @@ struct rfi_model {
     int arch = 0;                     // 0: U-Net (models/unet.py), 1: 3-layer CNN (depth == 0)
     bool training = true;
     float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
+    bool compute_bf16 = false;        // conv / wgrad MFMAs on bf16-rounded operands (fp32 storage + accumulate)
     bool head_sigmoid = false;        // UNetOverfit: forward returns sigmoid(logits); the loss sees that too
     int probs = -1;                   // buffer index of sigmoid(logits) when head_sigmoid
 

@@ -21,6 +21,18 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s16x4 pack_bf16(float a, float b, float c, float d) {   // RNE, 2 x v_cvt_pk_bf16_f32
+    const f32x2 lo = {a, b}, hi = {c, d};
+    u32x2 r;
+    r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+    r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+    return __builtin_bit_cast(s16x4, r);
+}
 
 template <int R, int S, int BY, int BX, int TH, int TW>
 struct WCfg {
@@ -49,7 +61,10 @@ struct WgradDev {
     int64_t slab_stride; // floats per slab
 };
 
-template <int R, int S, int BY, int BX, int TH, int TW>
+// BF: bf16 compute mode -- same fp32 tiles in LDS; a lane gathers its channel's values of 4 consecutive
+// pixels (lane half lh: pixels 4 lh .. 4 lh + 3 of an 8-pixel tile row), rounds them to bf16 and ONE
+// v_mfma_f32_32x32x8_bf16 per tap (fp32 accumulate) covers the 8 pixels four fp32 k-steps covered.
+template <int R, int S, int BY, int BX, int TH, int TW, bool BF>
 __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
     using C = WCfg<R, S, BY, BX, TH, TW>;
     const WgradArgs& a = d.a;
@@ -178,6 +193,25 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         // previous k-step still occupies the pipe.
         static_assert((C::BM / C::WP) % TW == 0 && TW % 2 == 0, "a wave's pixels must start on a tile row");
         const int pw0 = ps * C::KSTEPS * 2;                          // first pixel of this wave
+        if constexpr (BF) {
+            static_assert(TW == 8 && (C::KSTEPS % 4) == 0, "bf16 path: 8-pixel tile rows, whole rows per wave");
+            const float* ya4 = s_y + (pw0 + lh * 4) * C::BYP + by * 32 + li;
+            const float* xb4 = s_x + (((pw0 / TW) * S) * C::HW + lh * 4 * S) * C::BXP + bx * 32 + li;
+#pragma unroll
+            for (int g = 0; g < C::KSTEPS / 4; ++g) {                  // one 8-pixel tile row per group
+                const float* yp = ya4 + g * 8 * C::BYP;
+                const s16x4 a4 = pack_bf16(yp[0], yp[C::BYP], yp[2 * C::BYP], yp[3 * C::BYP]);
+                const float* xr = xb4 + (g * S) * C::HW * C::BXP;
+#pragma unroll
+                for (int tap = 0; tap < C::NTAP; ++tap) {
+                    const float* xp = xr + ((tap / R) * C::HW + (tap % R)) * C::BXP;
+                    const s16x4 b4 = pack_bf16(xp[0], xp[S * C::BXP], xp[2 * S * C::BXP], xp[3 * S * C::BXP]);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a4, b4, acc[tap], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         const float* ya = s_y + (pw0 + lh) * C::BYP + by * 32 + li;
         const float* xb0 = s_x + (((pw0 / TW) * S) * C::HW + lh * S) * C::BXP + bx * 32 + li;
         float av[2], bv[2][C::NTAP];
@@ -269,8 +303,11 @@ Plan plan_cfg(const WgradArgs& a, int cus) {
     return p;
 }
 
-template <int R, int S, int BY, int BX, int TH, int TW>
+template <int R, int S, int BY, int BX, int TH, int TW, bool BF = false>
 void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
+    if constexpr (!BF) {
+        if (a.bf16) return launch_cfg<R, S, BY, BX, TH, TW, true>(ctx, a);
+    }
     using C = WCfg<R, S, BY, BX, TH, TW>;
     const Plan p = plan_cfg<R, S, BY, BX, TH, TW>(a, 256);
     const int nslabs = p.nsplit * p.wp;
@@ -281,7 +318,7 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
         RFI_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&wgrad_igemm_kernel<R, S, BY, BX, TH, TW>),
+            reinterpret_cast<const void*>(&wgrad_igemm_kernel<R, S, BY, BX, TH, TW, BF>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -291,9 +328,9 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
         if (ctx->profiling)
             label = "wgrad R" + std::to_string(R) + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
                     std::to_string(a.W) + " cx" + std::to_string(a.Cx) + " cy" + std::to_string(a.Cy) + " split" +
-                    std::to_string(p.nsplit);
+                    std::to_string(p.nsplit) + (BF ? " bf16" : "");
         ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0, label);
-        hipLaunchKernelGGL((wgrad_igemm_kernel<R, S, BY, BX, TH, TW>), grid, dim3(256), lds, ctx->stream, d);
+        hipLaunchKernelGGL((wgrad_igemm_kernel<R, S, BY, BX, TH, TW, BF>), grid, dim3(256), lds, ctx->stream, d);
         check_launch("wgrad_igemm");
     }
     launch_reduce_slabs(ctx, a.slab, nslabs, p.slab_stride, a.dw);

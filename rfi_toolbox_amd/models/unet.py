@@ -153,6 +153,17 @@ class HipSegmenter:
     def cuda(self, device=None):
         return self.to("cuda" if device is None else f"cuda:{device}")
 
+    def set_compute_dtype(self, dtype="float32"):
+        """``"float32"`` (default, parity-pinned) or ``"bfloat16"``: MFMA operands rounded to bf16 in
+        registers with float32 accumulation -- the mixed-precision mode the reference gets from
+        ``torch.autocast`` on a GPU (train_model.py:131,144).  Storage, BatchNorm, loss, Adam stay float32."""
+        code = {"float32": 0, "fp32": 0, "f32": 0, "bfloat16": 1, "bf16": 1}.get(str(dtype).replace("torch.", ""))
+        if code is None:
+            raise ValueError(f"compute dtype must be float32 or bfloat16, got {dtype!r}")
+        check(lib.rfi_model_set_compute_dtype(self._h, code))
+        self.compute_dtype = "bfloat16" if code else "float32"
+        return self
+
     # ---- mode
     def train(self, mode=True):
         self.training = bool(mode)

