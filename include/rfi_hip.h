@@ -249,7 +249,7 @@ int rfi_threshold_logits(rfi_ctx* ctx, const float* logits_dev, int64_t count, f
 
 /* ---- kernel-level entry points (device pointers only).  Used by the parity tests to
  *      check each HIP kernel against the oracle in isolation.  impl: 0 auto, 1 direct VALU,
- *      2 MFMA implicit GEMM. ---- */
+ *      2 MFMA implicit GEMM, 3 MFMA implicit GEMM with bfloat16 operands (the bf16 compute mode). ---- */
 int rfi_op_conv3x3(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
                    const float* w_oihw, const float* bias, int cout,
                    const float* in_scale, const float* in_shift, int in_relu, float* y);

@@ -531,6 +531,10 @@ bool conv_mfma_eligible(const ConvArgs& a) {
 }
 
 void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
+    if (impl == IMPL_MFMA_BF16) {
+        a.bf16 = true;
+        impl = IMPL_MFMA;
+    }
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "conv: empty shape");
     RFI_REQUIRE(a.x.pstride >= a.Cin && a.y.pstride >= a.Cout, "conv: pixel stride smaller than channels");
     RFI_REQUIRE(a.zgroups == 1 || (a.zgroups == 4 && a.R == 1), "conv: zgroups only for convT forward");

@@ -64,7 +64,7 @@ struct ConvArgs {
 #endif
 };
 
-enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2 };
+enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 3 };   // 3: MFMA kernel, bf16 operands
 
 bool conv_mfma_eligible(const ConvArgs& a);
 void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl = IMPL_AUTO);

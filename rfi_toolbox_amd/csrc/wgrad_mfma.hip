@@ -374,6 +374,7 @@ Plan dispatch(rfi_ctx* ctx, const WgradArgs& a, int what, int cus) {
 }  // namespace
 
 size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
+    if (impl == IMPL_MFMA_BF16) impl = IMPL_MFMA;
     size_t need = wgrad_direct_slab_floats(a);
     if (impl != IMPL_DIRECT && wgrad_mfma_eligible(a)) {
         const Plan p = dispatch(nullptr, a, SEL_PLAN, 256);
@@ -384,7 +385,12 @@ size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
     return need;
 }
 
-void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl) {
+void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
+    WgradArgs a = a_in;
+    if (impl == IMPL_MFMA_BF16) {
+        a.bf16 = true;
+        impl = IMPL_MFMA;
+    }
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cx > 0 && a.Cy > 0, "wgrad: empty shape");
     RFI_REQUIRE((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride < (int64_t)1 << 31 &&
                     (int64_t)a.N * a.H * a.W * a.yop.pstride < (int64_t)1 << 31,
