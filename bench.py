@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="patches per GPU per step")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--features", type=int, default=None)
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3"), default="f32",
                     help="f32: float32 MFMA, the parity-pinned path (default); bf16: MFMA operands rounded to "
                          "bfloat16 in registers, float32 accumulate/storage (the reference's autocast mode on a GPU)")
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -130,6 +130,8 @@ def main():
     model.train()
     if args.dtype == "bf16":
         model.set_compute_dtype("bfloat16")
+    elif args.dtype == "f32x3":
+        model.set_compute_dtype("float32_3xbf16")
     log("model built")
     B, S = args.batch, args.size
     # synthetic waterfalls -> views/tiling -> 3-channel patches + labels, generated and kept in HBM

@@ -46,11 +46,53 @@ __device__ __forceinline__ s16x4 pack_bf16(f32x4 x) {
     return __builtin_bit_cast(s16x4, r);
 }
 
+// ---- "3 x bf16" float32 emulation.  A float32 value is the exact sum of three bf16 pieces (8 + 8 + 8
+// significand bits): h = bf16(v), m = bf16(v - h), l = bf16(v - h - m).  A product a*b is then the sum of nine
+// piece products, each exact in the float32 accumulator; the three smallest (m*l, l*m, l*l <= 2^-24 |a b|) are
+// dropped, i.e. an error of the size of ONE float32 rounding per product.  Six v_mfma_f32_32x32x16_bf16
+// (32 cycles each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x the matrix-pipe
+// throughput at float32-level accuracy (tools/mfma_rate.hip: 142 vs 2425 TFLOP/s raw).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ unsigned cvt_pair(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pair(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = cvt_pair(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = cvt_pair(sa, sb);
+}
+__device__ __forceinline__ Split3 split3(f32x4 x0, f32x4 x1) {      // 8 consecutive k of one lane
+    unsigned h[4], m[4], l[4];
+    split_pair(x0.x, x0.y, h[0], m[0], l[0]);
+    split_pair(x0.z, x0.w, h[1], m[1], l[1]);
+    split_pair(x1.x, x1.y, h[2], m[2], l[2]);
+    split_pair(x1.z, x1.w, h[3], m[3], l[3]);
+    const u32x4 H = {h[0], h[1], h[2], h[3]}, M = {m[0], m[1], m[2], m[3]}, L = {l[0], l[1], l[2], l[3]};
+    return Split3{__builtin_bit_cast(bf16x8, H), __builtin_bit_cast(bf16x8, M), __builtin_bit_cast(bf16x8, L)};
+}
+__device__ __forceinline__ f32x16 mfma_3xbf16(const Split3& a, const Split3& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);      // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+    return acc;
+}
+
 constexpr int KC = 16;    // channels per K-chunk
 constexpr int KCP = 20;   // padded LDS row (floats)
 
-template <int R, int S, int TH, int TW, int BN, int WM, int WN>
+constexpr int HROW3 = 28;  // halo row of the 3 x bf16 path: [h 32 B | m 32 B | l 32 B | pad 16 B] = 112 B, conflict-free b128 reads
+
+template <int R, int S, int TH, int TW, int BN, int WM, int WN, int PREC = 0>
 struct Cfg {
+    static constexpr int HROW = PREC == 2 ? HROW3 : KCP;   // floats per halo-tile row
     static constexpr int BM = TH * TW;
     static constexpr int HH = TH * S + R - S;
     static constexpr int HW = TW * S + R - S;
@@ -60,7 +102,7 @@ struct Cfg {
     static constexpr int NTL = BN / WN / 32;      // 32-channel n-tiles per wave
     static constexpr int HALO_ITEMS = (HP * 4 + 255) / 256;
     static constexpr int W_ITEMS = (NTAP * BN * 4 + 255) / 256;
-    static constexpr int STAGE_FLOATS = HP * KCP + NTAP * BN * KCP;
+    static constexpr int STAGE_FLOATS = HP * HROW + NTAP * BN * KCP;
     static constexpr int EPI_FLOATS = 4 * 32 * 36;            // epilogue transpose scratch (4 waves)
     static constexpr int LDS_FLOATS0 = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
     static constexpr int LDS_FLOATS = (LDS_FLOATS0 + 1) & ~1;          // the fp64 statistics area follows, 8-byte aligned
@@ -73,12 +115,13 @@ struct Cfg {
 // BF: bf16 compute mode -- the SAME fp32 tiles in HBM and LDS; each lane's k-quad of an operand fragment is
 // rounded to bf16 in registers and ONE v_mfma_f32_32x32x8_bf16 (fp32 accumulate) replaces the four
 // fp32 32x32x2 MFMAs of that quad (identical k-to-lane mapping: lane half lh holds k = 4 lh .. 4 lh + 3).
-template <int R, int S, int TH, int TW, int BN, int WM, int WN, bool BF>
+// PREC: 0 float32 MFMA, 1 bf16 (above), 2 float32 emulated by 3 x bf16 (Split3 above)
+template <int R, int S, int TH, int TW, int BN, int WM, int WN, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
-    using C = Cfg<R, S, TH, TW, BN, WM, WN>;
+    using C = Cfg<R, S, TH, TW, BN, WM, WN, PREC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_halo = smem;
-    float* s_w = smem + C::HP * KCP;
+    float* s_w = smem + C::HP * C::HROW;
 
     // the conv kernels carry the dependent chain of the step; when a weight-gradient kernel of the side
     // stream shares the SIMD, the arbiter should prefer these waves
@@ -203,7 +246,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 if (a.xf.relu) v = __builtin_elementwise_max(v, v * a.xf.slope);
             }
             v = (((h_mask >> it) & 1u) && cv_l) ? v : zero;      // zero padding AFTER the transform
-            if (tid + it * 256 < C::HP * 4) *reinterpret_cast<f32x4*>(s_halo + lds_item0 + it * 64 * KCP) = v;
+            if constexpr (PREC == 2) {
+                // split ONCE per element here (each halo element feeds up to 9 taps): three bf16 planes per row
+                unsigned h0, m0, l0, h1, m1, l1;
+                split_pair(v.x, v.y, h0, m0, l0);
+                split_pair(v.z, v.w, h1, m1, l1);
+                if (tid + it * 256 < C::HP * 4) {
+                    float* row = s_halo + ((tid >> 2) + it * 64) * C::HROW + (tid & 3) * 2;   // 4 channels = 8 B per plane
+                    *reinterpret_cast<u32x2*>(row) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(row + 8) = u32x2{m0, m1};
+                    *reinterpret_cast<u32x2*>(row + 16) = u32x2{l0, l1};
+                }
+            } else {
+                if (tid + it * 256 < C::HP * 4) *reinterpret_cast<f32x4*>(s_halo + lds_item0 + it * 64 * KCP) = v;
+            }
         }
 #pragma unroll
         for (int it = 0; it < C::W_ITEMS; ++it) {
@@ -218,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     for (int mt = 0; mt < C::MT; ++mt) {
         const int p = (wm * C::MT + mt) * 32 + li;
         const int ty = p / TW, tx = p % TW;
-        a_base[mt] = ((ty * S) * C::HW + tx * S) * KCP + lh * 4;
+        a_base[mt] = ((ty * S) * C::HW + tx * S) * C::HROW + lh * 4;      // lh: k-quad (float32) / 8 bf16 of a plane (3 x bf16)
     }
     int b_base[C::NTL];
 #pragma unroll
@@ -266,6 +322,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
         issue_loads(lch * KC);                       // (the very last item is re-read once: harmless)
         RFI_T(t3);
+        if constexpr (PREC == 2) {
+            // one K = 16 group per tap: lane half lh holds channels 8 lh .. 8 lh + 7 of the 16-channel chunk row
+#pragma unroll
+            for (int tap = 0; tap < C::NTAP; ++tap) {
+                const int tr = tap / R, ts = tap % R;
+                Split3 bs[C::NTL];
+#pragma unroll
+                for (int nt = 0; nt < C::NTL; ++nt) {
+                    const float* bp = s_w + b_base[nt] + lh * 4 + tap * BN * KCP;
+                    bs[nt] = split3(*reinterpret_cast<const f32x4*>(bp), *reinterpret_cast<const f32x4*>(bp + 4));
+                }
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) {
+                    const float* ap = s_halo + a_base[mt] + (tr * C::HW + ts) * C::HROW;   // planes h | m | l, 8 floats apart
+                    const Split3 as{__builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ap)),
+                                    __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ap + 8)),
+                                    __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ap + 16))};
+#pragma unroll
+                    for (int nt = 0; nt < C::NTL; ++nt) acc[mt][nt] = mfma_3xbf16(as, bs[nt], acc[mt][nt]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int tap = 0; tap < C::NTAP; ++tap) {
             const int tr = tap / R, ts = tap % R;
@@ -275,11 +353,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt)
                     af[mt] = *reinterpret_cast<const f32x4*>(
-                        s_halo + a_base[mt] + (tr * C::HW + ts) * KCP + kb * 8);
+                        s_halo + a_base[mt] + (tr * C::HW + ts) * C::HROW + kb * 8);
 #pragma unroll
                 for (int nt = 0; nt < C::NTL; ++nt)
                     bf[nt] = *reinterpret_cast<const f32x4*>(s_w + b_base[nt] + tap * BN * KCP + kb * 8);
-                if constexpr (BF) {
+                if constexpr (PREC == 1) {
                     s16x4 ah[C::MT], bh[C::NTL];
 #pragma unroll
                     for (int mt = 0; mt < C::MT; ++mt) ah[mt] = pack_bf16(af[mt]);
@@ -301,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                                                                                   acc[mt][nt], 0, 0, 0);
                 }
             }
+        }
         }
         RFI_T(t4);
         __syncthreads();
@@ -431,12 +510,13 @@ static int occupancy_for(size_t lds_bytes) {
     return o < 1 ? 1 : (o > 3 ? 3 : o);   // VGPRs: <= 215 for the 72 KB tiles (2 waves/SIMD), <= 151 for the others (3)
 }
 
-template <int R, int S, int TH, int TW, int BN, int WM, int WN, bool BF = false>
+template <int R, int S, int TH, int TW, int BN, int WM, int WN, int PREC = 0>
 void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
-    if constexpr (!BF) {
-        if (a.bf16) return launch_cfg<R, S, TH, TW, BN, WM, WN, true>(ctx, a);
+    if constexpr (PREC == 0) {
+        if (a.bf16) return launch_cfg<R, S, TH, TW, BN, WM, WN, 1>(ctx, a);
+        if (a.bf16x3) return launch_cfg<R, S, TH, TW, BN, WM, WN, 2>(ctx, a);
     }
-    using C = Cfg<R, S, TH, TW, BN, WM, WN>;
+    using C = Cfg<R, S, TH, TW, BN, WM, WN, PREC>;
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
     const int ychunks = (int)cdiv(a.Cout, BN);
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + (size_t)C::STAT_DOUBLES * sizeof(double);
@@ -456,7 +536,7 @@ void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
         RFI_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, BF>),
+            reinterpret_cast<const void*>(&conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, PREC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -466,7 +546,7 @@ void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
         const size_t nw = (size_t)G * ychunks * a.zgroups * 32;
         RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&b.stamps), nw * 8));
         RFI_CHECK_HIP(hipMemsetAsync(b.stamps, 0, nw * 8, ctx->stream));
-        hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, BF>), grid, dim3(256), lds, ctx->stream, b);
+        hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, PREC>), grid, dim3(256), lds, ctx->stream, b);
         std::vector<unsigned long long> h(nw);
         RFI_CHECK_HIP(hipMemcpyAsync(h.data(), b.stamps, nw * 8, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -485,7 +565,7 @@ void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
         return;
     }
 #endif
-    hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, BF>), grid, dim3(256), lds, ctx->stream,
+    hipLaunchKernelGGL((conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, PREC>), grid, dim3(256), lds, ctx->stream,
                        a);
     check_launch("conv_igemm");
 }
@@ -500,10 +580,12 @@ void dispatch_tiles(rfi_ctx* ctx, ConvArgs& a) {
         return (int64_t)a.N * cdiv(a.H, th) * cdiv(a.W, tw) * ych >= 512;
     };
     if constexpr (S == 1) {          // (a stride-2 halo of the double tile would not fit the LDS)
+      if (!a.bf16x3) {               // (the 3 x bf16 halo planes of a double tile would leave one workgroup per CU)
         if (a.W >= 32 && a.Cout <= 32 && big_ok(16, 32, a.zgroups)) return launch_cfg<R, S, 16, 32, 32, 4, 1>(ctx, a);
         if (a.W >= 32 && a.Cout > 32 && big_ok(8, 32, ychunks64)) return launch_cfg<R, S, 8, 32, 64, 4, 1>(ctx, a);
         if (a.W >= 16 && a.W < 32 && a.Cout > 32 && big_ok(16, 16, ychunks64))
             return launch_cfg<R, S, 16, 16, 64, 4, 1>(ctx, a);
+      }
     }
     if (a.W >= 32) {
         if (a.Cout <= 32) launch_cfg<R, S, 8, 32, 32, 4, 1>(ctx, a);
@@ -535,6 +617,10 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
         a.bf16 = true;
         impl = IMPL_MFMA;
     }
+    if (impl == IMPL_MFMA_BF16X3) {
+        a.bf16x3 = true;
+        impl = IMPL_MFMA;
+    }
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "conv: empty shape");
     RFI_REQUIRE(a.x.pstride >= a.Cin && a.y.pstride >= a.Cout, "conv: pixel stride smaller than channels");
     RFI_REQUIRE(a.zgroups == 1 || (a.zgroups == 4 && a.R == 1), "conv: zgroups only for convT forward");
@@ -555,7 +641,7 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
         label = "conv R" + std::to_string(a.R) + "S" + std::to_string(a.S) + " N" + std::to_string(a.N) + " " +
                 std::to_string(a.H) + "x" + std::to_string(a.W) + " " + std::to_string(a.Cin) + "->" +
                 std::to_string(a.Cout) + (a.xf.scale ? " xf" : "") + (a.zgroups > 1 ? " z4" : "") +
-                (a.bf16 ? " bf16" : "");
+                (a.bf16 ? " bf16" : "") + (a.bf16x3 ? " 3xbf16" : "");
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0, label);
     if (a.R == 3) dispatch_tiles<3, 1>(ctx, a);
     else if (a.R == 1) dispatch_tiles<1, 1>(ctx, a);

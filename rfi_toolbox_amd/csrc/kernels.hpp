@@ -53,6 +53,7 @@ struct ConvArgs {
     InXform xf;
     double algo_flops = -1;           // algorithmic FLOPs for the profile (default: from the shape)
     bool bf16 = false;                // MFMA kernels: operands rounded to bf16 in registers, fp32 accumulate
+    bool bf16x3 = false;              // MFMA kernels: float32 operands split into 3 bf16 pieces, 6 bf16 MFMAs per K=16
     // optional: per-channel (sum, sumsq) of the OUTPUT in the epilogue (BatchNorm statistics).  in: stats
     // = [records][Cout][2] doubles with room for stats_max_records; out: stats_records = records written
     // (0 and stats = null when the launch could not provide them: direct kernel, unaligned output)
@@ -64,7 +65,7 @@ struct ConvArgs {
 #endif
 };
 
-enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 3 };   // 3: MFMA kernel, bf16 operands
+enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 3, IMPL_MFMA_BF16X3 = 4 };
 
 bool conv_mfma_eligible(const ConvArgs& a);
 void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl = IMPL_AUTO);
@@ -88,6 +89,7 @@ struct WgradArgs {
     size_t slab_floats = 0;
     double algo_flops = -1;
     bool bf16 = false;                // MFMA kernel: operands rounded to bf16 in registers, fp32 accumulate
+    bool bf16x3 = false;              // MFMA kernel: float32 emulated by 3 x bf16 pieces
 };
 size_t wgrad_slab_floats(const WgradArgs& a, int impl);
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);

@@ -347,6 +347,7 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
         a.stats_max_records = (int)(bn_stats_ws_floats(c.cout) / ((size_t)c.cout * 4));
     }
     a.bf16 = m->compute_bf16;
+    a.bf16x3 = m->compute_x3;
     launch_conv(m->ctx, a);
     const int64_t M = (int64_t)s.N * s.H * s.W;
     if (train) {
@@ -416,6 +417,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         a.zgroups = 4;
         a.xf = bn_xf(*prevBN);
         a.bf16 = compute_bf16;
+    a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
         ConvBN& c1 = convs[2 * D + 2 + 2 * k];
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
@@ -496,6 +498,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
     wa.slab_floats = m->bufs[m->ws_slab].n;
     m->side_begin();
     wa.bf16 = m->compute_bf16;
+    wa.bf16x3 = m->compute_x3;
     launch_wgrad(ctx, wa);
     m->side_end();
     if (dx) {
@@ -509,6 +512,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
         a.Hout = s.H; a.Wout = s.W;
         a.R = 3; a.S = 1; a.pad = 1;
         a.bf16 = m->compute_bf16;
+    a.bf16x3 = m->compute_x3;
         launch_conv(ctx, a);
     }
 }
@@ -561,6 +565,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         wa.slab_floats = bufs[ws_slab].n;
         side_begin();
         wa.bf16 = compute_bf16;
+    wa.bf16x3 = compute_x3;
         launch_wgrad(ctx, wa);
         side_end();
         ConvArgs a;
@@ -574,6 +579,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         a.Hout = sin.H; a.Wout = sin.W;
         a.R = 2; a.S = 2; a.pad = 0;
         a.bf16 = compute_bf16;
+    a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
     }
     // bottleneck

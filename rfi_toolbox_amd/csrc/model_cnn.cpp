@@ -156,10 +156,12 @@ void rfi_model::forward_cnn3(const float* x_dev, int n, int h, int w) {
     ConvArgs a1 = conv3x3(c1, x, InXform{}, params + c1.w_off, params + c1.b_off, buf(cY1), c1.cin_p, c1.cout,
                           n, h, w);
     a1.bf16 = compute_bf16;
+    a1.bf16x3 = compute_x3;
     launch_conv(ctx, a1);
     ConvArgs a2 = conv3x3(c2, View{buf(cY1), c1.cout}, relu_xf(c1), params + c2.w_off, params + c2.b_off,
                           buf(cY2), c2.cin_p, c2.cout, n, h, w);
     a2.bf16 = compute_bf16;
+    a2.bf16x3 = compute_x3;
     launch_conv(ctx, a2);
     launch_head_fwd(ctx, buf(cY2), (int64_t)n * h * w, feat, c2.scale(), c2.shift(), params + head_w_off,
                     params + head_b_off, out_ch, buf(logits));
@@ -192,11 +194,13 @@ void rfi_model::backward_cnn3(const float* x_dev, const uint8_t* labels_dev, int
         wa.slab_floats = bufs[ws_slab].n;
         side_begin();                      // wgrad on the side stream, next to the dgrad / ReLU chain
         wa.bf16 = compute_bf16;
+    wa.bf16x3 = compute_x3;
         launch_wgrad(ctx, wa);
         side_end();
         if (dx) {
             ConvArgs a = conv3x3(c, View{dA, c.cout}, InXform{}, c.wd, nullptr, dx, c.cout, c.cin, n, h, w);
             a.bf16 = compute_bf16;
+    a.bf16x3 = compute_x3;
             launch_conv(ctx, a);
         }
     };

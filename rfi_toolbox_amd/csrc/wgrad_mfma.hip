@@ -374,7 +374,7 @@ Plan dispatch(rfi_ctx* ctx, const WgradArgs& a, int what, int cus) {
 }  // namespace
 
 size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
-    if (impl == IMPL_MFMA_BF16) impl = IMPL_MFMA;
+    if (impl == IMPL_MFMA_BF16 || impl == IMPL_MFMA_BF16X3) impl = IMPL_MFMA;
     size_t need = wgrad_direct_slab_floats(a);
     if (impl != IMPL_DIRECT && wgrad_mfma_eligible(a)) {
         const Plan p = dispatch(nullptr, a, SEL_PLAN, 256);
@@ -391,6 +391,7 @@ void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
         a.bf16 = true;
         impl = IMPL_MFMA;
     }
+    if (impl == IMPL_MFMA_BF16X3) impl = IMPL_MFMA;     // (no 3 x bf16 wgrad yet: float32 MFMA)
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cx > 0 && a.Cy > 0, "wgrad: empty shape");
     RFI_REQUIRE((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride < (int64_t)1 << 31 &&
                     (int64_t)a.N * a.H * a.W * a.yop.pstride < (int64_t)1 << 31,

@@ -157,11 +157,12 @@ class HipSegmenter:
         """``"float32"`` (default, parity-pinned) or ``"bfloat16"``: MFMA operands rounded to bf16 in
         registers with float32 accumulation -- the mixed-precision mode the reference gets from
         ``torch.autocast`` on a GPU (train_model.py:131,144).  Storage, BatchNorm, loss, Adam stay float32."""
-        code = {"float32": 0, "fp32": 0, "f32": 0, "bfloat16": 1, "bf16": 1}.get(str(dtype).replace("torch.", ""))
+        code = {"float32": 0, "fp32": 0, "f32": 0, "bfloat16": 1, "bf16": 1, "float32_3xbf16": 2, "3xbf16": 2,
+                "bf16x3": 2}.get(str(dtype).replace("torch.", ""))
         if code is None:
-            raise ValueError(f"compute dtype must be float32 or bfloat16, got {dtype!r}")
+            raise ValueError(f"compute dtype must be float32, bfloat16 or float32_3xbf16, got {dtype!r}")
         check(lib.rfi_model_set_compute_dtype(self._h, code))
-        self.compute_dtype = "bfloat16" if code else "float32"
+        self.compute_dtype = ("float32", "bfloat16", "float32_3xbf16")[code]
         return self
 
     # ---- mode

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One conv layer in a loop (GPU box): timing, or a target for `rocprofv3 --pmc` passes.
-usage: bench_conv.py N H W CIN COUT [fwd|wgrad] [reps]"""
+usage: bench_conv.py N H W CIN COUT [fwd|wgrad] [reps] [impl: 0 auto, 2 f32 MFMA, 3 bf16, 4 3xbf16]"""
 import ctypes as C
 import sys
 
@@ -13,6 +13,7 @@ from rfi_toolbox_amd.runtime import Context  # noqa: E402
 n, h, w, cin, cout = [int(v) for v in sys.argv[1:6]]
 what = sys.argv[6] if len(sys.argv) > 6 else "fwd"
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
+impl = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 ctx = Context.get(0)
 rng = np.random.default_rng(0)
 x = ctx.to_device(rng.standard_normal((n, h, w, cin), dtype=np.float32))
@@ -28,9 +29,9 @@ P = lambda a: C.c_void_p(a.ptr)  # noqa: E731
 
 def run():
     if what == "fwd":
-        check(lib.rfi_op_conv3x3(ctx.handle, 0, P(x), n, h, w, cin, P(wt), P(b), cout, P(sc), P(sh), 1, P(y)))
+        check(lib.rfi_op_conv3x3(ctx.handle, impl, P(x), n, h, w, cin, P(wt), P(b), cout, P(sc), P(sh), 1, P(y)))
     else:
-        check(lib.rfi_op_conv3x3_wgrad(ctx.handle, 0, P(x), P(dy), n, h, w, cin, cout, P(sc), P(sh), 1, P(gw)))
+        check(lib.rfi_op_conv3x3_wgrad(ctx.handle, impl, P(x), P(dy), n, h, w, cin, cout, P(sc), P(sh), 1, P(gw)))
 
 
 for _ in range(3):
