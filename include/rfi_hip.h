@@ -87,10 +87,15 @@ int rfi_model_destroy(rfi_model* m);
  * (forward returns sigmoid(logits), :196; the training step then applies BCE-with-logits + dice to THAT
  * output, as scripts/train_model.py:120,146 does with whatever the model returns). */
 int rfi_model_set_activation(rfi_model* m, float negative_slope);
-/* arithmetic of the conv / transposed-conv / weight-gradient contractions: 0 = float32 MFMA (default; the
- * parity-pinned path), 1 = operands rounded to bfloat16 (RNE) in registers, float32 accumulate -- the
- * mixed-precision mode the reference gets from torch.autocast on a GPU (scripts/train_model.py:131,144).
- * Tensors in HBM, BatchNorm, loss and the optimiser stay float32 in both modes. */
+/* arithmetic of the conv / transposed-conv / weight-gradient contractions (tensors in HBM, BatchNorm,
+ * loss and the optimiser are float32 in every mode):
+ *   2 (default) float32 by splitting: every float32 operand is the exact sum of three bfloat16 pieces and a
+ *     product block is six v_mfma_f32_32x32x16_bf16 (float32 accumulate; the three piece products below
+ *     2^-24 of the product are dropped).  Error against float64 is that of the native float32 MFMA path
+ *     (tests/test_gpu_ops.py runs both against the same tolerances), at 2.7x its matrix-pipe rate.
+ *   0 native float32 MFMA (v_mfma_f32_32x32x2_f32, an exact fmaf chain).
+ *   1 bfloat16: operands rounded to bfloat16 (RNE), float32 accumulate -- the mixed precision the
+ *     reference gets from torch.autocast on a GPU (scripts/train_model.py:131,144). */
 int rfi_model_set_compute_dtype(rfi_model* m, int dtype);
 int rfi_model_set_head_sigmoid(rfi_model* m, int enabled);
 /* deterministic init with torch's default distributions (kaiming-uniform(a=sqrt5) conv

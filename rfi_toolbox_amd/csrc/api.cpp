@@ -542,8 +542,8 @@ int rfi_model_set_activation(rfi_model* m, float negative_slope) {
 }
 int rfi_model_set_compute_dtype(rfi_model* m, int dtype) {
     return guarded([&] {
-        RFI_REQUIRE(dtype >= 0 && dtype <= 2, "set_compute_dtype: 0 (float32 MFMA), 1 (bfloat16 operands) or "
-                                              "2 (float32 emulated by 3 x bfloat16)");
+        RFI_REQUIRE(dtype >= 0 && dtype <= 2, "set_compute_dtype: 0 (native float32 MFMA), 1 (bfloat16 operands) or "
+                                              "2 (float32 by 3 x bfloat16 splitting, the default)");
         m->compute_bf16 = dtype == 1;
         m->compute_x3 = dtype == 2;
     });

@@ -17,6 +17,7 @@
 #include "model.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <random>
 
 using namespace rfi;
@@ -53,6 +54,10 @@ rfi_model::~rfi_model() {
 
 // ------------------------------------------------------------------------------------ build
 void rfi_model::build() {
+    if (const char* e = getenv("RFI_COMPUTE")) {      // arithmetic of new models: f32 (default) | f32mfma | bf16
+        compute_bf16 = std::string(e) == "bf16";
+        compute_x3 = std::string(e) == "f32" || std::string(e) == "f32x3";
+    }
     if (arch == 1) return build_cnn3();
     RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
     RFI_REQUIRE(depth >= 1 && depth <= 6, "UNet: depth must be in [1,6]");

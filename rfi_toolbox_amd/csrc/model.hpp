@@ -66,7 +66,7 @@ struct rfi_model {
     bool training = true;
     float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
     bool compute_bf16 = false;        // conv / wgrad MFMAs on bf16-rounded operands (fp32 storage + accumulate)
-    bool compute_x3 = false;          // float32 contractions emulated by 3 x bf16 pieces (float32-level accuracy)
+    bool compute_x3 = true;           // DEFAULT: float32 contractions by 3 x bf16 pieces (float32-level accuracy)
     bool head_sigmoid = false;        // UNetOverfit: forward returns sigmoid(logits); the loss sees that too
     int probs = -1;                   // buffer index of sigmoid(logits) when head_sigmoid
 

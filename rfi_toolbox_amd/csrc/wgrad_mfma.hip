@@ -26,6 +26,38 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// float32 emulated by three bf16 pieces (see conv_mfma.hip): h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ unsigned cvt_pair(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pair(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = cvt_pair(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = cvt_pair(sa, sb);
+}
+__device__ __forceinline__ Split3 split8(const float (&v)[8]) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+    const u32x4 H = {h[0], h[1], h[2], h[3]}, M = {m[0], m[1], m[2], m[3]}, L = {l[0], l[1], l[2], l[3]};
+    return Split3{__builtin_bit_cast(bf16x8, H), __builtin_bit_cast(bf16x8, M), __builtin_bit_cast(bf16x8, L)};
+}
+__device__ __forceinline__ f32x16 mfma_3xbf16(const Split3& a, const Split3& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);      // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+    return acc;
+}
+
 __device__ __forceinline__ s16x4 pack_bf16(float a, float b, float c, float d) {   // RNE, 2 x v_cvt_pk_bf16_f32
     const f32x2 lo = {a, b}, hi = {c, d};
     u32x2 r;
@@ -64,7 +96,9 @@ struct WgradDev {
 // BF: bf16 compute mode -- same fp32 tiles in LDS; a lane gathers its channel's values of 4 consecutive
 // pixels (lane half lh: pixels 4 lh .. 4 lh + 3 of an 8-pixel tile row), rounds them to bf16 and ONE
 // v_mfma_f32_32x32x8_bf16 per tap (fp32 accumulate) covers the 8 pixels four fp32 k-steps covered.
-template <int R, int S, int BY, int BX, int TH, int TW, bool BF>
+// PREC: 0 float32 MFMA, 1 bf16 operands, 2 float32 emulated by 3 x bf16 pieces (lane half lh takes one whole
+// 8-pixel tile row; six v_mfma_f32_32x32x16_bf16 per tap and 16 pixels)
+template <int R, int S, int BY, int BX, int TH, int TW, int PREC>
 __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
     using C = WCfg<R, S, BY, BX, TH, TW>;
     const WgradArgs& a = d.a;
@@ -193,7 +227,29 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradDev d) {
         // previous k-step still occupies the pipe.
         static_assert((C::BM / C::WP) % TW == 0 && TW % 2 == 0, "a wave's pixels must start on a tile row");
         const int pw0 = ps * C::KSTEPS * 2;                          // first pixel of this wave
-        if constexpr (BF) {
+        if constexpr (PREC == 2) {
+            static_assert(TW == 8 && (C::KSTEPS % 8) == 0, "3 x bf16 path: pairs of 8-pixel tile rows per wave");
+            const float* yr = s_y + (pw0 + lh * 8) * C::BYP + by * 32 + li;
+            const float* xr0 = s_x + (((pw0 / TW + lh) * S) * C::HW) * C::BXP + bx * 32 + li;
+#pragma unroll
+            for (int g = 0; g < C::KSTEPS / 8; ++g) {                  // two tile rows (16 pixels) per group
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = yr[(g * 16 + t) * C::BYP];
+                const Split3 a3 = split8(v);
+                const float* xr = xr0 + (g * 2 * S) * C::HW * C::BXP;
+#pragma unroll
+                for (int tap = 0; tap < C::NTAP; ++tap) {
+                    const float* xp = xr + ((tap / R) * C::HW + (tap % R)) * C::BXP;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] = xp[t * S * C::BXP];
+                    acc[tap] = mfma_3xbf16(a3, split8(v), acc[tap]);
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+        if constexpr (PREC == 1) {
             static_assert(TW == 8 && (C::KSTEPS % 4) == 0, "bf16 path: 8-pixel tile rows, whole rows per wave");
             const float* ya4 = s_y + (pw0 + lh * 4) * C::BYP + by * 32 + li;
             const float* xb4 = s_x + (((pw0 / TW) * S) * C::HW + lh * 4 * S) * C::BXP + bx * 32 + li;
@@ -303,10 +359,13 @@ Plan plan_cfg(const WgradArgs& a, int cus) {
     return p;
 }
 
-template <int R, int S, int BY, int BX, int TH, int TW, bool BF = false>
+template <int R, int S, int BY, int BX, int TH, int TW, int PREC = 0>
 void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
-    if constexpr (!BF) {
-        if (a.bf16) return launch_cfg<R, S, BY, BX, TH, TW, true>(ctx, a);
+    if constexpr (PREC == 0) {
+        if (a.bf16) return launch_cfg<R, S, BY, BX, TH, TW, 1>(ctx, a);
+        if constexpr (WCfg<R, S, BY, BX, TH, TW>::KSTEPS % 8 == 0) {
+            if (a.bf16x3) return launch_cfg<R, S, BY, BX, TH, TW, 2>(ctx, a);
+        }
     }
     using C = WCfg<R, S, BY, BX, TH, TW>;
     const Plan p = plan_cfg<R, S, BY, BX, TH, TW>(a, 256);
@@ -318,7 +377,7 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
         RFI_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&wgrad_igemm_kernel<R, S, BY, BX, TH, TW, BF>),
+            reinterpret_cast<const void*>(&wgrad_igemm_kernel<R, S, BY, BX, TH, TW, PREC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -328,9 +387,9 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
         if (ctx->profiling)
             label = "wgrad R" + std::to_string(R) + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
                     std::to_string(a.W) + " cx" + std::to_string(a.Cx) + " cy" + std::to_string(a.Cy) + " split" +
-                    std::to_string(p.nsplit) + (BF ? " bf16" : "");
+                    std::to_string(p.nsplit) + (PREC == 1 ? " bf16" : (PREC == 2 ? " 3xbf16" : ""));
         ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0, label);
-        hipLaunchKernelGGL((wgrad_igemm_kernel<R, S, BY, BX, TH, TW, BF>), grid, dim3(256), lds, ctx->stream, d);
+        hipLaunchKernelGGL((wgrad_igemm_kernel<R, S, BY, BX, TH, TW, PREC>), grid, dim3(256), lds, ctx->stream, d);
         check_launch("wgrad_igemm");
     }
     launch_reduce_slabs(ctx, a.slab, nslabs, p.slab_stride, a.dw);
@@ -391,7 +450,10 @@ void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
         a.bf16 = true;
         impl = IMPL_MFMA;
     }
-    if (impl == IMPL_MFMA_BF16X3) impl = IMPL_MFMA;     // (no 3 x bf16 wgrad yet: float32 MFMA)
+    if (impl == IMPL_MFMA_BF16X3) {
+        a.bf16x3 = true;
+        impl = IMPL_MFMA;
+    }
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cx > 0 && a.Cy > 0, "wgrad: empty shape");
     RFI_REQUIRE((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride < (int64_t)1 << 31 &&
                     (int64_t)a.N * a.H * a.W * a.yop.pstride < (int64_t)1 << 31,

@@ -1,4 +1,5 @@
-"""-m gpu: every HIP conv-like kernel (direct VALU and MFMA implicit GEMM) against torch-CPU fp32
+"""-m gpu: every HIP conv-like kernel (direct VALU, MFMA implicit GEMM in native float32 and in the default
+float32-by-3xbf16 arithmetic) against torch-CPU fp32
 (F.conv2d / F.conv_transpose2d + autograd, the substrate the reference runs on) on seeded inputs.
 Tolerance: fp32 path, relative max error <= 2e-5 of the output scale (fp32 MFMA is an exact fmaf
 chain; the difference is summation order only)."""
@@ -19,8 +20,11 @@ CONV_SHAPES = [
 ]
 
 
+IMPL_X3 = 4       # MFMA kernel, float32 by 3 x bf16 splitting (the default arithmetic of the models)
+
+
 def _impls(cin):
-    return [IMPL_DIRECT, IMPL_MFMA] if cin % 4 == 0 else [IMPL_DIRECT]
+    return [IMPL_DIRECT, IMPL_MFMA, IMPL_X3] if cin % 4 == 0 else [IMPL_DIRECT]
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
@@ -76,7 +80,7 @@ def test_conv3x3_wgrad_with_load_transform():
     c = ctx()
     dx, ddy, dsc, dsh = (c.to_device(nhwc(x)), c.to_device(nhwc(dy)), c.to_device(sc.numpy()),
                          c.to_device(sh.numpy()))      # keep the device buffers alive across the calls
-    for impl in (IMPL_DIRECT, IMPL_MFMA):
+    for impl in (IMPL_DIRECT, IMPL_MFMA, IMPL_X3):
         gw = c.empty((cout, cin, 3, 3))
         check(lib.rfi_op_conv3x3_wgrad(c.handle, impl, P(dx), P(ddy), n, h, w, cin, cout, P(dsc), P(dsh), 1, P(gw)))
         assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, f"impl={impl}"
@@ -99,7 +103,7 @@ def test_convt2x2_all(shape):
     c = ctx()
     dx, dw, db, ddy = (c.to_device(nhwc(x.detach())), c.to_device(wt.detach().numpy()), c.to_device(b.numpy()),
                        c.to_device(nhwc(dy)))
-    for impl in (IMPL_DIRECT, IMPL_MFMA):
+    for impl in (IMPL_DIRECT, IMPL_MFMA, IMPL_X3) if cin % 4 == 0 and cout % 4 == 0 else (IMPL_DIRECT,):
         out = c.empty((n, 2 * h, 2 * w, cout))
         check(lib.rfi_op_convt2x2(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout, P(out)))
         assert rel_err(out.numpy(), nhwc(y.detach())) <= TOL, f"fwd impl={impl}"
