@@ -418,6 +418,7 @@ int rfi_model_init(rfi_model* m, uint64_t seed) {
         RFI_CHECK_HIP(hipMemsetAsync(m->adam_v, 0, m->n_flat * sizeof(float), m->ctx->stream));
         m->adam_step = 0;
         m->wd_dirty = true;
+        m->x3_fresh = false;
     });
 }
 
@@ -465,6 +466,7 @@ int rfi_model_load_entry(rfi_model* m, const char* name, const void* host, size_
         else tmp.assign(src, src + e.numel());
         upload(m, m->params + flat_offset(m, e), tmp.data(), tmp.size());
         m->wd_dirty = true;
+        m->x3_fresh = false;
     });
 }
 

@@ -88,6 +88,7 @@ __device__ __forceinline__ f32x16 mfma_3xbf16(const Split3& a, const Split3& b, 
 constexpr int KC = 16;    // channels per K-chunk
 constexpr int KCP = 20;   // padded LDS row (floats)
 
+constexpr int WROW3 = 24;  // filter row of the 3 x bf16 path: [h 32 B | m 32 B | l 32 B], pre-split in HBM (ConvArgs::w3)
 constexpr int HROW3 = 28;  // halo row of the 3 x bf16 path: [h 32 B | m 32 B | l 32 B | pad 16 B] = 112 B, conflict-free b128 reads
 
 template <int R, int S, int TH, int TW, int BN, int WM, int WN, int PREC = 0>
@@ -101,8 +102,10 @@ struct Cfg {
     static constexpr int MT = BM / WM / 32;       // 32-pixel m-tiles per wave
     static constexpr int NTL = BN / WN / 32;      // 32-channel n-tiles per wave
     static constexpr int HALO_ITEMS = (HP * 4 + 255) / 256;
-    static constexpr int W_ITEMS = (NTAP * BN * 4 + 255) / 256;
-    static constexpr int STAGE_FLOATS = HP * HROW + NTAP * BN * KCP;
+    static constexpr int W_ITEMS = (NTAP * BN * (PREC == 2 ? 6 : 4) + 255) / 256;
+    static constexpr int WROW = PREC == 2 ? WROW3 : KCP;   // floats per filter-tile row
+    static constexpr int WQ = PREC == 2 ? 6 : 4;           // float4 pieces per filter row (3 x bf16: h | m | l of 16 channels)
+    static constexpr int STAGE_FLOATS = HP * HROW + NTAP * BN * WROW;
     static constexpr int EPI_FLOATS = 4 * 32 * 36;            // epilogue transpose scratch (4 waves)
     static constexpr int LDS_FLOATS0 = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
     static constexpr int LDS_FLOATS = (LDS_FLOATS0 + 1) & ~1;          // the fp64 statistics area follows, 8-byte aligned
@@ -160,7 +163,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     if (st_out)
         for (int i = tid; i < C::STAT_DOUBLES; i += 256) s_stat[i] = 0.0;   // visible after the first barrier below
     const int z = blockIdx.z;
-    const float* __restrict__ wbase = a.w + (a.zgroups > 1 ? (size_t)z * a.Cout * a.Cin : 0);
+    const float* __restrict__ wbase =
+        PREC == 2 ? a.w3 + (a.zgroups > 1 ? (size_t)z * a.Cout * ((a.Cin + KC - 1) / KC) * WROW3 : 0)
+                  : a.w + (a.zgroups > 1 ? (size_t)z * a.Cout * a.Cin : 0);
     const int ooy = a.zgroups > 1 ? (z >> 1) : a.ooy;
     const int oox = a.zgroups > 1 ? (z & 1) : a.oox;
     const int q4 = (tid & 3) * 4;                    // channel offset of this thread's float4 in a chunk
@@ -175,14 +180,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < C::HALO_ITEMS; ++it) h_off[it] = 0;
     int w_off[C::W_ITEMS];
+    const int nchunks_w = (a.Cin + KC - 1) / KC;      // 3 x bf16: records of 24 floats per (tap, cout, chunk)
 #pragma unroll
     for (int it = 0; it < C::W_ITEMS; ++it) {
         const int idx = tid + it * 256;
-        const int row = idx >> 2, q = idx & 3;       // row = tap*BN + nloc
+        const int row = idx / C::WQ, q = idx % C::WQ;       // row = tap*BN + nloc
         w_off[it] = -1;
-        if (idx < C::NTAP * BN * 4) {
+        if (idx < C::NTAP * BN * C::WQ) {
             const int tap = row / BN, nloc = row % BN;
-            if (n0 + nloc < a.Cout) w_off[it] = (tap * a.Cout + n0 + nloc) * a.Cin + q * 4;
+            if (n0 + nloc < a.Cout) {
+                if constexpr (PREC == 2) w_off[it] = ((tap * a.Cout + n0 + nloc) * nchunks_w) * WROW3 + q * 4;
+                else w_off[it] = (tap * a.Cout + n0 + nloc) * a.Cin + q * 4;
+            }
         }
     }
     const int lds_item0 = (tid >> 2) * KCP + (tid & 3) * 4;   // LDS float offset of item 0; item it: + it*64*KCP
@@ -232,8 +241,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             hreg[it] = *reinterpret_cast<const f32x4*>(
                 a.x.p + (unsigned)((((h_mask >> it) & 1u) && cv_l) ? h_off[it] + cc : 0));   // never past the tensor
 #pragma unroll
-        for (int it = 0; it < C::W_ITEMS; ++it)
-            wreg[it] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)((w_off[it] >= 0 && cv_l) ? w_off[it] + cc : 0));
+        for (int it = 0; it < C::W_ITEMS; ++it) {
+            if constexpr (PREC == 2)     // pre-split records: chunk c0/16 of the row, always in range (zero padded)
+                wreg[it] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)(w_off[it] >= 0 ? w_off[it] + (c0 / KC) * WROW3 : 0));
+            else
+                wreg[it] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)((w_off[it] >= 0 && cv_l) ? w_off[it] + cc : 0));
+        }
     };
     auto store_chunk = [&]() {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -263,8 +276,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < C::W_ITEMS; ++it) {
-            const f32x4 v = (w_off[it] >= 0 && cv_l) ? wreg[it] : zero;
-            if (tid + it * 256 < C::NTAP * BN * 4) *reinterpret_cast<f32x4*>(s_w + lds_item0 + it * 64 * KCP) = v;
+            if constexpr (PREC == 2) {      // 6 float4 pieces per 96-byte row: item idx -> row idx/6, piece idx%6
+                const int idx = tid + it * 256;
+                const f32x4 v = w_off[it] >= 0 ? wreg[it] : zero;
+                if (idx < C::NTAP * BN * 6) *reinterpret_cast<f32x4*>(s_w + (idx / 6) * WROW3 + (idx % 6) * 4) = v;
+            } else {
+                const f32x4 v = (w_off[it] >= 0 && cv_l) ? wreg[it] : zero;
+                if (tid + it * 256 < C::NTAP * BN * 4) *reinterpret_cast<f32x4*>(s_w + lds_item0 + it * 64 * KCP) = v;
+            }
         }
     };
 
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     int b_base[C::NTL];
 #pragma unroll
     for (int nt = 0; nt < C::NTL; ++nt)
-        b_base[nt] = (wn * (BN / WN) + nt * 32 + li) * KCP + lh * 4;
+        b_base[nt] = (wn * (BN / WN) + nt * 32 + li) * C::WROW + lh * 4;
 
     f32x16 acc[C::MT][C::NTL];
 #pragma unroll
@@ -330,8 +349,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 Split3 bs[C::NTL];
 #pragma unroll
                 for (int nt = 0; nt < C::NTL; ++nt) {
-                    const float* bp = s_w + b_base[nt] + lh * 4 + tap * BN * KCP;
-                    bs[nt] = split3(*reinterpret_cast<const f32x4*>(bp), *reinterpret_cast<const f32x4*>(bp + 4));
+                    const float* bp = s_w + b_base[nt] + tap * BN * WROW3;        // planes h | m | l, 8 floats apart
+                    bs[nt] = Split3{__builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(bp)),
+                                    __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(bp + 8)),
+                                    __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(bp + 16))};
                 }
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt) {
@@ -601,6 +622,68 @@ void dispatch_tiles(rfi_ctx* ctx, ConvArgs& a) {
 
 }  // namespace
 
+size_t weights_x3_floats(int taps, int Cout, int Cin) {
+    return (size_t)taps * Cout * ((Cin + KC - 1) / KC) * WROW3;
+}
+namespace {
+// w [taps][Cout][Cin] float32 -> records [taps][Cout][chunk][h16 | m16 | l16] bf16 (zero beyond Cin)
+__global__ void weights_to_x3_kernel(const float* __restrict__ w, int64_t rows, int Cin, int nchunks,
+                                     float* __restrict__ out) {
+    const int64_t total = rows * nchunks * 4;                    // one thread per 4 channels
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 3);
+        const int64_t rc = i >> 2;
+        const int chunk = (int)(rc % nchunks);
+        const int64_t row = rc / nchunks;
+        const int c = chunk * KC + q * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < Cin) v = *reinterpret_cast<const f32x4*>(w + row * Cin + c);      // Cin % 4 == 0
+        unsigned h0, m0, l0, h1, m1, l1;
+        split_pair(v.x, v.y, h0, m0, l0);
+        split_pair(v.z, v.w, h1, m1, l1);
+        float* rec = out + rc * WROW3 + q * 2;
+        *reinterpret_cast<u32x2*>(rec) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(rec + 8) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(rec + 16) = u32x2{l0, l1};
+    }
+}
+// the same for MANY filter tensors in one launch (all layers, both layouts, once per optimiser step)
+__global__ void weights_to_x3_batched_kernel(const X3Desc* __restrict__ descs) {
+    const X3Desc d = descs[blockIdx.y];
+    const int64_t total = d.rows * d.nchunks * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 3);
+        const int64_t rc = i >> 2;
+        const int chunk = (int)(rc % d.nchunks);
+        const int64_t row = rc / d.nchunks;
+        const int c = chunk * KC + q * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < d.Cin) v = *reinterpret_cast<const f32x4*>(d.src + row * d.Cin + c);
+        unsigned h0, m0, l0, h1, m1, l1;
+        split_pair(v.x, v.y, h0, m0, l0);
+        split_pair(v.z, v.w, h1, m1, l1);
+        float* rec = d.dst + rc * WROW3 + q * 2;
+        *reinterpret_cast<u32x2*>(rec) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(rec + 8) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(rec + 16) = u32x2{l0, l1};
+    }
+}
+}  // namespace
+void launch_weights_to_x3_batched(rfi_ctx* ctx, const X3Desc* descs_dev, int n, double total_bytes) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, total_bytes);
+    hipLaunchKernelGGL(weights_to_x3_batched_kernel, dim3(128, n), dim3(256), 0, ctx->stream, descs_dev);
+    check_launch("weights_to_x3_batched");
+}
+void launch_weights_to_x3(rfi_ctx* ctx, const float* w, int taps, int Cout, int Cin, float* out) {
+    const int nchunks = (Cin + KC - 1) / KC;
+    const int64_t rows = (int64_t)taps * Cout, total = rows * nchunks * 4;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)rows * Cin * 4 + (double)rows * nchunks * 96);
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(weights_to_x3_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w, rows, Cin, nchunks, out);
+    check_launch("weights_to_x3");
+}
+
 bool conv_mfma_eligible(const ConvArgs& a) {
     if (a.Cin % 4 != 0 || a.x.pstride % 4 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(a.x.p) & 15) || (reinterpret_cast<uintptr_t>(a.w) & 15)) return false;
@@ -634,6 +717,25 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
         launch_conv_direct(ctx, a);
         return;
     }
+    // 3 x bf16: the filters are read pre-split (ConvArgs::w3); callers that only have float32 weights (the
+    // kernel-level API) get a temporary split copy
+    float* tmp_w3 = nullptr;
+    if (a.bf16x3 && !a.w3) {
+        const int taps = a.R * a.R * a.zgroups;
+        tmp_w3 = static_cast<float*>(ctx->alloc(weights_x3_floats(taps, a.Cout, a.Cin) * sizeof(float)));
+        launch_weights_to_x3(ctx, a.w, taps, a.Cout, a.Cin, tmp_w3);
+        a.w3 = tmp_w3;
+    }
+    struct FreeTmp {
+        rfi_ctx* c; float* p; ConvArgs& a;
+        ~FreeTmp() {
+            if (p) {
+                (void)hipStreamSynchronize(c->stream);
+                try { c->release(p); } catch (...) {}
+                a.w3 = nullptr;
+            }
+        }
+    } free_tmp{ctx, tmp_w3, a};
     const double flops = a.algo_flops >= 0 ? a.algo_flops
                                            : 2.0 * a.N * a.H * a.W * (double)a.Cout * a.R * a.R * a.Cin * a.zgroups;
     std::string label;

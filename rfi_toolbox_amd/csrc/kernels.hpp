@@ -43,6 +43,7 @@ struct ConvArgs {
     int Hin = 0, Win = 0;             // input spatial size
     int Cin = 0, Cout = 0;
     const float* w = nullptr;         // [taps][Cout][Cin]
+    const float* w3 = nullptr;        // 3 x bf16 mode: the same filters pre-split (launch_weights_to_x3); null: split on the fly
     const float* bias = nullptr;      // [Cout] or null
     MutView y;
     int Hout = 0, Wout = 0;           // spatial size of the tensor y points into
@@ -68,6 +69,11 @@ struct ConvArgs {
 enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 3, IMPL_MFMA_BF16X3 = 4 };
 
 bool conv_mfma_eligible(const ConvArgs& a);
+// filters [taps][Cout][Cin] -> [taps][Cout][ceil(Cin/16)][h16 | m16 | l16] bf16 records (24 floats each)
+size_t weights_x3_floats(int taps, int Cout, int Cin);
+void launch_weights_to_x3(rfi_ctx* ctx, const float* w, int taps, int Cout, int Cin, float* out);
+struct X3Desc { const float* src; float* dst; int64_t rows; int Cin; int nchunks; };
+void launch_weights_to_x3_batched(rfi_ctx* ctx, const X3Desc* descs_dev, int n, double total_bytes);
 void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl = IMPL_AUTO);
 
 // ---------------------------------------------------------------- weight gradient

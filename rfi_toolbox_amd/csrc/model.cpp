@@ -45,9 +45,10 @@ rfi_model::~rfi_model() {
     if (!ctx) return;
     ctx->activate();
     for (auto& b : bufs) b.free();
-    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool})
+    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool})
         if (p) ctx->release(p);
     if (relayout_descs) ctx->release(relayout_descs);
+    if (x3_descs) ctx->release(x3_descs);
     if (d_sums) ctx->release(d_sums);
     if (d_scalars) ctx->release(d_scalars);
 }
@@ -194,6 +195,7 @@ void rfi_model::build() {
     }
     adam_step = 0;
     wd_dirty = true;
+        x3_fresh = false;
     reset_channel_state();
 }
 
@@ -306,7 +308,7 @@ void rfi_model::prepare(int n, int h, int w) {
 }
 
 void rfi_model::refresh_dgrad_weights() {
-    if (!wd_dirty) return;
+    if (!wd_dirty && (!compute_x3 || x3_fresh)) return;
     if (!relayout_descs) {          // one descriptor per conv-like layer, built once
         std::vector<RelayoutDesc> h;
         relayout_bytes = 0;
@@ -326,6 +328,44 @@ void rfi_model::refresh_dgrad_weights() {
     }
     launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
                                    wd_pool, relayout_bytes);
+    if (compute_x3) {     // pre-split records of both layouts of every conv-like layer (the kernels read them as is)
+        if (!w3_pool) {
+            size_t need = 0;
+            for (auto& c : convs) need += weights_x3_floats(9, c.cout, c.cin_p) + weights_x3_floats(9, c.cin_p, c.cout);
+            for (auto& u : ups) need += 2 * weights_x3_floats(4, u.cout, u.cin) + weights_x3_floats(4, u.cin, u.cout);
+            w3_pool = static_cast<float*>(ctx->alloc((need + 64) * sizeof(float)));
+            size_t o = 0;
+            for (auto& c : convs) {
+                c.w3 = w3_pool + o; o += weights_x3_floats(9, c.cout, c.cin_p);
+                c.wd3 = w3_pool + o; o += weights_x3_floats(9, c.cin_p, c.cout);
+            }
+            for (auto& u : ups) {
+                u.w3 = w3_pool + o; o += weights_x3_floats(4, u.cout, u.cin);
+                u.wd3 = w3_pool + o; o += weights_x3_floats(4, u.cin, u.cout);
+            }
+        }
+        if (!x3_descs) {
+            std::vector<X3Desc> h;
+            auto add = [&](const float* src, float* dst, int taps, int cout, int cin) {
+                h.push_back(X3Desc{src, dst, (int64_t)taps * cout, cin, (cin + 15) / 16});
+                x3_bytes += (double)taps * cout * cin * 4 + (double)weights_x3_floats(taps, cout, cin) * 4;
+            };
+            for (auto& c : convs) {
+                add(params + c.w_off, c.w3, 9, c.cout, c.cin_p);
+                add(c.wd, c.wd3, 9, c.cin_p, c.cout);
+            }
+            for (auto& u : ups) {
+                add(params + u.w_off, u.w3, 4, u.cout, u.cin);
+                add(u.wd, u.wd3, 4, u.cin, u.cout);
+            }
+            x3_n = (int)h.size();
+            x3_descs = ctx->alloc(h.size() * sizeof(X3Desc));
+            RFI_CHECK_HIP(hipMemcpyAsync(x3_descs, h.data(), h.size() * sizeof(X3Desc), hipMemcpyHostToDevice, ctx->stream));
+            RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // h goes out of scope
+        }
+        launch_weights_to_x3_batched(ctx, static_cast<const X3Desc*>(x3_descs), x3_n, x3_bytes);
+        x3_fresh = true;
+    }
     wd_dirty = false;
 }
 
@@ -340,6 +380,7 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
     a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
     a.Cin = c.cin_p; a.Cout = c.cout;
     a.w = m->params + c.w_off;
+    a.w3 = m->compute_x3 ? c.w3 : nullptr;
     a.bias = m->params + c.b_off;
     a.y = MutView{Y, c.cout};
     a.Hout = s.H; a.Wout = s.W;
@@ -382,6 +423,7 @@ rfi::View rfi_model::network_input(const float* x_dev, int n, int h, int w) {
 
 void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode) {
     prepare(n, h, w);
+    refresh_dgrad_weights();          // derived filter copies (dgrad layout, 3 x bf16 records) follow the parameters
     if (arch == 1) return forward_cnn3(x_dev, n, h, w);
     const int D = depth;
     View cur = network_input(x_dev, n, h, w);
@@ -414,6 +456,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = sin.H; a.Win = sin.W;
         a.Cin = u.cin; a.Cout = u.cout;
         a.w = params + u.w_off;
+        a.w3 = compute_x3 ? u.w3 : nullptr;
         a.bias = params + u.b_off;
         a.y = MutView{buf(concat[l]), 2 * u.cout};
         a.Hout = s.H; a.Wout = s.W;
@@ -512,6 +555,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
         a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
         a.Cin = c.cout; a.Cout = c.cin;     // dx exists only for layers whose cin == cin_p
         a.w = c.wd;
+        a.w3 = m->compute_x3 ? c.wd3 : nullptr;
         a.bias = nullptr;
         a.y = MutView{dx, c.cin};
         a.Hout = s.H; a.Wout = s.W;
@@ -578,6 +622,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = s.H; a.Win = s.W;
         a.Cin = u.cout; a.Cout = u.cin;
         a.w = u.wd;
+        a.w3 = compute_x3 ? u.wd3 : nullptr;
         a.bias = nullptr;
         float* dprev = (l == D) ? buf(gBottA) : buf(gA[l + 1]);
         a.y = MutView{dprev, u.cin};
@@ -631,4 +676,5 @@ void rfi_model::apply(const rfi_hyper& hp, float grad_scale) {
     a.norm_out = d_scalars + 1;
     launch_adam(ctx, a);
     wd_dirty = true;
+        x3_fresh = false;
 }

@@ -32,6 +32,8 @@ struct ConvBN {
     float* c1() const { return chan + 6 * cout; }
     float* c2() const { return chan + 7 * cout; }
     float* wd = nullptr;                // dgrad-layout copy of the weight [9][cin_p][cout]
+    float* w3 = nullptr;                // 3 x bf16 records of the forward layout (launch_weights_to_x3)
+    float* wd3 = nullptr;               // ... and of the dgrad layout
 };
 
 // ConvTranspose2d(k2,s2)+bias
@@ -40,6 +42,8 @@ struct UpConv {
     int cin = 0, cout = 0;
     size_t w_off = 0, b_off = 0;        // forward layout [4][cout][cin]
     float* wd = nullptr;                // dgrad layout [4][cin][cout]
+    float* w3 = nullptr;                // 3 x bf16 records of both layouts
+    float* wd3 = nullptr;
 };
 
 struct Entry {
@@ -81,8 +85,13 @@ struct rfi_model {
     float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     float* chan_pool = nullptr;
     float* wd_pool = nullptr;
+    float* w3_pool = nullptr;         // pre-split (3 x bf16) filter records, rebuilt with the dgrad layouts
+    void* x3_descs = nullptr;         // device table of the batched rebuild
+    int x3_n = 0;
+    double x3_bytes = 0;
     int64_t adam_step = 0;
     bool wd_dirty = true;
+    bool x3_fresh = false;            // the 3 x bf16 records match the current parameters
     void* relayout_descs = nullptr;   // device table for the batched dgrad-layout rebuild
     int relayout_n = 0;
     double relayout_bytes = 0;
