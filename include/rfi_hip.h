@@ -98,6 +98,11 @@ int rfi_model_set_activation(rfi_model* m, float negative_slope);
  *     reference gets from torch.autocast on a GPU (scripts/train_model.py:131,144). */
 int rfi_model_set_compute_dtype(rfi_model* m, int dtype);
 int rfi_model_set_head_sigmoid(rfi_model* m, int enabled);
+/* training loss: 0 = mean BCE-with-logits + dice, the reference's (scripts/train_model.py:120-128,146; default);
+ * 1 = sigmoid focal loss, mean over elements (NOT in the reference; builder-defined as
+ * Lin et al. 2017 / torchvision.ops.sigmoid_focal_loss: alpha_t (1 - p_t)^gamma BCEwithLogits; alpha < 0
+ * disables the alpha weighting). */
+int rfi_model_set_loss(rfi_model* m, int kind, float alpha, float gamma);
 /* deterministic init with torch's default distributions (kaiming-uniform(a=sqrt5) conv
  * weights/biases, BN gamma=1 beta=0, running stats 0/1) from a 64-bit seed */
 int rfi_model_init(rfi_model* m, uint64_t seed);

@@ -258,8 +258,23 @@ def new_adam_state(state):
             "v": {k: torch.zeros_like(state[k]) for k in param_names(state)}}
 
 
-def loss_and_grads(state, x_nchw, y, training=True, tape=None, forward_fn=None):
-    """``forward_fn`` defaults to the U-Net ``forward``; oracle/cnn_ref.py passes its own."""
+def focal_loss(logits, target, alpha=0.25, gamma=2.0):
+    """Sigmoid focal loss, mean over elements.  NOT in the reference: builder-defined as
+    Lin et al. 2017 / the published torchvision.ops.sigmoid_focal_loss formula."""
+    x = logits.reshape(-1)
+    t = target.reshape(-1).to(x.dtype)
+    p = torch.sigmoid(x)
+    ce = torch.clamp(x, min=0) - x * t + torch.log1p(torch.exp(-x.abs()))
+    p_t = p * t + (1 - p) * (1 - t)
+    loss = ce * (1 - p_t) ** gamma
+    if alpha >= 0:
+        loss = (alpha * t + (1 - alpha) * (1 - t)) * loss
+    return loss.mean()
+
+
+def loss_and_grads(state, x_nchw, y, training=True, tape=None, forward_fn=None, loss_fn=None):
+    """``forward_fn`` defaults to the U-Net ``forward``; oracle/cnn_ref.py passes its own.  ``loss_fn``
+    defaults to the reference's BCE + dice."""
     names = param_names(state)
     work = OrderedDict(state)
     leaves = []
@@ -269,7 +284,7 @@ def loss_and_grads(state, x_nchw, y, training=True, tape=None, forward_fn=None):
         leaves.append(t)
     bufs = {}
     logits = (forward_fn or forward)(work, x_nchw, training=training, buffer_updates=bufs, tape=tape)
-    loss = segmentation_loss(logits, y)
+    loss = (loss_fn or segmentation_loss)(logits, y)
     grads = torch.autograd.grad(loss, leaves)
     return loss.detach(), logits.detach(), OrderedDict(zip(names, grads)), bufs
 

@@ -66,6 +66,7 @@ _PROTOS = {
     "rfi_model_set_activation": (_i, [_vp, _f]),
     "rfi_model_set_compute_dtype": (_i, [_vp, _i]),
     "rfi_model_set_head_sigmoid": (_i, [_vp, _i]),
+    "rfi_model_set_loss": (_i, [_vp, _i, _f, _f]),
     "rfi_model_destroy": (_i, [_vp]),
     "rfi_model_init": (_i, [_vp, C.c_uint64]),
     "rfi_model_entry_count": (_i, [_vp, _pi]),

@@ -550,6 +550,15 @@ int rfi_model_set_compute_dtype(rfi_model* m, int dtype) {
         m->compute_x3 = dtype == 2;
     });
 }
+int rfi_model_set_loss(rfi_model* m, int kind, float alpha, float gamma) {
+    return guarded([&] {
+        RFI_REQUIRE(kind == 0 || kind == 1, "set_loss: 0 (BCE-with-logits + dice) or 1 (sigmoid focal loss)");
+        RFI_REQUIRE(kind == 0 || (gamma >= 0.0f && alpha <= 1.0f), "set_loss: focal needs gamma >= 0 and alpha <= 1");
+        m->loss_kind = kind;
+        m->focal_alpha = alpha;
+        m->focal_gamma = gamma;
+    });
+}
 int rfi_model_set_head_sigmoid(rfi_model* m, int enabled) {
     return guarded([&] {
         RFI_REQUIRE(m->arch == 0, "set_head_sigmoid: U-Net models only");

@@ -548,6 +548,68 @@ __global__ void loss_bwd_kernel(const float* __restrict__ logits, const uint8_t*
     }
 }
 
+// ---- focal loss (NOT in the reference, which trains with BCE + dice only).  Builder-
+// defined as the published sigmoid focal loss (Lin et al. 2017; torchvision.ops.sigmoid_focal_loss, mean):
+//   p = sigmoid(x), p_t = p t + (1-p)(1-t), FL = alpha_t (1 - p_t)^gamma * BCEwithLogits(x, t), mean over elements
+__device__ __forceinline__ float focal_elem(float x, float t, float alpha, float gamma) {
+    const float p = sigmoidf_(x);
+    const float ce = fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x)));
+    const float pt = p * t + (1.0f - p) * (1.0f - t);
+    const float at = alpha >= 0.0f ? alpha * t + (1.0f - alpha) * (1.0f - t) : 1.0f;
+    return at * powf(1.0f - pt, gamma) * ce;
+}
+__global__ void focal_reduce_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                                    int64_t count, float alpha, float gamma, double* __restrict__ partial) {
+    __shared__ double red[kBlock / 64];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        s += (double)focal_elem(logits[i], labels[i] ? 1.0f : 0.0f, alpha, gamma);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < kBlock / 64; ++k) t += red[k];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ void focal_finish_kernel(const double* __restrict__ partial, int blocks, double count,
+                                    float* __restrict__ loss_out) {
+    __shared__ double red[kBlock / 64];
+    double s = 0;
+    for (int b = threadIdx.x; b < blocks; b += blockDim.x) s += partial[b];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < kBlock / 64; ++k) t += red[k];
+        loss_out[0] = (float)(t / count);
+    }
+}
+// d FL / d x (closed form), times 1/N
+__global__ void focal_bwd_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels, int64_t count,
+                                 float alpha, float gamma, float* __restrict__ dlogits) {
+    const float invN = (float)(1.0 / (double)count);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = logits[i];
+        const bool pos = labels[i] != 0;
+        const float p = sigmoidf_(x);
+        // log p and log(1-p) without cancellation: -softplus(-x), -softplus(x)
+        const float sp_neg = fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));     // softplus(-x) = -log p
+        const float sp_pos = fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));      // softplus(x)  = -log(1-p)
+        float g;
+        if (pos) {       // FL = -a (1-p)^g log p
+            const float a = alpha >= 0.0f ? alpha : 1.0f;
+            g = a * powf(1.0f - p, gamma) * (gamma * p * (-sp_neg) - (1.0f - p));
+        } else {         // FL = -(1-a) p^g log(1-p)
+            const float a = alpha >= 0.0f ? 1.0f - alpha : 1.0f;
+            g = a * powf(p, gamma) * (p - gamma * (1.0f - p) * (-sp_pos));
+        }
+        dlogits[i] = g * invN;
+    }
+}
+
 // UNetOverfit's head (models/unet.py:196): the model RETURNS sigmoid(logits), and train_model.py:120 still
 // feeds that to BCE-with-logits + dice -- the loss kernels then see x = sigmoid(z) as their "logits"
 __global__ void sigmoid_fwd_kernel(const float* __restrict__ z, int64_t n, float* __restrict__ x) {
@@ -976,6 +1038,29 @@ void launch_loss_reduce(rfi_ctx* ctx, const float* logits, const uint8_t* labels
                            (double)count, sums4, loss_out);
         check_launch("loss_finish");
     }
+}
+void launch_focal_reduce(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count, float alpha,
+                         float gamma, double* partial_ws, float* loss_out) {
+    int blocks = grid_for(count, 1024);
+    {
+        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)count * 5);
+        hipLaunchKernelGGL(focal_reduce_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, logits, labels, count,
+                           alpha, gamma, partial_ws);
+        check_launch("focal_reduce");
+    }
+    {
+        ProfScope ps(ctx, FAM_ELEMWISE);
+        hipLaunchKernelGGL(focal_finish_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, partial_ws, blocks,
+                           (double)count, loss_out);
+        check_launch("focal_finish");
+    }
+}
+void launch_focal_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count, float alpha,
+                      float gamma, float* dlogits) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)count * 9);
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for(count)), dim3(kBlock), 0, ctx->stream, logits, labels,
+                       count, alpha, gamma, dlogits);
+    check_launch("focal_bwd");
 }
 void launch_loss_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count,
                      const double* sums4, float* dlogits) {

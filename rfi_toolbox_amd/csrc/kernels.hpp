@@ -151,6 +151,11 @@ size_t loss_ws_doubles(int64_t count);
 // dlogits from logits + the 4 sums (BCE mean + dice), in place into dlogits
 void launch_loss_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count,
                      const double* sums4, float* dlogits);
+// sigmoid focal loss (builder-defined, not in the reference): mean over elements, alpha < 0 = no alpha
+void launch_focal_reduce(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count, float alpha,
+                         float gamma, double* partial_ws, float* loss_out);
+void launch_focal_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, int64_t count, float alpha,
+                      float gamma, float* dlogits);
 // head backward: da[m,c] = sum_o dlogits[m,o]*w[o][c] (NOT yet relu-masked: bn_bwd does that);
 // dw[o][c] = sum_m dlogits[m,o]*act[m,c]; db[o] = sum_m dlogits[m,o]
 void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,

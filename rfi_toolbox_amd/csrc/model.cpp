@@ -484,6 +484,11 @@ void rfi_model::loss_forward(const uint8_t* labels_dev, int n, int h, int w) {
     RFI_REQUIRE(out_ch == 1, "loss: the reference's BCE+dice step is defined for out_channels == 1");
     const int64_t cnt = (int64_t)n * h * w;
     // UNetOverfit: BCE-with-logits + dice are applied to the model OUTPUT, i.e. to sigmoid(logits)
+    if (loss_kind == 1) {
+        launch_focal_reduce(ctx, buf(head_sigmoid ? probs : logits), labels_dev, cnt, focal_alpha, focal_gamma,
+                            reinterpret_cast<double*>(buf(ws_red)), d_scalars);
+        return;
+    }
     launch_loss_reduce(ctx, buf(head_sigmoid ? probs : logits), labels_dev, cnt,
                        reinterpret_cast<double*>(buf(ws_red)), d_sums, d_scalars);
 }
@@ -574,7 +579,10 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     const int64_t M1 = (int64_t)n * h * w;
     refresh_dgrad_weights();
     // loss -> dlogits -> head
-    launch_loss_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, d_sums, buf(dlogits));
+    if (loss_kind == 1)
+        launch_focal_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, focal_alpha, focal_gamma, buf(dlogits));
+    else
+        launch_loss_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, d_sums, buf(dlogits));
     if (head_sigmoid) launch_sigmoid_bwd(ctx, buf(probs), M1 * out_ch, buf(dlogits));
     {
         ConvBN& last = convs[2 * D + 2 + 2 * (D - 1) + 1];

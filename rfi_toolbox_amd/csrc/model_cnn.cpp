@@ -176,7 +176,8 @@ void rfi_model::backward_cnn3(const float* x_dev, const uint8_t* labels_dev, int
     ConvBN& c2 = convs[1];
     const int64_t M = (int64_t)n * h * w;
     refresh_dgrad_weights();
-    launch_loss_bwd(ctx, buf(logits), labels_dev, M, d_sums, buf(dlogits));
+    if (loss_kind == 1) launch_focal_bwd(ctx, buf(logits), labels_dev, M, focal_alpha, focal_gamma, buf(dlogits));
+    else launch_loss_bwd(ctx, buf(logits), labels_dev, M, d_sums, buf(dlogits));
     // head: dW, db and the gradient w.r.t. relu(Y2)
     launch_head_bwd(ctx, buf(cY2), M, feat, c2.scale(), c2.shift(), params + head_w_off, out_ch, buf(dlogits),
                     buf(cG2), buf(ws_red), grads + head_w_off, grads + head_b_off);

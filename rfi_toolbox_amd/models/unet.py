@@ -168,6 +168,15 @@ class HipSegmenter:
         self.compute_dtype = {2: "float32", 0: "float32_mfma", 1: "bfloat16"}[code]
         return self
 
+    def set_loss(self, kind="bce_dice", alpha=0.25, gamma=2.0):
+        """``"bce_dice"``: the reference's BCE-with-logits + dice (train_model.py:120-128, default);
+        ``"focal"``: sigmoid focal loss, mean over elements (not in the reference; Lin et al. 2017)."""
+        code = {"bce_dice": 0, "focal": 1}.get(kind)
+        if code is None:
+            raise ValueError(f"loss must be 'bce_dice' or 'focal', got {kind!r}")
+        check(lib.rfi_model_set_loss(self._h, code, float(alpha), float(gamma)))
+        return self
+
     # ---- mode
     def train(self, mode=True):
         self.training = bool(mode)

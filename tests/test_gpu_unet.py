@@ -384,3 +384,27 @@ def test_legacy_eight_channel_input():
     for k in ("encoder1.conv.conv.0.weight", "encoder1.conv.conv.1.weight", "decoder1.up.weight"):
         want = g32[k].numpy()
         assert np.linalg.norm(m.grad(k) - want) <= 2e-2 * np.linalg.norm(want), k
+
+
+@pytest.mark.parametrize("alpha,gamma", [(0.25, 2.0), (-1.0, 1.5), (0.6, 0.0)])
+def test_focal_loss_matches_oracle(alpha, gamma):
+    """SURVEY 8a row A12 (not in the reference; builder-defined sigmoid focal loss): loss value and
+    gradients through the whole U-Net against autograd on the oracle's formula."""
+    st = unet_ref.init_state(3, 1, 8, seed=41)
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(2, 32, 32, 3, generator=g)
+    y = (torch.rand(2, 32, 32, generator=g) > 0.7).to(torch.uint8)
+    fn = lambda lg, tt: unet_ref.focal_loss(lg, tt, alpha, gamma)      # noqa: E731
+    l32, _, g32, _ = unet_ref.loss_and_grads(st, unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1), loss_fn=fn)
+    m = UNet(3, 1, 8).load_state_dict(st).train().set_loss("focal", alpha=alpha, gamma=gamma)
+    loss = m.forward_backward(x, y)
+    assert loss == pytest.approx(float(l32), rel=2e-5, abs=1e-7)
+    for k in ("final_conv.weight", "final_conv.bias", "decoder1.conv.conv.3.weight", "bottleneck.conv.0.weight",
+              "encoder1.conv.conv.0.weight"):
+        want = g32[k].numpy()
+        assert np.linalg.norm(m.grad(k) - want) <= 2e-3 * np.linalg.norm(want) + 1e-9, k
+    assert m.set_loss("bce_dice").loss(x, y) == pytest.approx(
+        float(unet_ref.segmentation_loss(unet_ref.forward(st, unet_ref.nhwc_to_nchw(x), training=True, buffer_updates={}),
+                                         y.float().unsqueeze(1))), abs=2e-5)
+    with pytest.raises(ValueError):
+        m.set_loss("hinge")
