@@ -48,6 +48,53 @@ __global__ __launch_bounds__(256) void kmix(float* out, int iters) {
     for (int i = 0; i < 8; ++i) s += v[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// 6 x 32x32x16 bf16 MFMAs + NL ds_read_b128 per iteration (reads feed a dependent xor chain only at the end)
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int NL>
+__global__ __launch_bounds__(256) void klds(float* out, int iters) {
+    __shared__ f32x4m sm[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) sm[i] = f32x4m{(float)i, 1.f, 2.f, 3.f};
+    __syncthreads();
+    f32x16 acc[2];
+    for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    s16x8 a8 = {(short)threadIdx.x, 1, 2, 3, 4, 5, 6, 7}, b8 = {7, 6, 5, 4, 3, 2, 1, (short)threadIdx.x};
+    f32x4m v = {0.f, 0.f, 0.f, 0.f};
+    int idx = threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a8), __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b8), acc[i & 1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const f32x4m t = sm[(idx + i * 7 + it) & 1023];
+            v.x += t.x;
+        }
+    }
+    float s = v.x;
+    for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int NL>
+void runlds(int blocks) {
+    float* d;
+    hipMalloc(&d, 4096 * 256 * 4);
+    const int iters = 20000;
+    hipLaunchKernelGGL(klds<NL>, dim3(blocks), dim3(256), 0, 0, d, 100);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(klds<NL>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("6 mfma16 + %3d ds_read_b128 (+1 add each), %4d blocks: %8.2f ms  ~%6.0f cycles/iter/wave-slot\n", NL, blocks, ms,
+           ms * 1e-3 * 2.3e9 / iters / (blocks / 256.0));
+    hipFree(d);
+}
 template <int NV>
 void runmix(int blocks) {
     float* d;
@@ -93,5 +140,6 @@ int main() {
     run<2>("bf16 32x32x16", 32768.0);
     runmix<0>(256); runmix<40>(256); runmix<80>(256);
     runmix<0>(512); runmix<40>(512); runmix<80>(512);
+    runlds<0>(512); runlds<8>(512); runlds<16>(512); runlds<32>(512);
     return 0;
 }
