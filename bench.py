@@ -7,7 +7,9 @@
 
 A step = forward + BCE/dice loss + backward + (RCCL gradient all-reduce when N > 1) + global-norm
 clip + Adam on one batch of 64 synthetic patches per GPU that is already resident in HBM.
-Prints ONE JSON line on rank 0.  fp32 compute (the reference's CPU path is fp32).
+Prints ONE JSON line on rank 0.  float32 results (the reference's CPU path is fp32); --dtype picks how the
+contractions are computed: f32 = float32 by 3 x bf16 splitting (default), f32mfma = native float32 MFMA,
+bf16 = bfloat16 operands.
 """
 import argparse
 import json

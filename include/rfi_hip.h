@@ -132,8 +132,9 @@ int rfi_model_forward_nchw(rfi_model* m, const float* x, int x_mem, int n, int h
 /* ---- optimisation step: replaces the body of the loop in scripts/train_model.py:139-154
  *      zero_grad -> forward -> BCEWithLogits(mean)+dice (:120-128,146) -> backward ->
  *      clip_grad_norm_(max_norm) (:149) -> Adam(lr, betas, eps, coupled L2 weight_decay)
- *      (:130,150).  labels are uint8 (N,H,W), non-zero == RFI.  fp32 throughout (the
- *      reference's CPU path; autocast/GradScaler are off there, :131,144). ---- */
+ *      (:130,150).  labels are uint8 (N,H,W), non-zero == RFI.  float32 results throughout (the
+ *      reference's CPU path; autocast/GradScaler are off there, :131,144); how the contractions
+ *      reach them is rfi_model_set_compute_dtype's business. ---- */
 typedef struct rfi_hyper {   /* doubles: the reference's hyper-parameters are python floats */
     double lr, beta1, beta2, eps, weight_decay, max_grad_norm;
 } rfi_hyper;
