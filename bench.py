@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: training patches/sec of the U-Net step on 128x128x3 patches.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps 20 --warmup 5          # N > 1: starts one child process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   # or under an external launcher
 
 A step = forward + BCE/dice loss + backward + (RCCL gradient all-reduce when N > 1) + global-norm
 clip + Adam on one batch of 64 synthetic patches per GPU that is already resident in HBM.
@@ -23,9 +23,15 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
-PEAK_BF16_1K_MFMA_TFLOPS = 1258.0  # v_mfma_f32_32x32x8_bf16 (the instruction the bf16 mode uses): 8x the fp32 rate
-PEAK_BF16_MFMA_TFLOPS = 2516.0     # v_mfma_f32_32x32x16_bf16, dense; the 3 x bf16 float32 path issues 6 per product block
+PEAK_BF16_MFMA_TFLOPS = 2516.0     # v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0
+# `roofline.peak` is the peak of the INSTRUCTION the dominant kernel issues, in units of the algorithmic FLOPs it
+# is credited with: the default float32 path issues six v_mfma_f32_32x32x16_bf16 per 32x32x16 block product
+# (3 x bf16 splitting), so its ceiling is 2516 / 6 = 419.3 TFLOP/s of float32 work.
+PEAK_BY_DTYPE = {"f32": PEAK_BF16_MFMA_TFLOPS / 6, "f32mfma": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS / 2}
+INSTR_BY_DTYPE = {"f32": "6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block product (float32 by 3 x bf16 splitting)",
+                  "f32mfma": "v_mfma_f32_32x32x2_f32",
+                  "bf16": "v_mfma_f32_32x32x8_bf16 (half the rate of the 32x32x16 form: 1258 TFLOP/s)"}
 
 
 def usable_cpus():
@@ -41,39 +47,50 @@ def usable_cpus():
 
 
 def cpu_baseline(workload, features, size, seconds_cap=25.0):
-    """The oracle (torch-CPU fp32 restatement of the reference step) timed on this host: batch 4
-    (BASELINE config 0; batch 1 for the 1024x1024 workload), all host threads.  A reported baseline,
-    not the target."""
+    """The oracle (torch-CPU fp32 restatement of the reference step) timed on this host.  A BOUNDED sample:
+    batch 4 (BASELINE configs[0]; batch 1 for the 1024x1024 workload) -- not the GPU's batch 64 -- first on all
+    usable host threads, then on ONE thread (SURVEY 8d asks for both).  A reported baseline, not the target."""
     import torch
 
     from oracle import cnn_ref, unet_ref
     threads = usable_cpus()
-    torch.set_num_threads(threads)
     if workload == "cnn3":
-        st, step, what = cnn_ref.init_state(3, 1, features, seed=0), cnn_ref.train_step, f"cnn_ref SimpleCNN(3,1,{features})"
+        mk, step, what = cnn_ref.init_state, cnn_ref.train_step, f"cnn_ref SimpleCNN(3,1,{features})"
     else:
-        st, step, what = unet_ref.init_state(3, 1, features, seed=0), unet_ref.train_step, f"unet_ref UNet(3,1,{features})"
-    batch, warm, timed = (1, 1, 3) if size >= 512 else (4, 2, 10)
-    adam = unet_ref.new_adam_state(st)
+        mk, step, what = unet_ref.init_state, unet_ref.train_step, f"unet_ref UNet(3,1,{features})"
+    batch = 1 if size >= 512 else 4
     g = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 3, size, size, generator=g)
     y = (torch.rand(batch, 1, size, size, generator=g) > 0.8).float()
-    t_all0 = time.perf_counter()
-    times = []
-    for i in range(warm + timed):
-        t0 = time.perf_counter()
-        step(st, adam, x, y, lr=1e-4, weight_decay=1e-5)
-        dt = time.perf_counter() - t0
-        if i >= warm:
-            times.append(dt)
-        if time.perf_counter() - t_all0 > seconds_cap and len(times) >= 2:
-            break
-    med = float(np.median(times))
-    return {"value": round(batch / med, 3), "unit": "patches/s" if size < 512 else "samples/s", "cores": threads,
-            "kind": "port",
-            "sample": f"oracle/{what}.train_step, batch {batch} x {size}x{size}x3 fp32, "
-                      f"{len(times)} timed steps after {warm} warm-up, median {med * 1e3:.1f} ms/step, "
-                      f"torch.set_num_threads({threads})"}
+
+    def timed(nthreads, warm, n_timed, cap):
+        torch.set_num_threads(nthreads)
+        st = mk(3, 1, features, seed=0)
+        adam = unet_ref.new_adam_state(st)
+        t_all0, times = time.perf_counter(), []
+        for i in range(warm + n_timed):
+            t0 = time.perf_counter()
+            step(st, adam, x, y, lr=1e-4, weight_decay=1e-5)
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                times.append(dt)
+            if time.perf_counter() - t_all0 > cap and len(times) >= 2:
+                break
+        return float(np.median(times)), len(times)
+
+    warm, n_timed = (1, 3) if size >= 512 else (2, 10)
+    med, n = timed(threads, warm, n_timed, seconds_cap * 0.6)
+    med1, n1 = timed(1, 1, 3, seconds_cap * 0.4) if size < 512 else (None, 0)
+    unit = "patches/s" if size < 512 else "samples/s"
+    out = {"value": round(batch / med, 3), "unit": unit, "cores": threads, "kind": "port",
+           "sample": f"oracle/{what}.train_step, batch {batch} (the GPU line is batch 64) x {size}x{size}x3 fp32, "
+                     f"{n} timed steps after {warm} warm-up, median {med * 1e3:.1f} ms/step, "
+                     f"torch.set_num_threads({threads})"}
+    if med1:
+        out["single_thread"] = {"value": round(batch / med1, 3), "unit": unit, "cores": 1,
+                                "sample": f"same step, torch.set_num_threads(1), {n1} timed steps, "
+                                          f"median {med1 * 1e3:.1f} ms/step"}
+    return out
 
 
 def log(msg):
@@ -81,6 +98,31 @@ def log(msg):
 
 
 T0 = time.perf_counter()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh child processes (one rank per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this process has touched
+    the GPU or loaded the HIP library, wait for them and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench ranks failed (rank, exit code): {bad}")
 
 
 def main():
@@ -102,7 +144,12 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-csv", default=None, help="write the per-launch HIP-event profile here")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control plane only (rendezvous, barrier, max-over-ranks, one JSON line); no GPU work")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
 
     if args.batch is None:
         args.batch = 1 if args.workload == "unet1024" else 64
@@ -111,18 +158,28 @@ def main():
     if args.features is None:
         args.features = 64 if args.workload == "cnn3" else 32
 
+    from rfi_toolbox_amd import distributed as D
+    rank, local_rank, world = D.init_control_plane("gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        D.barrier()
+        t0 = time.perf_counter()
+        D.barrier()
+        wall = D.max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "barrier_ms": round(wall * 1e3, 3)}))
+        return
+
     import torch
 
-    from rfi_toolbox_amd import distributed as D
     from rfi_toolbox_amd._lib import Hyper
     from rfi_toolbox_amd.data_generation import make_training_patches_device
     from rfi_toolbox_amd.models import SimpleCNN, UNet
     from rfi_toolbox_amd.runtime import Context
 
     log("imports done")
-    rank, local_rank, world = D.init_control_plane("gloo")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     ctx = Context.get(local_rank)
     D.init_gradient_exchange(ctx, rank, world)
 
@@ -187,12 +244,10 @@ def main():
     ms_per_step = wall * 1e3 / args.steps
     value = world * B * args.steps / wall
     fwd_flops, step_flops = model.algorithmic_flops(B, S, S)
-    # `peak` is the dense MFMA peak of the DTYPE (float32: 157.3, the native fp32 MFMA rate the guide quotes).
-    # The default float32 path reaches its results with bf16 instructions (6 per product block), so the
-    # instruction-level ceiling for its algorithmic FLOPs is 2516 / 6 = 419 TFLOP/s: reported beside it.
-    peak = PEAK_BF16_1K_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-    roof = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,
-            "traffic": None}
+    peak = PEAK_BY_DTYPE[args.dtype]
+    roof = {"bound": "mfma", "achieved": None, "peak": round(peak, 1), "unit": "TFLOP/s", "frac": None,
+            "traffic": None, "instruction": INSTR_BY_DTYPE[args.dtype]}
+
     def per_family(report):
         out_ = {}
         for name, f in report.items():
@@ -207,16 +262,21 @@ def main():
     # the kernel family the step spends most time in (conv_igemm_mfma for the U-Net)
     mfma_fams = [k for k in ("conv_igemm_mfma", "wgrad_igemm_mfma") if k in fam and fam[k]["ms"]]
     dom = max(mfma_fams, key=lambda k: fam[k]["ms"]) if mfma_fams else "conv_igemm_mfma"
-    # HBM bytes per launch of the dominant family from the committed rocprofv3 PMC passes of this
-    # same command (bench.py cannot run under the profiler and time itself at once)
+    # HBM bytes per launch of the dominant family: NOT measured by this run (bench.py cannot sit under the
+    # profiler and time itself at once) -- a constant read from the committed rocprofv3 --pmc passes of this
+    # same command, and labelled as such
     import glob
-    traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if traffic_files and args.workload == "unet" and args.dtype == "f32":
+    tag = {"unet": "", "cnn3": "_cnn3", "unet1024": "_unet1024"}[args.workload] + \
+          {"f32": "", "f32mfma": "_f32mfma", "bf16": "_bf16"}[args.dtype]
+    traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic{tag}.json")))
+    if traffic_files:
         try:
             tj = json.load(open(traffic_files[-1]))["families"].get(dom)
             if tj:
                 roof["traffic"] = tj["hbm_bytes_per_launch"]
-                roof["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
+                roof["traffic_source"] = ("static, from " + os.path.relpath(traffic_files[-1], ROOT) +
+                                          " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                          "not measured by this run)")
         except Exception:
             pass
     if dom in fam and fam[dom]["ms"]:
@@ -227,10 +287,10 @@ def main():
                     avg_launch_ms=round(fam[dom]["ms"] / fam[dom]["launches"], 5),
                     launches_per_step=fam[dom]["launches"] / args.profile_steps,
                     algorithmic_flops_per_launch=fam[dom]["flops"] / fam[dom]["launches"])
-        if args.dtype == "f32":
-            roof.update(arithmetic="float32 by 3 x bf16 splitting: six v_mfma_f32_32x32x16_bf16 per product block",
-                        peak_3xbf16=round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
-                        frac_3xbf16=round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4))
+        if args.dtype == "f32":    # secondary: the same float32 work against what the native float32 MFMA could do
+            roof["vs_native_f32_mfma_peak_157.3"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
+        if not roof["frac"] <= 1.0:
+            raise SystemExit(f"roofline fraction {roof['frac']} > 1: wrong peak for the instruction stream")
     step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
     out = {
         "metric": ("training patches/sec (128x128x3)" if S == 128 else f"training samples/sec ({S}x{S}x3)"),
@@ -255,7 +315,7 @@ def main():
         "roofline": roof,
         "step": {"algorithmic_gflop_per_patch": round(step_flops / B / 1e9, 3),
                  "tflops_whole_step": round(step_tflops, 3),
-                 "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                 "frac_of_instruction_peak": round(step_tflops / peak, 4),
                  "hip_event_ms_per_step": round(ev_ms / args.steps, 4), "final_loss": round(float(loss), 6)},
         "families": fam_out,
         "families_overlapped": per_family(fam_ov),

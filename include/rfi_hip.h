@@ -139,6 +139,11 @@ typedef struct rfi_hyper {   /* doubles: the reference's hyper-parameters are py
     double lr, beta1, beta2, eps, weight_decay, max_grad_norm;
 } rfi_hyper;
 
+/* Data parallel: when the model's context holds a communicator of more than one rank (rfi_comm_init),
+ * rfi_train_step and rfi_train_step_async all-reduce(sum) the flat gradient buffer over the ranks before
+ * clipping and apply the MEAN gradient (grad_scale = 1/world), so every rank makes the identical update.
+ * BatchNorm batch statistics, running buffers and the dice term stay LOCAL to each rank's batch (torch DDP
+ * broadcasts rank 0's buffers every step; here they are only taken from rank 0 at checkpoint time). */
 int rfi_train_step(rfi_model* m, const float* x_nhwc, int x_mem, const uint8_t* labels,
                    int labels_mem, int n, int h, int w, const rfi_hyper* hp, float* loss_out);
 /* same step split in two so a data-parallel caller can all-reduce the gradients in between */
@@ -260,7 +265,9 @@ int rfi_threshold_logits(rfi_ctx* ctx, const float* logits_dev, int64_t count, f
 
 /* ---- kernel-level entry points (device pointers only).  Used by the parity tests to
  *      check each HIP kernel against the oracle in isolation.  impl: 0 auto, 1 direct VALU,
- *      2 MFMA implicit GEMM, 3 MFMA implicit GEMM with bfloat16 operands (the bf16 compute mode). ---- */
+ *      2 MFMA implicit GEMM in native float32 (v_mfma_f32_32x32x2_f32), 3 MFMA implicit GEMM with bfloat16
+ *      operands (the bf16 compute mode), 4 MFMA implicit GEMM, float32 by 3 x bf16 splitting (the models'
+ *      default arithmetic). ---- */
 int rfi_op_conv3x3(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
                    const float* w_oihw, const float* bias, int cout,
                    const float* in_scale, const float* in_shift, int in_relu, float* y);

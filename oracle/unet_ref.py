@@ -192,10 +192,72 @@ def _bn(x, st, prefix, training, ema_repeats, buffer_updates, tape, tag):
         + beta[None, :, None, None]
 
 
+# --------------------------------------------------------------------------
+# bf16-operand arithmetic (what torch.autocast gives the reference on a GPU, train_model.py:131,144, and what
+# the HIP library's bf16 compute mode does): every contraction (conv / convT, forward, input gradient, weight
+# gradient) sees its two operands rounded to bfloat16 and accumulates in float32; everything else is float32.
+# --------------------------------------------------------------------------
+def _bf(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _ConvBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, padding):
+        ctx.save_for_backward(x, w)
+        ctx.padding = padding
+        return F.conv2d(_bf(x), _bf(w), b, padding=padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dyb = _bf(dy)
+        dx = torch.nn.grad.conv2d_input(x.shape, _bf(w), dyb, padding=ctx.padding)
+        dw = torch.nn.grad.conv2d_weight(_bf(x), w.shape, dyb, padding=ctx.padding)
+        return dx, dw, dy.sum(dim=(0, 2, 3)), None
+
+
+class _ConvT2x2BF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.conv_transpose2d(_bf(x), _bf(w), b, stride=2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dyb = _bf(dy)
+        dx = F.conv2d(dyb, _bf(w), None, stride=2)                               # adjoint of the scatter
+        dw = torch.nn.grad.conv2d_weight(dyb, w.shape, _bf(x), stride=2)         # [cin][cout][2][2]
+        return dx, dw, dy.sum(dim=(0, 2, 3))
+
+
+_BF16_OPERANDS = False
+
+
+class bf16_operands:
+    """``with unet_ref.bf16_operands(): ...`` -- forward/backward of the oracle in the bf16-operand arithmetic."""
+
+    def __enter__(self):
+        global _BF16_OPERANDS
+        self.prev, _BF16_OPERANDS = _BF16_OPERANDS, True
+
+    def __exit__(self, *exc):
+        global _BF16_OPERANDS
+        _BF16_OPERANDS = self.prev
+
+
+def _conv3x3(x, w, b):
+    return _ConvBF16.apply(x, w, b, 1) if _BF16_OPERANDS else F.conv2d(x, w, b, padding=1)
+
+
+def _convt2x2(x, w, b):
+    return _ConvT2x2BF16.apply(x, w, b) if _BF16_OPERANDS else F.conv_transpose2d(x, w, b, stride=2)
+
+
 def _double_conv(x, st, prefix, training, ema_repeats, buffer_updates, tape, negative_slope=0.0):
     for conv_idx, bn_idx in ((0, 1), (3, 4)):
-        x = F.conv2d(x, st[f"{prefix}.{conv_idx}.weight"], st[f"{prefix}.{conv_idx}.bias"],
-                     padding=1)
+        x = _conv3x3(x, st[f"{prefix}.{conv_idx}.weight"], st[f"{prefix}.{conv_idx}.bias"])
         if tape is not None:
             tape[f"{prefix}.{conv_idx}.out"] = x
         x = _bn(x, st, f"{prefix}.{bn_idx}", training, ema_repeats, buffer_updates, tape,
@@ -221,8 +283,7 @@ def forward(state, x_nchw, training=False, buffer_updates=None, tape=None, negat
         h = F.max_pool2d(a, kernel_size=2, stride=2)
     h = _double_conv(h, state, "bottleneck.conv", training, 1, buffer_updates, tape, ns)
     for lvl in range(depth, 0, -1):
-        up = F.conv_transpose2d(h, state[f"decoder{lvl}.up.weight"], state[f"decoder{lvl}.up.bias"],
-                                stride=2)
+        up = _convt2x2(h, state[f"decoder{lvl}.up.weight"], state[f"decoder{lvl}.up.bias"])
         if tape is not None:
             tape[f"decoder{lvl}.up.out"] = up
         h = torch.cat([up, skips[lvl - 1]], dim=1)

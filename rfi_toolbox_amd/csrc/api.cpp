@@ -611,6 +611,20 @@ void check_hyper(const rfi_hyper* hp) {
     RFI_REQUIRE(hp->beta1 >= 0 && hp->beta1 < 1 && hp->beta2 >= 0 && hp->beta2 < 1, "Adam: betas must be in [0,1)");
 }
 
+void comm_allreduce_sum(rfi_ctx* ctx, float* dptr, int64_t count);   // RCCL section below; throws
+
+// The optimiser half of a full training step, shared by rfi_train_step and rfi_train_step_async: when the
+// context holds a communicator of more than one rank the flat gradient buffer is summed over the ranks
+// (RCCL, on this context's stream) and clip + Adam see the MEAN gradient (grad_scale = 1 / world).
+void exchange_and_apply(rfi_model* m, const rfi_hyper& hp) {
+    if (m->ctx->nccl_comm && m->ctx->world > 1) {
+        comm_allreduce_sum(m->ctx, m->grads, (int64_t)m->n_flat);
+        m->apply(hp, 1.0f / (float)m->ctx->world);
+    } else {
+        m->apply(hp, 1.0f);
+    }
+}
+
 }  // namespace
 
 int rfi_model_forward_nhwc(rfi_model* m, const float* x, int x_mem, int n, int h, int w, float* logits,
@@ -667,7 +681,7 @@ int rfi_train_step(rfi_model* m, const float* x, int x_mem, const uint8_t* label
         m->forward(xd, n, h, w, true);
         m->loss_forward(yd, n, h, w);
         m->backward(xd, yd, n, h, w);
-        m->apply(*hp, 1.0f);
+        exchange_and_apply(m, *hp);
         RFI_CHECK_HIP(hipMemcpyAsync(m->ctx->pinned, m->d_scalars, 2 * sizeof(float), hipMemcpyDeviceToHost,
                                      m->ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -685,12 +699,7 @@ int rfi_train_step_async(rfi_model* m, const float* x_dev, const uint8_t* labels
         m->forward(x_dev, n, h, w, true);
         m->loss_forward(labels_dev, n, h, w);
         m->backward(x_dev, labels_dev, n, h, w);
-        if (m->ctx->nccl_comm && m->ctx->world > 1) {
-            RFI_REQUIRE(rfi_comm_allreduce_sum_f32(m->ctx, m->grads, (int64_t)m->n_flat) == 0, rfi_last_error());
-            m->apply(*hp, 1.0f / (float)m->ctx->world);
-        } else {
-            m->apply(*hp, 1.0f);
-        }
+        exchange_and_apply(m, *hp);
     });
 }
 int rfi_model_last_loss(rfi_model* m, float* loss_out, float* grad_norm_out) {
@@ -910,14 +919,17 @@ int rfi_comm_destroy(rfi_ctx* ctx) {
         }
     });
 }
+namespace {
+void comm_allreduce_sum(rfi_ctx* ctx, float* dptr, int64_t count) {
+    RFI_REQUIRE(ctx->nccl_comm, "rfi_comm_allreduce: communicator not initialised");
+    ctx->activate();
+    ProfScope ps(ctx, FAM_COMM, 0, (double)count * 4);
+    // ncclFloat32 = 7, ncclSum = 0
+    nccl_check(g_nccl.AllReduce(dptr, dptr, (size_t)count, 7, 0, ctx->nccl_comm, ctx->stream), "ncclAllReduce");
+}
+}  // namespace
 int rfi_comm_allreduce_sum_f32(rfi_ctx* ctx, float* dptr, int64_t count) {
-    return guarded([&] {
-        RFI_REQUIRE(ctx->nccl_comm, "rfi_comm_allreduce: communicator not initialised");
-        ctx->activate();
-        ProfScope ps(ctx, FAM_COMM, 0, (double)count * 4);
-        // ncclFloat32 = 7, ncclSum = 0
-        nccl_check(g_nccl.AllReduce(dptr, dptr, (size_t)count, 7, 0, ctx->nccl_comm, ctx->stream), "ncclAllReduce");
-    });
+    return guarded([&] { comm_allreduce_sum(ctx, dptr, count); });
 }
 int rfi_model_allreduce_grads(rfi_model* m) {
     return rfi_comm_allreduce_sum_f32(m->ctx, m->grads, (int64_t)m->n_flat);

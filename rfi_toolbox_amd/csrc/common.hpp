@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -155,5 +156,20 @@ static inline void check_launch(const char* what) {
 }
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// "do once per device": function attributes such as hipFuncAttributeMaxDynamicSharedMemorySize are
+// per device, and a process may hold contexts on several GPUs (and host threads)
+struct PerDeviceOnce {
+    std::mutex mu;
+    uint64_t done[4] = {0, 0, 0, 0};     // up to 256 device ordinals
+    template <typename F>
+    void run(int device, F&& f) {
+        std::lock_guard<std::mutex> g(mu);
+        const unsigned d = (unsigned)device & 255u;
+        if (done[d >> 6] >> (d & 63) & 1u) return;
+        f();
+        done[d >> 6] |= uint64_t(1) << (d & 63);
+    }
+};
 
 }  // namespace rfi

@@ -554,13 +554,12 @@ void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
     if (a.stats && vec_out && a.zgroups == 1 && G <= a.stats_max_records) a.stats_records = G;
     else a.stats = nullptr;
     dim3 grid(G, ychunks, a.zgroups);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    attr_once.run(ctx->device, [&] {
         RFI_CHECK_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void*>(&conv_igemm_kernel<R, S, TH, TW, BN, WM, WN, PREC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    });
 #ifdef RFI_DIAG_STAMPS
     {   // diagnostic build: run with per-phase cycle stamps and print the per-wave averages
         ConvArgs b = a;

@@ -195,7 +195,7 @@ void rfi_model::build() {
     }
     adam_step = 0;
     wd_dirty = true;
-        x3_fresh = false;
+    x3_fresh = false;
     reset_channel_state();
 }
 
@@ -465,7 +465,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         a.zgroups = 4;
         a.xf = bn_xf(*prevBN);
         a.bf16 = compute_bf16;
-    a.bf16x3 = compute_x3;
+        a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
         ConvBN& c1 = convs[2 * D + 2 + 2 * k];
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
@@ -524,6 +524,15 @@ void rfi_model::side_join() {
 
 namespace {
 
+// launches inside a SideScope go to the side stream; if one throws, the context's stream is put back
+struct SideScope {
+    rfi_model* m;
+    bool ended = false;
+    explicit SideScope(rfi_model* model) : m(model) { m->side_begin(); }
+    void end() { m->side_end(); ended = true; }
+    ~SideScope() { if (!ended) m->ctx->stream = m->ctx->main_stream; }
+};
+
 // given dA (grad w.r.t. the ACTIVATED output of conv c, overwritten with dY), produce dW/db/dgamma/
 // dbeta into the grad buffer and, if dx != null, the gradient w.r.t. the conv's (activated) input
 void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in, InXform in_xf,
@@ -549,11 +558,13 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
     wa.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
     wa.slab = m->buf(m->ws_slab);
     wa.slab_floats = m->bufs[m->ws_slab].n;
-    m->side_begin();
     wa.bf16 = m->compute_bf16;
     wa.bf16x3 = m->compute_x3;
-    launch_wgrad(ctx, wa);
-    m->side_end();
+    {
+        SideScope side(m);
+        launch_wgrad(ctx, wa);
+        side.end();
+    }
     if (dx) {
         ConvArgs a;
         a.x = View{dA, c.cout};
@@ -566,7 +577,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
         a.Hout = s.H; a.Wout = s.W;
         a.R = 3; a.S = 1; a.pad = 1;
         a.bf16 = m->compute_bf16;
-    a.bf16x3 = m->compute_x3;
+        a.bf16x3 = m->compute_x3;
         launch_conv(ctx, a);
     }
 }
@@ -620,11 +631,13 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         wa.sy = 1; wa.sx = u.cin;          // -> [tap][cout][cin]
         wa.slab = buf(ws_slab);
         wa.slab_floats = bufs[ws_slab].n;
-        side_begin();
         wa.bf16 = compute_bf16;
-    wa.bf16x3 = compute_x3;
-        launch_wgrad(ctx, wa);
-        side_end();
+        wa.bf16x3 = compute_x3;
+        {
+            SideScope side(this);
+            launch_wgrad(ctx, wa);
+            side.end();
+        }
         ConvArgs a;
         a.x = dUp;
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = s.H; a.Win = s.W;
@@ -637,7 +650,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         a.Hout = sin.H; a.Wout = sin.W;
         a.R = 2; a.S = 2; a.pad = 0;
         a.bf16 = compute_bf16;
-    a.bf16x3 = compute_x3;
+        a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
     }
     // bottleneck
@@ -684,5 +697,5 @@ void rfi_model::apply(const rfi_hyper& hp, float grad_scale) {
     a.norm_out = d_scalars + 1;
     launch_adam(ctx, a);
     wd_dirty = true;
-        x3_fresh = false;
+    x3_fresh = false;
 }

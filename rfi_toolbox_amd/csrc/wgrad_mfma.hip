@@ -374,13 +374,12 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
     WgradDev d{a, p.nsplit, p.slab_stride};
     dim3 grid(p.nsplit, (unsigned)cdiv(a.Cy, BY), (unsigned)cdiv(a.Cx, BX));
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    attr_once.run(ctx->device, [&] {
         RFI_CHECK_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void*>(&wgrad_igemm_kernel<R, S, BY, BX, TH, TW, PREC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    });
     {
         const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cy * a.Cx * R * R;
         std::string label;

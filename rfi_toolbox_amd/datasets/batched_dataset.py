@@ -87,14 +87,63 @@ class BatchWriter:
         return meta
 
 
-def load_batches(directory):
-    """Read every ``batch_*.pt`` shard a (reference or local) BatchWriter wrote into one TorchDataset."""
+def _shard_files(directory):
     import json
     d = Path(directory)
     files = sorted(d.glob("batch_*.pt"))
     if not files:
         raise FileNotFoundError(f"no batch_*.pt shards under {d}")
-    parts = [torch.load(f, weights_only=False) for f in files]
     meta = json.load(open(d / "metadata.json")) if (d / "metadata.json").exists() else {}
-    return TorchDataset(torch.cat([p["images"] for p in parts]).float(),
-                        torch.cat([p["labels"] for p in parts]).to(torch.uint8), meta)
+    return files, meta
+
+
+def _check_shard(p, f):
+    img, lab = p["images"], p["labels"]
+    if img.ndim != 4 or img.shape[-1] != 3 or lab.ndim != 3 or tuple(lab.shape) != tuple(img.shape[:3]):
+        raise ValueError(f"{f}: expected images (n,H,W,3) and labels (n,H,W), got {tuple(img.shape)} / {tuple(lab.shape)}")
+    return img, lab
+
+
+def load_batches(directory):
+    """Read every ``batch_*.pt`` shard a (reference or local) BatchWriter wrote into one TorchDataset.
+
+    Shapes come from the tensors: the reference's ``metadata.json`` hard-codes ``image_shape [1024,1024,3]``
+    whatever was written (datasets/batched_dataset.py:168-169), so it is kept as metadata only.  A reference shard
+    is a VIEW into the whole flushed block (``torch.save`` of a slice stores the full storage); loading gives the
+    slice back."""
+    files, meta = _shard_files(directory)
+    parts = [_check_shard(torch.load(f, weights_only=False), f) for f in files]
+    return TorchDataset(torch.cat([i for i, _ in parts]).float(),
+                        torch.cat([lb for _, lb in parts]).to(torch.uint8), meta)
+
+
+def load_batches_device(directory, device=None):
+    """The same shards straight into HBM: each ``batch_*.pt`` is memory-mapped and its patches are copied from the
+    mapping into their slot of ONE (N,H,W,3) float32 / (N,H,W) uint8 device buffer pair -- the NHWC layout the
+    kernels consume -- without a concatenated host copy.  -> (images DeviceArray, labels DeviceArray, metadata)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from .._lib import DEVICE, HOST, check, lib
+    from ..runtime import Context
+    files, meta = _shard_files(directory)
+    parts = [_check_shard(torch.load(f, mmap=True, weights_only=True), f) for f in files]
+    shape = tuple(parts[0][0].shape[1:])
+    for (img, _), f in zip(parts, files):
+        if tuple(img.shape[1:]) != shape:
+            raise ValueError(f"{f}: patch shape {tuple(img.shape[1:])} differs from {shape}")
+    n = sum(len(i) for i, _ in parts)
+    ctx = Context.get(device)
+    images, labels = ctx.empty((n, *shape), np.float32), ctx.empty((n, *shape[:2]), np.uint8)
+    off = 0
+    for img, lab in parts:
+        img, lab = img.to(torch.float32).contiguous(), lab.to(torch.uint8).contiguous()     # no-ops for reference shards
+        k = len(img)
+        per = shape[0] * shape[1]
+        check(lib.rfi_memcpy(ctx.handle, C.c_void_p(images.ptr + off * per * 3 * 4), DEVICE,
+                             C.c_void_p(img.data_ptr()), HOST, k * per * 3 * 4))
+        check(lib.rfi_memcpy(ctx.handle, C.c_void_p(labels.ptr + off * per), DEVICE,
+                             C.c_void_p(lab.data_ptr()), HOST, k * per))
+        off += k
+    return images, labels, meta

@@ -100,3 +100,21 @@ def test_batch_writer_shards_round_trip(tmp_path):
     assert torch.equal(back.images, imgs) and back[1]["label"].shape == (4, 4)
     with pytest.raises(AssertionError):
         TorchDataset(imgs.double(), labs)
+
+
+def test_load_batches_reads_reference_written_shards(golden_dir):
+    """shards written by the REFERENCE's BatchWriter (tests/golden/make_shard_fixture.py): ragged
+    shard sizes (5,3,5,3 -- the reference flushes everything it holds in samples_per_batch chunks), tensors that
+    are views into a larger stored block, and a metadata.json whose shapes are the hard-coded 1024x1024."""
+    import numpy as np
+    from rfi_toolbox_amd.datasets import load_batches
+    d = os.path.join(golden_dir, "ref_shards")
+    want = np.load(os.path.join(d, "expected.npz"))
+    ds = load_batches(d)
+    assert len(ds) == 16 and tuple(ds.images.shape) == (16, 32, 32, 3) and tuple(ds.labels.shape) == (16, 32, 32)
+    assert ds.images.dtype == torch.float32 and ds.labels.dtype == torch.uint8
+    np.testing.assert_array_equal(ds.images.numpy(), want["images"])
+    np.testing.assert_array_equal(ds.labels.numpy(), want["labels"])
+    assert ds.metadata["num_samples"] == 16 and ds.metadata["num_batches"] == 4
+    assert ds.metadata["image_shape"] == [1024, 1024, 3]        # the reference's constant, not the data's shape
+    assert ds[3]["image"].shape == (32, 32, 3) and ds[3]["label"].dtype == torch.uint8

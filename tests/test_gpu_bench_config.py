@@ -1,0 +1,102 @@
+"""-m gpu: parity AT THE BENCHED CONFIGURATION (BASELINE configs[1]/[4] shape): UNet(3,1,32), batch 64 x 128x128x3
+patches produced by the device input pipeline bench.py uses (`make_training_patches_device`), one training
+step (train_model.py:139-151) in each of the three arithmetic modes of the contraction kernels, against the
+CPU oracle in float32 and -- to calibrate the gradient tolerance instead of guessing it -- in float64.
+
+At this size every layer launches the tile instantiations the bench runs (the double tiles of the native-float32
+and bf16 modes included), so the numbers bench.py reports come from kernels this file has checked.
+"""
+from collections import OrderedDict
+from functools import lru_cache
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics_ref, unet_ref
+from rfi_toolbox_amd.data_generation import make_training_patches_device
+from rfi_toolbox_amd.models import UNet
+
+pytestmark = pytest.mark.gpu
+B, S, FEAT = 64, 128, 32
+
+
+def _is_prebn_bias(k):          # conv bias in front of a BatchNorm: exactly 0 gradient in exact arithmetic
+    return k.endswith(".0.bias") or k.endswith(".3.bias")
+
+
+@lru_cache(maxsize=1)
+def _case():
+    """Inputs, initial state and the oracle's float32 / float64 answers, computed once for all modes."""
+    d_x, d_y = make_training_patches_device(B, S, seed=1234, device=0)       # bench.py's inputs (rank 0)
+    x = torch.from_numpy(d_x.numpy().copy())
+    y = torch.from_numpy(d_y.numpy().copy())
+    torch.manual_seed(1234)                                                  # bench.py's weights
+    st = UNet(3, 1, FEAT).state_dict()
+    xo, yo = unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    l32, lg32, g32, bufs = unet_ref.loss_and_grads(st, xo, yo)
+    st64 = OrderedDict((k, v.double() if v.dtype.is_floating_point else v.clone()) for k, v in st.items())
+    l64, lg64, g64, _ = unet_ref.loss_and_grads(st64, xo.double(), yo.double())
+    total, coef = unet_ref.clip_coefficient(g32, 1.0)
+    return dict(x=x, y=y, st=st, l32=float(l32), lg32=lg32, g32=g32, g64=g64, lg64=lg64, l64=float(l64),
+                bufs=bufs, norm=float(total))
+
+
+@pytest.mark.parametrize("mode", ["float32", "float32_mfma", "bfloat16"])
+def test_bench_configuration_step_vs_oracle(mode):
+    c = _case()
+    m = UNet(3, 1, FEAT).load_state_dict(c["st"]).train().set_compute_dtype(mode)
+    loss = m.forward_backward(c["x"], c["y"])
+    logits = m.debug_tensor("logits")
+    want_logits = c["lg32"].permute(0, 2, 3, 1).reshape(-1).numpy()
+    span = float(np.abs(want_logits).max())
+    f32 = mode != "bfloat16"
+    # loss and logits: float32 modes agree with the float32 oracle to rounding; bf16 operands to ~2^-8 relative
+    assert loss == pytest.approx(c["l32"], abs=2e-5 if f32 else 2e-2 * abs(c["l32"]))
+    assert np.abs(logits - want_logits).max() <= (2e-4 if f32 else 0.05 * span)
+    ratios, rels = [], []
+    for k, want64 in c["g64"].items():
+        want64 = want64.numpy().ravel()
+        got = m.grad(k).ravel()
+        assert np.isfinite(got).all(), k
+        if _is_prebn_bias(k):
+            assert np.abs(got).max() <= 1e-6 + (1e-5 if f32 else 1e-2) * max(np.abs(c["g32"][k].numpy()).max(), 1e-3), k
+            continue
+        nrm = np.linalg.norm(want64) + 1e-30
+        rel_ref = np.linalg.norm(c["g32"][k].numpy().ravel() - want64) / nrm
+        rel_hip = np.linalg.norm(got - want64) / nrm
+        rels.append(rel_hip)
+        if f32:
+            # the criterion of test_flagship_width_vs_oracle: each tensor within 4x the float32 CPU path's own
+            # distance from the float64 result (or 2e-2 where a ReLU-threshold element dominates) ...
+            assert rel_hip <= max(4 * rel_ref, 2e-2), (k, rel_hip, rel_ref)
+            ratios.append(rel_hip / max(rel_ref, 1e-9))
+        else:
+            assert rel_hip <= 0.25, (k, rel_hip)          # bf16 operands through up to 23 layers, both directions
+    if f32:
+        assert np.median(ratios) <= 3.0, np.median(ratios)  # ... and the typical tensor at that noise level
+    else:
+        assert np.median(rels) <= 0.08, np.median(rels)
+    norm = m.apply_gradients(lr=1e-4, weight_decay=1e-5)
+    assert norm == pytest.approx(c["norm"], rel=5e-3 if f32 else 5e-2)
+    sd = m.state_dict()
+    for k in ("encoder1.conv.conv.1.running_mean", "encoder4.conv.conv.4.running_var", "bottleneck.conv.4.running_var",
+              "decoder1.conv.conv.4.running_var"):
+        np.testing.assert_allclose(sd[k].numpy(), c["bufs"][k].numpy(), rtol=0 if f32 else 2e-2,
+                                   atol=5e-6 if f32 else 2e-3, err_msg=k)
+    assert int(sd["encoder1.conv.conv.1.num_batches_tracked"]) == 2
+
+
+def test_bench_configuration_masks_agree_across_modes():
+    """Eval-mode masks of the two float32 arithmetic modes at the bench shape on the same (random-init) weights
+    differ at most in threshold pixels: fewer than 1e-4 of the pixels, and |dIoU| <= 1e-3 against each other."""
+    c = _case()
+    masks = {}
+    for mode in ("float32", "float32_mfma"):
+        m = UNet(3, 1, FEAT).load_state_dict(c["st"]).eval().set_compute_dtype(mode)
+        masks[mode] = m.forward_nhwc(c["x"].numpy())[..., 0] > 0
+    a, b = masks["float32"], masks["float32_mfma"]
+    assert (a != b).mean() <= 1e-4
+    if (a | b).mean() > 0.01:
+        assert metrics_ref.evaluate_segmentation(a, b)["iou"] >= 1 - 1e-3

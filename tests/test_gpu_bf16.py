@@ -71,3 +71,58 @@ def test_bf16_training_tracks_float32():
     ia = metrics_ref.evaluate_segmentation(a.eval().forward_nhwc(x)[..., 0] > 0, y.numpy())["iou"]
     ib = metrics_ref.evaluate_segmentation(b.eval().forward_nhwc(x)[..., 0] > 0, y.numpy())["iou"]
     assert abs(ia - ib) <= 0.02, (ia, ib)
+
+
+def test_bf16_unet_1024_vs_bf16_operand_oracle():
+    """BASELINE configs[2] shape in its stated arithmetic (SURVEY 8a A10 stand-in): UNet(3,1,32), one
+    1024x1024x3 waterfall, bf16 compute mode, forward + loss + backward against the oracle run in the SAME
+    arithmetic (`unet_ref.bf16_operands()`: every contraction sees bf16-rounded operands, float32 accumulate).
+    What is left between the two is summation order and the handful of activations that round to the other
+    side of a bf16 tie or the ReLU threshold."""
+    st = unet_ref.init_state(3, 1, 32, seed=3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 1024, 1024, 3, generator=g)
+    y = (torch.rand(1, 1024, 1024, generator=g) > 0.9).to(torch.uint8)
+    y[:, 300:340, :] = 1
+    xo, yo = unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1)
+    with unet_ref.bf16_operands():
+        lbf, lgbf, gbf, _ = unet_ref.loss_and_grads(st, xo, yo)
+    l32, lg32, g32, _ = unet_ref.loss_and_grads(st, xo, yo)
+    m = UNet(3, 1, 32).load_state_dict(st).train().set_compute_dtype("bfloat16")
+    loss = m.forward_backward(x, y)
+    got = m.debug_tensor("logits")
+    want = lgbf.permute(0, 2, 3, 1).reshape(-1).numpy()
+    span = float(np.abs(want).max())
+    d_same = np.abs(got - want).max()                    # against the oracle in the same arithmetic
+    d_f32 = np.abs(lg32.permute(0, 2, 3, 1).reshape(-1).numpy() - want).max()   # what the arithmetic itself costs
+    assert d_same <= 0.02 * span and d_same <= max(0.5 * d_f32, 2e-3 * span), (d_same, d_f32, span)
+    assert loss == pytest.approx(float(lbf), rel=2e-3)
+    for k in ("final_conv.weight", "decoder1.conv.conv.3.weight", "decoder1.up.weight", "decoder3.conv.conv.0.weight",
+              "bottleneck.conv.3.weight", "encoder3.conv.conv.0.weight", "encoder1.conv.conv.3.weight",
+              "encoder1.conv.conv.0.weight", "encoder2.conv.conv.1.weight", "decoder2.conv.conv.4.bias"):
+        w_bf, w_32 = gbf[k].numpy().ravel(), g32[k].numpy().ravel()
+        nrm = np.linalg.norm(w_bf) + 1e-30
+        rel_same = np.linalg.norm(m.grad(k).ravel() - w_bf) / nrm
+        rel_arith = np.linalg.norm(w_32 - w_bf) / nrm
+        # closer to the same-arithmetic oracle than the float32 oracle is (the two differ by the bf16 rounding)
+        assert rel_same <= max(0.6 * rel_arith, 5e-3), (k, rel_same, rel_arith)
+
+
+def test_bf16_inference_iou_at_1024_on_reference_weights(golden_dir):
+    """|dIoU| <= 1e-3 (north_star) at the configs[2] size: the weights the REFERENCE trained (tests/golden,
+    f = 8) applied to a 1024x1024 synthetic waterfall from the device generator + Preprocessor pipeline,
+    bf16 mode on the GPU against the float32 oracle, both scored against the generator's own RFI mask."""
+    from rfi_toolbox_amd.data_generation import make_training_patches_device
+    g = np.load(os.path.join(golden_dir, "unet_f8_b4_s64.npz"))
+    st = OrderedDict((k[8:], torch.from_numpy(g[k].copy())) for k in g.files if k.startswith("state40/"))
+    d_x, d_y = make_training_patches_device(1, 1024, seed=77, device=0)
+    x, lab = d_x.numpy(), d_y.numpy()
+    assert x.shape == (1, 1024, 1024, 3) and 0.005 < lab.mean() < 0.9
+    m = UNet(3, 1, 8).load_state_dict(st).eval().set_compute_dtype("bfloat16")
+    logits = m.forward_nhwc(x)[..., 0]
+    with torch.no_grad():
+        want = unet_ref.forward(st, unet_ref.nhwc_to_nchw(torch.from_numpy(x)), training=False)[:, 0].numpy()
+    got_m, ref_m = metrics_ref.evaluate_segmentation(logits > 0, lab), metrics_ref.evaluate_segmentation(want > 0, lab)
+    for k in ("iou", "precision", "recall", "f1", "dice"):
+        assert abs(got_m[k] - ref_m[k]) <= 1e-3, (k, got_m[k], ref_m[k])
+    assert ((logits > 0) != (want > 0)).mean() <= 1e-3

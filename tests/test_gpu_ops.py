@@ -222,3 +222,120 @@ def test_bn_relu_backward(m, ch):
         off = np.abs(got - want) > 1e-4 * np.abs(want) + 1e-4
         assert off.sum() <= 2 and np.abs(got - want).max() <= 2 * float(da.abs().max()) * 6, off.sum()
     assert np.abs(obias.numpy()).max() <= 1e-3 * max(1.0, scale * m ** 0.5)
+
+
+# ------------------------------------------------------------------ double-tile instantiations
+# conv_igemm_kernel<R,S,16,32,32,4,1>, <8,32,64,4,1>, <16,16,64,4,1> are only selected when a launch has >= 512
+# workgroups of the double tile (dispatch_tiles in conv_mfma.hip) and the arithmetic is native float32 or bf16:
+# these shapes reach them (forward; the dgrad of the mirrored shape reaches them with Cin/Cout swapped).
+BIG_SHAPES = [(16, 128, 128, 32, 32), (8, 128, 128, 32, 64), (64, 16, 16, 128, 512), (8, 128, 128, 64, 32)]
+
+
+@pytest.mark.parametrize("shape", BIG_SHAPES)
+def test_conv3x3_double_tile_kernels(shape):
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(101 + cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    dy = torch.randn(n, cout, h, w, generator=g)
+    xin = torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    y = F.conv2d(xin, wt, b, padding=1)
+    y.backward(dy)
+    c = ctx()
+    dx, dw, db, ddy = c.to_device(nhwc(x)), c.to_device(wt.numpy()), c.to_device(b.numpy()), c.to_device(nhwc(dy))
+    dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
+    for impl in (IMPL_MFMA, IMPL_X3):
+        out = c.empty((n, h, w, cout))
+        check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout, P(dsc), P(dsh), 1, P(out)))
+        assert rel_err(out.numpy(), nhwc(y.detach())) <= TOL, f"fwd impl={impl}"
+        gx = c.empty((n, h, w, cin))
+        check(lib.rfi_op_conv3x3_dgrad(c.handle, impl, P(ddy), n, h, w, cout, P(dw), cin, P(gx)))
+        assert rel_err(gx.numpy(), nhwc(xin.grad)) <= TOL, f"dgrad impl={impl}"
+
+
+# ------------------------------------------------------------------ adversarial inputs of the 3 x bf16 split
+def _wide(shape, g, lo, hi):
+    """randn scaled by 2^k, k uniform in [lo, hi]: a dynamic range no randn draw has."""
+    k = torch.randint(lo, hi + 1, shape, generator=g).double()
+    return (torch.randn(shape, generator=g).double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), k)).float()
+
+
+@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3])
+def test_conv3x3_wide_dynamic_range_and_cancellation(impl):
+    """The float32-by-3xbf16 arithmetic claims ONE float32 rounding per product (the three dropped piece
+    products are <= 2^-24 |a b|), for any finite operands, not just randn.  Operands spanning 2^-60 .. 2^60
+    and channel pairs that cancel EXACTLY in exact arithmetic (x equal, weights opposite): the error against
+    float64 is bounded per output by a few float32 roundings of sum |a||b| -- the same bound the native
+    float32 MFMA (an fmaf chain) is held to."""
+    n, h, w, cin, cout = 2, 16, 16, 32, 32
+    g = torch.Generator().manual_seed(77)
+    x = _wide((n, cin, h, w), g, -60, 60)
+    wt = _wide((cout, cin, 3, 3), g, -30, 30)
+    x[:, 1::2] = x[:, 0::2]                       # channel pairs (2k, 2k+1): same input ...
+    wt[:, 1::2] = -wt[:, 0::2]                    # ... opposite weights: every pair cancels exactly
+    x[0, :, 5, 5] = _wide((cin,), g, -60, 60)     # except where the pairing is broken at one pixel
+    want = F.conv2d(x.double(), wt.double(), None, padding=1)
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1)        # sum |a||b|
+    cancel = torch.ones(n, cout, h, w, dtype=torch.bool)                          # exact result is 0 there
+    cancel[0, :, 4:7, 4:7] = False
+    want[cancel] = 0.0                            # (float64 summation leaves ~2^-53 residues of its own)
+    c = ctx()
+    dx, dw = c.to_device(nhwc(x)), c.to_device(wt.numpy())
+    out = c.empty((n, h, w, cout))
+    check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), None, cout, None, None, 0, P(out)))
+    got = torch.from_numpy(out.numpy()).permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    err = ((got - want).abs() / (bound + 1e-300)).max().item()
+    # K = 288 products: an fmaf chain may lose up to K * 2^-24 of sum|ab| in the worst case, a few 2^-24 typically
+    assert err <= 16 * 2.0 ** -24, err
+    # where everything cancels the result must be tiny against the operands, not a stale piece product
+    assert (got[cancel].abs() <= 16 * 2.0 ** -24 * bound[cancel]).all()
+
+
+@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3])
+def test_conv3x3_non_finite_lanes(impl):
+    """An inf and a NaN in the input: every output whose 3x3 window contains one of them must come out
+    non-finite, every other output must be unaffected.  (The split path turns inf into NaN -- inf - inf in the
+    residual -- so 'non-finite' is the contract, not the kind; documented in DESIGN.md.)"""
+    n, h, w, cin, cout = 1, 16, 16, 16, 32
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 12
+    clean = F.conv2d(x, wt, None, padding=1)
+    x[0, 3, 4, 4] = float("inf")
+    x[0, 9, 10, 12] = float("nan")
+    c = ctx()
+    dx, dw = c.to_device(nhwc(x)), c.to_device(wt.numpy())
+    out = c.empty((n, h, w, cout))
+    check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), None, cout, None, None, 0, P(out)))
+    got = out.numpy()[0]                                      # (h, w, cout)
+    bad = np.zeros((h, w), bool)
+    bad[3:6, 3:6] = True
+    bad[9:12, 11:14] = True
+    assert not np.isfinite(got[bad]).any()
+    ok = ~bad
+    assert np.isfinite(got[ok]).all()
+    assert rel_err(got[ok], nhwc(clean)[0][ok]) <= TOL
+
+
+@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3])
+def test_conv3x3_tiny_operands_underflow(impl):
+    """Operands near the bottom of the float32 range: the low bf16 pieces underflow (bf16 shares float32's
+    exponent range), which may cost relative accuracy only where the PRODUCTS are themselves subnormal; results
+    must stay finite and within an absolute 2^-126-scale error plus the usual relative bound."""
+    n, h, w, cin, cout = 1, 8, 8, 16, 32
+    g = torch.Generator().manual_seed(79)
+    x = _wide((n, cin, h, w), g, -100, -80)
+    wt = _wide((cout, cin, 3, 3), g, -20, 10)
+    want = F.conv2d(x.double(), wt.double(), None, padding=1)
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1)
+    c = ctx()
+    dx, dw = c.to_device(nhwc(x)), c.to_device(wt.numpy())
+    out = c.empty((n, h, w, cout))
+    check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), None, cout, None, None, 0, P(out)))
+    got = torch.from_numpy(out.numpy()).permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    assert ((got - want).abs() <= 16 * 2.0 ** -24 * bound + 144 * 2.0 ** -126).all()

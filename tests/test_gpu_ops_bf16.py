@@ -100,3 +100,31 @@ def test_wgrad_bf16_with_load_transform():
     gw = c.empty((cout, cin, 3, 3))
     check(lib.rfi_op_conv3x3_wgrad(c.handle, BF, P(dx), P(ddy), n, h, w, cin, cout, P(dsc), P(dsh), 1, P(gw)))
     assert rel_err(gw.numpy(), wt.grad.float().numpy()) <= 5e-5
+
+
+# shapes that select the double-tile instantiations of the conv kernel (>= 512 workgroups; see test_gpu_ops.py)
+from test_gpu_ops import BIG_SHAPES  # noqa: E402
+
+
+@pytest.mark.parametrize("shape", BIG_SHAPES)
+def test_conv3x3_double_tile_kernels_bf16(shape):
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(201 + cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = bf(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5))
+    b = torch.randn(cout, generator=g)
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    dy = bf(torch.randn(n, cout, h, w, generator=g))
+    xin = bf(torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None])).double().requires_grad_(True)
+    y = F.conv2d(xin, wt.double(), b.double(), padding=1)
+    y.backward(dy.double())
+    c = ctx()
+    dx, dw, db, ddy = c.to_device(nhwc(x)), c.to_device(wt.numpy()), c.to_device(b.numpy()), c.to_device(nhwc(dy))
+    dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
+    out = c.empty((n, h, w, cout))
+    check(lib.rfi_op_conv3x3(c.handle, BF, P(dx), n, h, w, cin, P(dw), P(db), cout, P(dsc), P(dsh), 1, P(out)))
+    assert rel_err(out.numpy(), nhwc(y.detach().float())) <= TOL
+    gx = c.empty((n, h, w, cin))
+    check(lib.rfi_op_conv3x3_dgrad(c.handle, BF, P(ddy), n, h, w, cout, P(dw), cin, P(gx)))
+    assert rel_err(gx.numpy(), nhwc(xin.grad.float())) <= TOL

@@ -89,3 +89,35 @@ def test_training_loop_reduces_loss_and_writes_reference_checkpoints(tmp_path):
     hist2 = train_rfi_model(UNet(3, 1, 8), (x[:6], y[:6]), (x[6:], y[6:]), num_epochs=7, batch_size=2, lr=1e-3,
                             resume_from=str(tmp_path / "ckpt" / best), log=lambda s: None)
     assert hist2[0]["epoch"] == int(best.split("_")[-1].split(".")[0]) + 1
+
+
+def test_reference_shards_straight_to_hbm_and_one_step(golden_dir):
+    """the reference-written shard fixture goes from the memory-mapped .pt files straight into one
+    NHWC device buffer pair (`load_batches_device`), bit-identical to the host loader, and a training step run
+    from those device buffers equals the step run from the host tensors and the CPU oracle."""
+    from collections import OrderedDict as OD
+
+    from oracle import unet_ref
+    from rfi_toolbox_amd._lib import Hyper
+    from rfi_toolbox_amd.datasets import load_batches, load_batches_device
+    d = os.path.join(golden_dir, "ref_shards")
+    host = load_batches(d)
+    d_img, d_lab, meta = load_batches_device(d, device=0)
+    assert d_img.shape == (16, 32, 32, 3) and d_lab.shape == (16, 32, 32) and meta["num_batches"] == 4
+    np.testing.assert_array_equal(d_img.numpy(), host.images.numpy())
+    np.testing.assert_array_equal(d_lab.numpy(), host.labels.numpy())
+    torch.manual_seed(13)
+    a = UNet(3, 1, 8).train()
+    st0 = a.state_dict()
+    b = UNet(3, 1, 8).load_state_dict(st0).train()
+    la = a.train_step(host.images, host.labels, lr=1e-3)                       # host tensors in
+    b.train_step_async(d_img.ptr, d_lab.ptr, 16, 32, 32, Hyper(1e-3, 0.9, 0.999, 1e-8, 1e-5, 1.0))   # device buffers in
+    lb, _ = b.last_loss()
+    assert la == lb
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    ost = OD((k, v.clone()) for k, v in st0.items())
+    r = unet_ref.train_step(ost, unet_ref.new_adam_state(ost), unet_ref.nhwc_to_nchw(host.images),
+                            host.labels.float().unsqueeze(1), lr=1e-3)
+    assert la == pytest.approx(r["loss"], abs=5e-6)
