@@ -108,6 +108,9 @@ int rfi_ctx_create(int device_id, rfi_ctx** out) {
         RFI_CHECK_HIP(hipEventCreate(&c->t0));
         RFI_CHECK_HIP(hipEventCreate(&c->t1));
         RFI_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 4096, hipHostMallocDefault));
+        c->zero_page = c->alloc(4096);
+        RFI_CHECK_HIP(hipMemsetAsync(c->zero_page, 0, 4096, c->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(c->stream));
         *out = c;
     });
 }

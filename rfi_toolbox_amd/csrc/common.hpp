@@ -104,6 +104,9 @@ struct rfi_ctx {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     void* get_scratch(size_t bytes);
+    // 4 KiB of zeros in HBM: where the LDS-DMA staging of the plane kernels points lanes whose halo pixel
+    // lies outside the image (a DMA lane cannot be zero-filled conditionally)
+    void* zero_page = nullptr;
     // side stream: weight-gradient GEMMs of the backward pass run here, next to the main stream's
     // dgrad / batch-norm chain (model.cpp); `stream` is swapped to it for those launches
     hipStream_t main_stream = nullptr, side_stream = nullptr;

@@ -1,0 +1,102 @@
+// "Plane" activation format and the MFMA kernels that consume it (gfx950).
+//
+// A plane tensor holds an activation as the bf16 pieces the matrix cores consume, laid out so that the
+// contraction kernels stage it with LDS-DMA copies only (no VALU, no registers):
+//
+//     [pixel][chunk = channel / 16][plane p < P][16 channels] bf16        (32 bytes per plane row)
+//
+// P = 1: plain bf16 NHWC (the bf16 compute mode: activations live in HBM as bf16).
+// P = 3: float32 carried as three bf16 pieces, v = h + m + l with h = bf16(v), m = bf16(v - h),
+//        l = bf16(v - h - m) (RNE; 3 x 8 significand bits): the float32-by-3xbf16 arithmetic reads the pieces
+//        straight from HBM instead of splitting every element again in every consumer.
+// Channels are padded with zeros to a multiple of 16.  A tensor is produced ONCE, by the elementwise kernel that
+// materialises the activation anyway (BatchNorm-apply + ReLU, pooling, BatchNorm backward), and read by every
+// contraction that consumes it (forward conv, its weight gradient, the input-gradient conv).
+#pragma once
+#include "kernels.hpp"
+
+namespace rfi {
+
+typedef unsigned short bf16_t;
+
+struct PlaneSeg {                 // one K-segment of a contraction input
+    const bf16_t* p = nullptr;
+    int64_t pstride = 0;          // bf16 elements per pixel (>= nchunks * P * 16)
+    int nchunks = 0;              // 16-channel chunks
+};
+__host__ __device__ static inline int plane_chunks(int C) { return (C + 15) / 16; }
+static inline size_t plane_elems(int64_t pixels, int C, int P) { return (size_t)pixels * plane_chunks(C) * P * 16; }
+
+// ---------------------------------------------------------------- producers
+// fp32 [M][C] view (pstride floats per pixel) -> planes; optional BatchNorm-apply + (Leaky)ReLU in flight
+void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P, bf16_t* out, int64_t out_pstride);
+// planes -> fp32 (tests / debugging): sum of the pieces
+void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, int64_t M, int C, int P, float* out,
+                          int out_pstride);
+
+// ---------------------------------------------------------------- filters in MFMA B-operand order
+// wB[z][tap][kc][cb][plane][lane 0..63][8] bf16: lane (j = lane & 31, lh = lane >> 5) holds filter values of
+// output channel cb*32 + j for input channels 16*kc' + 8*lh + e (kc' = chunk within its segment), so one
+// wave-wide 16-byte load is one whole operand fragment.  Input channels come in up to two K-segments
+// (seg_c[0] + seg_c[1] = Cin of the source), each padded to whole chunks.
+struct WBDesc {
+    const float* src;             // [taps][Cout][Cin] float32 (forward layout or dgrad layout)
+    bf16_t* dst;
+    int taps, Cout, Cin;
+    int seg_c[2];                 // channels per K-segment (seg_c[1] may be 0)
+    int P;
+};
+static inline int wb_kchunks(const WBDesc& d) { return plane_chunks(d.seg_c[0]) + (d.seg_c[1] ? plane_chunks(d.seg_c[1]) : 0); }
+static inline size_t wb_elems(int taps, int Cout, int seg0, int seg1, int P) {
+    const size_t kc = (size_t)plane_chunks(seg0) + (seg1 ? plane_chunks(seg1) : 0);
+    return (size_t)taps * kc * ((Cout + 31) / 32) * P * 512;
+}
+void launch_weights_to_wb(rfi_ctx* ctx, const WBDesc* descs_dev, int n, double total_bytes);   // one block row per desc
+void launch_weights_to_wb_one(rfi_ctx* ctx, const WBDesc& d);                                   // uploads the descriptor itself
+
+// ---------------------------------------------------------------- conv-like contraction on planes
+//   y[n,oy,ox,co] = bias[co] + sum_{tap,ci} X[n, oy*S+r-pad, ox*S+s-pad, ci] * W[tap][co][ci]
+struct PConvArgs {
+    PlaneSeg x[2];
+    int nseg = 1;
+    int P = 3;
+    int N = 0, H = 0, W = 0;          // output grid
+    int Hin = 0, Win = 0;
+    int Cout = 0;
+    const bf16_t* wB = nullptr;
+    const float* bias = nullptr;
+    float* y = nullptr;               // raw float32 NHWC output (pre-BatchNorm), y_pstride floats per pixel
+    int y_pstride = 0;
+    int Hout = 0, Wout = 0;
+    int osy = 1, osx = 1, ooy = 0, oox = 0;
+    int R = 3, S = 1, pad = 1;
+    double* stats = nullptr;          // as ConvArgs::stats
+    int stats_max_records = 0;
+    int stats_records = 0;
+    double algo_flops = -1;
+};
+void launch_pconv(rfi_ctx* ctx, PConvArgs& a);
+
+// ---------------------------------------------------------------- weight gradient on planes
+//   dW[tap][cy][cx] = sum_{n,y,x} Yop[n,y,x,cy] * Xop[n, y*S+r-pad, x*S+s-pad, cx]   (Xop in up to two K-segments)
+struct PWgradArgs {
+    PlaneSeg xop[2];
+    int nseg = 1;
+    int seg_c[2] = {0, 0};            // true channel counts of the Xop segments (Cx = seg_c[0] + seg_c[1])
+    PlaneSeg yop;
+    int Cy = 0;
+    int P = 3;
+    int N = 0, H = 0, W = 0;          // grid of the Yop pixels
+    int Hx = 0, Wx = 0;
+    int R = 3, S = 1, pad = 1;
+    float* dw = nullptr;              // dw[tap*tap_stride + cy*sy + cx*sx]
+    int64_t tap_stride = 0;
+    int sy = 0, sx = 0;
+    float* slab = nullptr;
+    size_t slab_floats = 0;
+    double algo_flops = -1;
+};
+size_t pwgrad_slab_floats(const PWgradArgs& a);
+void launch_pwgrad(rfi_ctx* ctx, const PWgradArgs& a);
+
+}  // namespace rfi

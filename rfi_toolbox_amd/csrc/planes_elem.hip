@@ -1,0 +1,172 @@
+// Producers of the plane format (planes.hpp): activation split (with the producing layer's BatchNorm-apply +
+// activation folded in), filter re-layout into MFMA B-operand order, and the inverse (planes -> float32).
+// All HBM-bound elementwise kernels: 16-byte loads and stores, grid-stride.
+#include "planes.hpp"
+
+namespace rfi {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pair(float a, float b) {       // RNE, v_cvt_pk_bf16_f32
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// v = h + m + l exactly (three RNE bf16 pieces); the same sequence the round-1 kernels ran at staging time
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pair(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = cvt_pair(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = cvt_pair(sa, sb);
+}
+// 8 floats -> P pieces of 8 bf16 (16 bytes each)
+template <int P>
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (P == 3) split_pair(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+        else h[i] = cvt_pair(v[2 * i], v[2 * i + 1]);
+    }
+    out[0] = u32x4{h[0], h[1], h[2], h[3]};
+    if constexpr (P == 3) {
+        out[1] = u32x4{m[0], m[1], m[2], m[3]};
+        out[2] = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+template <int P, bool VEC>
+__global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ x, int xp, int64_t M, int C,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        int relu, float slope, bf16_t* __restrict__ out, int64_t op) {
+    const int groups = plane_chunks(C) * 2;                    // 8-channel groups per pixel (padded)
+    const int64_t total = M * groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const int64_t m = i / groups;
+        const int c0 = g * 8;
+        float v[8];
+        const float* src = x + m * xp + c0;
+        if (VEC && c0 + 8 <= C) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? src[e] : 0.0f;
+        }
+        if (scale) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (c0 + e < C) {
+                    float t = v[e] * scale[c0 + e] + shift[c0 + e];        // product and sum rounded separately (-ffp-contract=off)
+                    if (relu) t = fmaxf(t, t * slope);                       // slope 0: ReLU
+                    v[e] = t;
+                }
+            }
+        }
+        u32x4 pc[3];
+        split8<P>(v, pc);
+        bf16_t* o = out + m * op + (int64_t)(g >> 1) * (P * 16) + (g & 1) * 8;
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(o + p * 16) = pc[p];
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const bf16_t* __restrict__ in, int64_t ip, int64_t M, int C,
+                                                            float* __restrict__ out, int op) {
+    const int64_t total = M * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t m = i / C;
+        const bf16_t* q = in + m * ip + (int64_t)(c >> 4) * (P * 16) + (c & 15);
+        float s = 0.0f;
+#pragma unroll
+        for (int p = P - 1; p >= 0; --p) s += __builtin_bit_cast(float, (unsigned)q[p * 16] << 16);   // small pieces first
+        out[m * op + c] = s;
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void wb_body(const WBDesc& d) {
+    const int kc0 = (d.seg_c[0] + 15) / 16, kc1 = d.seg_c[1] ? (d.seg_c[1] + 15) / 16 : 0;
+    const int nkc = kc0 + kc1, ncb = (d.Cout + 31) / 32;
+    const int64_t total = (int64_t)d.taps * nkc * ncb * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int cb = (int)(r % ncb); r /= ncb;
+        const int kc = (int)(r % nkc);
+        const int tap = (int)(r / nkc);
+        const int j = lane & 31, lh = lane >> 5;
+        const int co = cb * 32 + j;
+        const int seg = kc >= kc0 ? 1 : 0;
+        const int cl = (seg ? kc - kc0 : kc) * 16 + lh * 8;         // channel within the segment
+        const int cbase = seg ? d.seg_c[0] : 0;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = (co < d.Cout && cl + e < d.seg_c[seg]) ? d.src[((int64_t)tap * d.Cout + co) * d.Cin + cbase + cl + e] : 0.0f;
+        u32x4 pc[3];
+        split8<P>(v, pc);
+        bf16_t* o = d.dst + ((((int64_t)tap * nkc + kc) * ncb + cb) * P) * 512 + lane * 8;
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(o + p * 512) = pc[p];
+    }
+}
+__global__ __launch_bounds__(256) void weights_to_wb_kernel(const WBDesc* __restrict__ descs) {
+    const WBDesc d = descs[blockIdx.y];
+    if (d.P == 3) wb_body<3>(d);
+    else wb_body<1>(d);
+}
+
+}  // namespace
+
+void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P, bf16_t* out, int64_t out_pstride) {
+    RFI_REQUIRE(P == 1 || P == 3, "act_split: planes must be 1 or 3");
+    RFI_REQUIRE(M > 0 && C > 0, "act_split: empty tensor");
+    RFI_REQUIRE(out_pstride % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "act_split: unaligned output");
+    const bool vec = (x.pstride % 4 == 0) && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;
+    const int64_t total = M * plane_chunks(C) * 2;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * 4 + (double)total * 16 * P);
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    const int relu = xf.scale ? xf.relu : 0;
+#define RFI_AS(P_, V_)                                                                                        \
+    hipLaunchKernelGGL((act_split_kernel<P_, V_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x.p,  \
+                       x.pstride, M, C, xf.scale, xf.shift, relu, xf.slope, out, out_pstride)
+    if (P == 3) { if (vec) RFI_AS(3, true); else RFI_AS(3, false); }
+    else { if (vec) RFI_AS(1, true); else RFI_AS(1, false); }
+#undef RFI_AS
+    check_launch("act_split");
+}
+
+void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, int64_t M, int C, int P, float* out,
+                          int out_pstride) {
+    const int64_t total = M * C;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * (4 + 2 * P));
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    if (P == 3) hipLaunchKernelGGL(planes_to_f32_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in, in_pstride, M, C, out, out_pstride);
+    else hipLaunchKernelGGL(planes_to_f32_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in, in_pstride, M, C, out, out_pstride);
+    check_launch("planes_to_f32");
+}
+
+void launch_weights_to_wb(rfi_ctx* ctx, const WBDesc* descs_dev, int n, double total_bytes) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, total_bytes);
+    hipLaunchKernelGGL(weights_to_wb_kernel, dim3(64, n), dim3(256), 0, ctx->stream, descs_dev);
+    check_launch("weights_to_wb");
+}
+void launch_weights_to_wb_one(rfi_ctx* ctx, const WBDesc& d) {
+    WBDesc* dev = static_cast<WBDesc*>(ctx->alloc(sizeof(WBDesc)));
+    RFI_CHECK_HIP(hipMemcpyAsync(dev, &d, sizeof(WBDesc), hipMemcpyHostToDevice, ctx->stream));
+    launch_weights_to_wb(ctx, dev, 1, 0);
+    RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));         // &d is the caller's stack; dev is freed here
+    ctx->release(dev);
+}
+
+}  // namespace rfi
