@@ -22,7 +22,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "kernels.hpp"
+#include "planes.hpp"
 
 namespace rfi {
 
@@ -714,6 +714,11 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     if (impl == IMPL_MFMA) RFI_REQUIRE(ok, "conv: shape/alignment not eligible for the MFMA kernel");
     if (impl == IMPL_DIRECT || !ok) {
         launch_conv_direct(ctx, a);
+        return;
+    }
+    // 3x3 stride-1 convolutions in the bf16 / 3 x bf16 arithmetic run on the plane kernels (conv_planes.hip)
+    if ((a.bf16 || a.bf16x3) && a.R == 3 && a.S == 1 && a.zgroups == 1 && !getenv("RFI_OLD_CONV")) {
+        launch_pconv_from_f32(ctx, a, a.bf16x3 ? 3 : 1);
         return;
     }
     // 3 x bf16: the filters are read pre-split (ConvArgs::w3); callers that only have float32 weights (the

@@ -1,0 +1,467 @@
+// NHWC implicit-GEMM "conv-like" contraction on PLANE tensors (planes.hpp) for the gfx950 matrix cores.
+//
+//   y[n,oy,ox,co] = bias[co] + sum_{tap=(r,s)} sum_ci X[n, oy*S+r-pad, ox*S+s-pad, ci] * W[tap][co][ci]
+//
+// GEMM view: M = N*H*W output pixels, N = Cout, K = taps * Cin, computed with v_mfma_f32_32x32x16_bf16:
+//   P = 1  bfloat16 activations and filters, float32 accumulate (one MFMA per 32x32x16 block product);
+//   P = 3  float32 carried as three bf16 pieces (h, m, l): six MFMAs per block product, small terms first
+//          (l*h, m*m, h*l, m*h, h*m, h*h; the three products below 2^-24 of a*b are dropped) -- float32-level
+//          accuracy at 2.7x the native float32 MFMA rate.
+// Both operands arrive in the layout the instruction wants, so staging is pure data movement:
+//   * the input HALO tile ((TH*S+R-S) x (TW*S+R-S) pixels x one 16-channel chunk x P planes) goes HBM/L2 -> LDS
+//     by LDS-DMA (global_load_lds_dwordx4): no registers, no VALU apart from one 32-bit offset per 16-byte
+//     piece; halo pixels outside the image point at a zero area at the end of the tensor.  A pixel row in LDS
+//     is 2P data slots + 1 pad slot of 16 bytes (odd slot stride: the ds_read_b128 of 64 consecutive pixels is
+//     conflict free); every tap reads the same tile at a shifted pixel offset, so the input crosses L2 -> LDS
+//     once per chunk, not taps times;
+//   * the filter tile of the chunk ([tap][32-channel block][plane][64 lanes x 16 B], already in B-operand
+//     order in HBM, planes.hpp) is copied the same way and read back lane-linearly.
+// One workgroup = WM x WN waves, each owning MT x NTL blocks of 32 pixels x 32 channels; workgroups are
+// persistent over an XCD-contiguous range of spatial tiles (neighbouring tiles share halos and filters in one
+// L2).  Staging is single-buffered: two workgroups per CU alternate between their DMA wait and their MFMA phase.
+// The epilogue transposes the accumulators through LDS into 16-byte stores of whole pixel rows, adds the bias and
+// folds the BatchNorm statistics of the output (sum y, sum y^2 per channel; fp64 per workgroup record).
+#include <algorithm>
+
+#include "planes.hpp"
+
+namespace rfi {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+struct PConvDev {
+    PConvArgs a;
+    int nkc, ncb;                    // K chunks (all segments), 32-channel output blocks
+    unsigned x_zero[2];              // byte offset of >= 64 zero bytes inside each segment's allocation
+    unsigned wb_zero;                // ... and inside the filter allocation
+    int diag;                        // RFI_PCONV_DIAG: 1 skip the MFMA phase, 2 skip the DMA (timing experiments only)
+};
+
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G>
+struct PCfg {
+    static constexpr int NW = WM * WN, NT = NW * 64;
+    static constexpr int BM = TH * TW, BN = WN * NTL * 32;
+    static constexpr int HH = TH * S + R - S, HW = TW * S + R - S, HP = HH * HW;
+    static constexpr int NTAP = R * R;
+    static constexpr int RS = 2 * P + 1;                    // 16-byte slots per halo pixel (2P data + 1 pad)
+    static constexpr int ROWB = RS * 16;
+    static constexpr int A_SLOTS = HP * RS;
+    static constexpr int A_ITEMS = (A_SLOTS + NT - 1) / NT;
+    static constexpr int A_BYTES = A_ITEMS * NT * 16;
+    static constexpr int NCBL = BN / 32;
+    static constexpr int B_SLOTS = NTAP * NCBL * P * 64;
+    static constexpr int B_ITEMS = (B_SLOTS + NT - 1) / NT;
+    static constexpr int B_BYTES = B_ITEMS * NT * 16;
+    // [A | B | stats]; the per-wave transpose scratch of the epilogue (16 pixel rows x 36 floats) aliases the staging
+    // area (the epilogue runs between two barriers, when nobody stages or reads)
+    static constexpr int EPI_WAVE_BYTES = 16 * 36 * 4;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int STAT_OFF = STAGE_BYTES > NW * EPI_WAVE_BYTES ? STAGE_BYTES : NW * EPI_WAVE_BYTES;
+    static constexpr int STAT_DOUBLES = NW * NTL * 32 * 2;  // [wave][n-tile][channel][sum, sumsq]
+    static constexpr int LDS_BYTES = STAT_OFF + STAT_DOUBLES * 8;
+    static_assert(BM == WM * MT * 32, "tile pixels must equal the waves' m-tiles");
+    static_assert(32 % TW == 0 || TW % 32 == 0, "TW must divide or be a multiple of 32");
+    static_assert(HW < 4096 && HH < 4096, "halo coordinates are packed in 12 bits");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int P>
+__device__ __forceinline__ f32x16 mma(const bf16x8 (&a)[P], const bf16x8 (&b)[P], f32x16 acc) {
+    if constexpr (P == 3) {            // pieces: [0] = h, [1] = m, [2] = l; small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// Two workgroups per CU alternate between their DMA wait and their MFMA phase (staging is single-buffered; the
+// other workgroup's MFMAs, LDS reads and output stores fill the wait).  A workgroup walks its tiles in GROUPS of
+// G: for each K chunk the filter tile is staged ONCE and used by the G tiles of the group (G sets of
+// accumulators), so the filter traffic per MFMA drops G-fold.
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G>
+__global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
+    using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G>;
+    const PConvArgs& a = d.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- persistent workgroup: blocks b and b+8 share an XCD (round-robin dispatch), so each XCD label gets
+    // one contiguous range of tiles and its workgroups stride through it
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int ntiles = a.N * tiles_y * tiles_x;
+    const int GX = gridDim.x;
+    int t_begin, t_count, j, gx;
+    if (GX >= 8 && (GX & 7) == 0) {
+        const int xcd = blockIdx.x & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+        j = blockIdx.x >> 3;
+        gx = GX >> 3;
+        t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        t_count = q8 + (xcd < r8 ? 1 : 0);
+    } else {
+        j = blockIdx.x; gx = GX; t_begin = 0; t_count = ntiles;
+    }
+    const int my_tiles = (j < t_count) ? (t_count - j + gx - 1) / gx : 0;
+    const int cb0 = blockIdx.y * C::NCBL, n0 = cb0 * 32;
+    double* const st_out = a.stats ? a.stats + ((size_t)blockIdx.x * a.Cout + n0) * 2 : nullptr;
+    if (my_tiles == 0) {                             // uniform for the workgroup, before any barrier
+        if (st_out && tid < C::BN && n0 + tid < a.Cout) st_out[tid * 2] = st_out[tid * 2 + 1] = 0.0;
+        return;
+    }
+    double* const s_stat = reinterpret_cast<double*>(smem + C::STAT_OFF);
+    if (st_out)
+        for (int i = tid; i < C::STAT_DOUBLES; i += C::NT) s_stat[i] = 0.0;   // visible after the first barrier below
+
+    // ---- DMA descriptors.  Slot s = it * NT + tid of a staging image; a wave-instruction writes the 64
+    // consecutive slots [it * NT + wave * 64, +64): LDS address = wave-uniform base + lane * 16.
+    unsigned a_rc[C::A_ITEMS];                       // halo row << 16 | piece << 12 | halo column (tile independent)
+#pragma unroll
+    for (int it = 0; it < C::A_ITEMS; ++it) {
+        const int s = it * C::NT + tid, pix = s / C::RS, piece = s % C::RS;
+        a_rc[it] = (pix < C::HP && piece < 2 * P) ? ((unsigned)(pix / C::HW) << 16) | ((unsigned)piece << 12) | (unsigned)(pix % C::HW)
+                                                  : 0x7fff0000u;
+    }
+    unsigned b_off[C::B_ITEMS];                      // byte offset of the slot's source in wB for chunk 0
+    const unsigned wb_chunk = (unsigned)d.ncb * P * 1024;           // bytes per K chunk
+#pragma unroll
+    for (int it = 0; it < C::B_ITEMS; ++it) {
+        int r = (it * C::NT + tid) >> 6;
+        const int plane = r % P; r /= P;
+        const int cbl = r % C::NCBL, tap = r / C::NCBL;
+        b_off[it] = (tap < C::NTAP && cb0 + cbl < d.ncb)
+                        ? (unsigned)(((tap * d.nkc) * d.ncb + cb0 + cbl) * P + plane) * 1024u + (unsigned)lane * 16u
+                        : 0xffffffffu;
+    }
+
+    struct Tile { int n, oy0, ox0; };
+    auto tile_of = [&](int k) {
+        const int t = t_begin + j + k * gx;
+        Tile r;
+        r.ox0 = (t % tiles_x) * TW;
+        r.oy0 = ((t / tiles_x) % tiles_y) * TH;
+        r.n = t / (tiles_x * tiles_y);
+        return r;
+    };
+    auto issue_A = [&](int k, int kc) {              // halo tile of chunk kc of this workgroup's k-th tile
+        const Tile t = tile_of(k);
+        const int seg = kc >= a.x[0].nchunks ? 1 : 0;
+        const unsigned coff = (unsigned)(seg ? kc - a.x[0].nchunks : kc) * (P * 32);
+        const unsigned ps = (unsigned)a.x[seg].pstride * 2u;
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x[seg].p);
+        const unsigned xz = d.x_zero[seg];
+        const int iy0 = t.oy0 * S - a.pad, ix0 = t.ox0 * S - a.pad, nb = t.n * a.Hin;
+        unsigned char* dst = smem;
+#pragma unroll
+        for (int it = 0; it < C::A_ITEMS; ++it) {
+            const int iy = iy0 + (int)(a_rc[it] >> 16), ix = ix0 + (int)(a_rc[it] & 0xfff);
+            const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;   // 0x7fff rows fail
+            const unsigned off = ok ? (unsigned)((nb + iy) * a.Win + ix) * ps + ((a_rc[it] >> 12) & 0xf) * 16u + coff : xz;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xb + off), (lds_void*)(dst + (it * C::NT + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    auto issue_B = [&](int kc) {
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.wB);
+        const unsigned koff = (unsigned)kc * wb_chunk;
+        unsigned char* dst = smem + C::A_BYTES;
+#pragma unroll
+        for (int it = 0; it < C::B_ITEMS; ++it) {
+            const unsigned off = b_off[it] != 0xffffffffu ? b_off[it] + koff : d.wb_zero;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wb + off), (lds_void*)(dst + (it * C::NT + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses (bytes)
+    int a_base[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = (wm * MT + mt) * 32 + li;
+        const int ty = p / TW, tx = p % TW;
+        a_base[mt] = ((ty * S) * C::HW + tx * S) * C::ROWB + lh * 16;
+    }
+    const int b_base = ((wn * NTL) * P * 64 + lane) * 16;
+
+    f32x16 acc[G][MT][NTL];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][mt][nt][r] = 0.0f;
+
+    const bool vec_out = (a.Cout & 3) == 0 && (a.y_pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+    // the bias of this lane's output channels, loaded ONCE: an ordinary global load inside the loop would make
+    // the compiler drain the whole vector-memory queue (DMA prefetch and output stores included) at its use
+    f32x4 bias4[NTL];
+    float bias1[NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int co0 = n0 + (wn * NTL + nt) * 32;
+        bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bias1[nt] = 0.0f;
+        if (a.bias) {
+            const int co = co0 + (lane & 7) * 4;
+            if (vec_out && co < a.Cout) bias4[nt] = *reinterpret_cast<const f32x4*>(a.bias + co);
+            if (!vec_out && co0 + li < a.Cout) bias1[nt] = a.bias[co0 + li];
+        }
+        // opaque to the compiler from here on: otherwise it re-loads the (invariant) bias at every use instead of
+        // keeping 5 registers, and each of those loads drains the vector-memory queue
+        asm volatile("" : "+v"(bias4[nt].x), "+v"(bias4[nt].y), "+v"(bias4[nt].z), "+v"(bias4[nt].w), "+v"(bias1[nt]));
+    }
+    // ---- epilogue of one tile.  C/D layout of 32x32: col = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2)
+    // + 4 * (lane >> 5) (pixel).  Each 32x32 block is transposed through this wave's private LDS scratch and leaves
+    // as 4 x 16-byte-per-lane stores of whole 128-byte pixel rows; BatchNorm statistics are folded on the way.
+    auto epilogue = [&](const Tile& ct, f32x16 (&ac)[MT][NTL], float* s_ep) {
+        const int xs = a.osx * a.y_pstride;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            const int co0 = n0 + (wn * NTL + nt) * 32;
+            f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = p1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int oyb = ct.oy0 + ((wm * MT + mt) * 32) / TW;
+                const int oxb = ct.ox0 + ((wm * MT + mt) * 32) % TW;
+                if (vec_out) {
+                    const int g4 = (lane & 7) * 4;
+                    const int co = co0 + g4;
+                    const f32x4 b4 = bias4[nt];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {          // pixel rows 16 * half .. + 15 of the block
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            s_ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = ac[mt][nt][half * 8 + r];
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps) {
+                            const int pl = ps * 8 + (lane >> 3);
+                            const int pp = half * 16 + pl;
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pl * 36 + g4) + b4;
+                            const int oy = oyb + pp / TW, ox = oxb + pp % TW;
+                            if (co < a.Cout && oy < a.H && ox < a.W) {
+                                *reinterpret_cast<f32x4*>(
+                                    a.y + (unsigned)(((ct.n * a.Hout + oy * a.osy + a.ooy) * a.Wout + ox * a.osx + a.oox) *
+                                                         a.y_pstride + co)) = v;
+                                if (st_out) {
+                                    p1 += v;
+                                    p2 += v * v;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    const int co = co0 + li;
+                    const bool cok = co < a.Cout;
+                    const float bv = bias1[nt];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pp = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int oy = oyb + pp / TW, ox = oxb + pp % TW;
+                        if (cok && oy < a.H && ox < a.W)
+                            a.y[(unsigned)(((ct.n * a.Hout + oy * a.osy + a.ooy) * a.Wout + a.oox) * a.y_pstride + co) +
+                                (unsigned)(ox * xs)] = ac[mt][nt][r] + bv;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ac[mt][nt][r] = 0.0f;
+            }
+            if (st_out && vec_out) {
+                // lanes l, l^8, l^16, l^32 hold the same 4 channels of different pixels: fold them
+                // (<= 128 fp32 terms per channel), then continue in fp64 in this wave's LDS slots
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        p1[e] += __shfl_xor(p1[e], o, 64);
+                        p2[e] += __shfl_xor(p2[e], o, 64);
+                    }
+                }
+                if (lane < 8) {
+                    double* dd = s_stat + ((wave * NTL + nt) * 32 + lane * 4) * 2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dd[e * 2] += (double)p1[e];
+                        dd[e * 2 + 1] += (double)p2[e];
+                    }
+                }
+            }
+        }
+    };
+    auto epilogue_group = [&](int g0) {
+        float* s_ep = reinterpret_cast<float*>(smem + wave * C::EPI_WAVE_BYTES);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (g0 + g < my_tiles) epilogue(tile_of(g0 + g), acc[g], s_ep);
+    };
+
+    const unsigned char* const sA = smem;
+    const unsigned char* const sB = smem + C::A_BYTES;
+    for (int g0 = 0; g0 < my_tiles; g0 += G) {
+        const int gcount = my_tiles - g0 < G ? my_tiles - g0 : G;
+        for (int kc = 0; kc < d.nkc; ++kc) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g < gcount) {
+                    if (!(d.diag & 2) || (g0 == 0 && kc == 0 && g == 0)) {
+                        issue_A(g0 + g, kc);
+                        if (g == 0) issue_B(kc);     // the filter tile of the chunk serves every tile of the group
+                    }
+                    __syncthreads();                 // s_waitcnt vmcnt(0) + barrier: every wave's pieces have landed
+                    if (!(d.diag & 1)) {
+#pragma unroll
+                        for (int tap = 0; tap < C::NTAP; ++tap) {
+                            const int tr = tap / R, ts = tap % R;
+                            bf16x8 bf[NTL][P];
+#pragma unroll
+                            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                                for (int p = 0; p < P; ++p)
+                                    bf[nt][p] = *reinterpret_cast<const bf16x8*>(sB + b_base + ((tap * C::NCBL + nt) * P + p) * 1024);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) {
+                                bf16x8 af[P];
+#pragma unroll
+                                for (int p = 0; p < P; ++p)
+                                    af[p] = *reinterpret_cast<const bf16x8*>(sA + a_base[mt] + (tr * C::HW + ts) * C::ROWB + p * 32);
+#pragma unroll
+                                for (int nt = 0; nt < NTL; ++nt) acc[g][mt][nt] = mma<P>(af, bf[nt], acc[g][mt][nt]);
+                            }
+                        }
+                    }
+                    __syncthreads();                 // every wave is done reading the halo tile (and, after the last tile
+                }                                    // of the group, the filter tile)
+            }
+        }
+        epilogue_group(g0);
+        __syncthreads();                             // the staging area (aliased by the scratch) is about to be overwritten
+    }
+    if (st_out) {
+        __syncthreads();
+        if (tid < C::BN && n0 + tid < a.Cout) {      // channel tid of the tile: waves (m, wn_c) cover it
+            const int wn_c = tid / (NTL * 32), nt_c = (tid % (NTL * 32)) / 32, cl = tid % 32;
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                const double* dd = s_stat + (((m * WN + wn_c) * NTL + nt_c) * 32 + cl) * 2;
+                t1 += dd[0];
+                t2 += dd[1];
+            }
+            st_out[tid * 2] = t1;
+            st_out[tid * 2 + 1] = t2;
+        }
+    }
+}
+
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G>
+void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
+    using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G>;
+    PConvArgs& a = d.a;
+    const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
+    const int ychunks = (int)cdiv(d.ncb, C::NCBL);
+    const size_t lds = C::LDS_BYTES;
+    // persistent grid: about (256 CUs x resident workgroups) workgroups in total, a multiple of 8 along x, tiles
+    // spread evenly over the workgroups of each XCD label
+    int occ = (int)((160 * 1024) / lds);
+    occ = occ < 1 ? 1 : (occ > 2 ? 2 : occ);
+    const int gmax = std::max(8, (256 * occ) / ychunks);
+    const int tx = (int)cdiv(ntiles, 8);
+    const int per = (int)cdiv(tx, std::max(1, gmax / 8));
+    int GX = 8 * (int)cdiv(tx, per);
+    if (ntiles < 8) GX = ntiles;
+    const bool vec_out = (a.Cout & 3) == 0 && (a.y_pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+    if (a.stats && vec_out && GX <= a.stats_max_records) a.stats_records = GX;
+    else { a.stats = nullptr; a.stats_records = 0; }
+    static PerDeviceOnce attr_once;
+    attr_once.run(ctx->device, [&] {
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    });
+    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+    check_launch("pconv");
+}
+
+template <int P>
+void dispatch(rfi_ctx* ctx, PConvDev& d) {
+    const PConvArgs& a = d.a;
+    if (a.W >= 32) launch_cfg<3, 1, 8, 32, 4, 1, 2, 1, P, 2>(ctx, d);
+    else if (a.W >= 16) launch_cfg<3, 1, 16, 16, 4, 1, 2, 1, P, 2>(ctx, d);
+    else launch_cfg<3, 1, 8, 8, 2, 2, 1, 1, P, 2>(ctx, d);
+}
+
+}  // namespace
+
+void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
+    RFI_REQUIRE(a.P == 1 || a.P == 3, "pconv: planes must be 1 or 3");
+    RFI_REQUIRE(a.R == 3 && a.S == 1 && a.pad == 1, "pconv: 3x3 stride-1 convolutions only");
+    RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cout > 0 && a.nseg >= 1 && a.nseg <= 2, "pconv: empty shape");
+    PConvDev d;
+    d.a = a;
+    d.nkc = a.x[0].nchunks + (a.nseg > 1 ? a.x[1].nchunks : 0);
+    d.ncb = (a.Cout + 31) / 32;
+    if (a.nseg == 1) d.a.x[1] = PlaneSeg{a.x[0].p, a.x[0].pstride, 0};
+    const int64_t pix = (int64_t)a.N * a.Hin * a.Win;
+    for (int s = 0; s < 2; ++s) {
+        const int64_t bytes = pix * d.a.x[s].pstride * 2;
+        RFI_REQUIRE(bytes + 64 < ((int64_t)1 << 32), "pconv: input tensor too large for 32-bit byte offsets");
+        d.x_zero[s] = (unsigned)bytes;                 // every plane tensor is allocated with a zeroed 64-byte tail
+    }
+    const int64_t wbytes = (int64_t)wb_elems(9, a.Cout, 16 * a.x[0].nchunks, a.nseg > 1 ? 16 * a.x[1].nchunks : 0, a.P) * 2;
+    RFI_REQUIRE(wbytes + 64 < ((int64_t)1 << 32), "pconv: filter tensor too large");
+    d.wb_zero = (unsigned)wbytes;                      // ... and so is every wB tensor
+    static const int diag = getenv("RFI_PCONV_DIAG") ? atoi(getenv("RFI_PCONV_DIAG")) : 0;
+    d.diag = diag;
+    RFI_REQUIRE((int64_t)a.N * a.Hout * a.Wout * a.y_pstride < (int64_t)1 << 31, "pconv: output too large for 32-bit offsets");
+    const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cout * 9 * 16.0 * d.nkc;
+    std::string label;
+    if (ctx->profiling)
+        label = "pconv N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" + std::to_string(a.W) + " k" +
+                std::to_string(d.nkc * 16) + "->" + std::to_string(a.Cout) + (a.P == 3 ? " 3xbf16" : " bf16");
+    ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0, label);
+    if (a.P == 3) dispatch<3>(ctx, d);
+    else dispatch<1>(ctx, d);
+    a.stats = d.a.stats;
+    a.stats_records = d.a.stats_records;
+}
+
+// Bridge for callers that hold float32 NHWC tensors (the kernel-level C ABI): split the input (with its load
+// transform) and the filters into temporary plane tensors, run the plane kernel, free the temporaries.
+void launch_pconv_from_f32(rfi_ctx* ctx, ConvArgs& c, int P) {
+    RFI_REQUIRE(c.R == 3 && c.S == 1 && c.pad == 1 && c.zgroups == 1, "pconv bridge: 3x3 stride-1 only");
+    const int64_t pix = (int64_t)c.N * c.Hin * c.Win;
+    const size_t xe = plane_elems(pix, c.Cin, P), we = wb_elems(9, c.Cout, c.Cin, 0, P);
+    bf16_t* xp = static_cast<bf16_t*>(ctx->alloc(xe * 2 + 64));
+    bf16_t* wb = static_cast<bf16_t*>(ctx->alloc(we * 2 + 64));
+    struct Free {
+        rfi_ctx* c; void* a; void* b;
+        ~Free() { (void)hipStreamSynchronize(c->stream); try { c->release(a); c->release(b); } catch (...) {} }
+    } fr{ctx, xp, wb};
+    RFI_CHECK_HIP(hipMemsetAsync(reinterpret_cast<char*>(xp) + xe * 2, 0, 64, ctx->stream));
+    RFI_CHECK_HIP(hipMemsetAsync(reinterpret_cast<char*>(wb) + we * 2, 0, 64, ctx->stream));
+    const int64_t ps = (int64_t)plane_chunks(c.Cin) * P * 16;
+    launch_act_split(ctx, c.x, pix, c.Cin, c.xf, P, xp, ps);
+    launch_weights_to_wb_one(ctx, WBDesc{c.w, wb, 9, c.Cout, c.Cin, {c.Cin, 0}, P});
+    PConvArgs a;
+    a.x[0] = PlaneSeg{xp, ps, plane_chunks(c.Cin)};
+    a.nseg = 1; a.P = P;
+    a.N = c.N; a.H = c.H; a.W = c.W; a.Hin = c.Hin; a.Win = c.Win; a.Cout = c.Cout;
+    a.wB = wb; a.bias = c.bias;
+    a.y = c.y.p; a.y_pstride = c.y.pstride;
+    a.Hout = c.Hout; a.Wout = c.Wout; a.osy = c.osy; a.osx = c.osx; a.ooy = c.ooy; a.oox = c.oox;
+    a.stats = c.stats; a.stats_max_records = c.stats_max_records;
+    a.algo_flops = c.algo_flops >= 0 ? c.algo_flops : 2.0 * c.N * c.H * c.W * (double)c.Cout * 9 * c.Cin;
+    launch_pconv(ctx, a);
+    c.stats = a.stats;
+    c.stats_records = a.stats_records;
+}
+
+}  // namespace rfi

@@ -76,6 +76,7 @@ struct PConvArgs {
     double algo_flops = -1;
 };
 void launch_pconv(rfi_ctx* ctx, PConvArgs& a);
+void launch_pconv_from_f32(rfi_ctx* ctx, ConvArgs& c, int P);     // float32 tensors in: temporary plane copies
 
 // ---------------------------------------------------------------- weight gradient on planes
 //   dW[tap][cy][cx] = sum_{n,y,x} Yop[n,y,x,cy] * Xop[n, y*S+r-pad, x*S+s-pad, cx]   (Xop in up to two K-segments)
