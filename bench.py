@@ -28,10 +28,14 @@ PEAK_HBM_GBS = 8000.0
 # `roofline.peak` is the peak of the INSTRUCTION the dominant kernel issues, in units of the algorithmic FLOPs it
 # is credited with: the default float32 path issues six v_mfma_f32_32x32x16_bf16 per 32x32x16 block product
 # (3 x bf16 splitting), so its ceiling is 2516 / 6 = 419.3 TFLOP/s of float32 work.
-PEAK_BY_DTYPE = {"f32": PEAK_BF16_MFMA_TFLOPS / 6, "f32mfma": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS / 2}
+PEAK_BY_DTYPE = {"f32": PEAK_BF16_MFMA_TFLOPS / 6, "f32planes": PEAK_BF16_MFMA_TFLOPS / 6, "f32mfma": PEAK_F32_MFMA_TFLOPS,
+                 "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16regs": PEAK_BF16_MFMA_TFLOPS / 2}
 INSTR_BY_DTYPE = {"f32": "6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block product (float32 by 3 x bf16 splitting)",
-                  "f32mfma": "v_mfma_f32_32x32x2_f32",
-                  "bf16": "v_mfma_f32_32x32x8_bf16 (half the rate of the 32x32x16 form: 1258 TFLOP/s)"}
+                  "f32planes": "6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block product (pre-split plane tensors)",
+                  "f32mfma": "v_mfma_f32_32x32x2_f32", "bf16": "v_mfma_f32_32x32x16_bf16",
+                  "bf16regs": "v_mfma_f32_32x32x8_bf16 (half the rate of the 32x32x16 form: 1258 TFLOP/s)"}
+MODE_BY_DTYPE = {"f32": "float32", "f32mfma": "float32_mfma", "bf16": "bfloat16", "f32planes": "float32_planes",
+                 "bf16regs": "bfloat16_regs"}
 
 
 def usable_cpus():
@@ -137,10 +141,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="patches per GPU per step")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--features", type=int, default=None)
-    ap.add_argument("--dtype", choices=("f32", "f32mfma", "bf16"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "f32mfma", "bf16", "f32planes", "bf16regs"), default="f32",
                     help="f32 (default): float32 contractions by 3 x bf16 splitting (float32-level accuracy, six "
                          "bf16 MFMAs per product block); f32mfma: native float32 MFMA; bf16: operands rounded to "
-                         "bfloat16, float32 accumulate/storage (the reference's autocast mode on a GPU)")
+                         "bfloat16 and activations stored as bf16, float32 accumulate / BatchNorm / optimiser (the "
+                         "reference's autocast mode on a GPU); f32planes: the default arithmetic on pre-split plane "
+                         "tensors; bf16regs: round 1's bf16 mode (float32 storage)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-csv", default=None, help="write the per-launch HIP-event profile here")
@@ -189,7 +195,7 @@ def main():
     else:
         model = UNet(3, 1, args.features, device=local_rank)
     model.train()
-    model.set_compute_dtype({"f32": "float32", "f32mfma": "float32_mfma", "bf16": "bfloat16"}[args.dtype])
+    model.set_compute_dtype(MODE_BY_DTYPE[args.dtype])
     log("model built")
     B, S = args.batch, args.size
     # synthetic waterfalls -> views/tiling -> 3-channel patches + labels, generated and kept in HBM
@@ -267,7 +273,7 @@ def main():
     # same command, and labelled as such
     import glob
     tag = {"unet": "", "cnn3": "_cnn3", "unet1024": "_unet1024"}[args.workload] + \
-          {"f32": "", "f32mfma": "_f32mfma", "bf16": "_bf16"}[args.dtype]
+          ("" if args.dtype == "f32" else "_" + args.dtype)
     traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic{tag}.json")))
     if traffic_files:
         try:
@@ -287,7 +293,7 @@ def main():
                     avg_launch_ms=round(fam[dom]["ms"] / fam[dom]["launches"], 5),
                     launches_per_step=fam[dom]["launches"] / args.profile_steps,
                     algorithmic_flops_per_launch=fam[dom]["flops"] / fam[dom]["launches"])
-        if args.dtype == "f32":    # secondary: the same float32 work against what the native float32 MFMA could do
+        if args.dtype in ("f32", "f32planes"):    # secondary: the same float32 work against what the native float32 MFMA could do
             roof["vs_native_f32_mfma_peak_157.3"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
         if not roof["frac"] <= 1.0:
             raise SystemExit(f"roofline fraction {roof['frac']} > 1: wrong peak for the instruction stream")
@@ -296,7 +302,7 @@ def main():
         "metric": ("training patches/sec (128x128x3)" if S == 128 else f"training samples/sec ({S}x{S}x3)"),
         "value": round(value, 2), "unit": "patches/s" if S < 512 else "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"f32": "f32", "f32mfma": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype.startswith("bf16") else "f32", "data": "synthetic",
         "config": {"workload": {
             "unet": f"UNet(3,1,{args.features}) train step (fwd+BCE/dice+bwd+clip+Adam), "
                     f"batch {B}/GPU x {S}x{S}x3 NHWC fp32, BASELINE configs[1] shape on the "
@@ -308,8 +314,11 @@ def main():
                         "(BASELINE configs[2] shape on the reference's U-Net)"}[args.workload],
                    "arithmetic": {"f32": "float32 (contractions by 3 x bf16 splitting, float32-level accuracy; "
                                          "--dtype f32mfma selects the native float32 MFMA)",
+                                  "f32planes": "float32 (3 x bf16 pieces, pre-split plane tensors, LDS-DMA staging)",
                                   "f32mfma": "float32 (native v_mfma_f32_32x32x2_f32)",
-                                  "bf16": "bfloat16 MFMA operands, float32 accumulate and storage"}[args.dtype],
+                                  "bf16": "bfloat16 activations in HBM and bf16 MFMA operands, float32 accumulate, "
+                                          "float32 BatchNorm / loss / optimiser state",
+                                  "bf16regs": "bfloat16 MFMA operands rounded in registers, float32 storage"}[args.dtype],
                    "global_batch": B * world, "patch": [S, S, 3], "parallelism": f"dp{world}",
                    "params": model.num_parameters()},
         "roofline": roof,

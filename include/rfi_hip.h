@@ -266,8 +266,9 @@ int rfi_threshold_logits(rfi_ctx* ctx, const float* logits_dev, int64_t count, f
 /* ---- kernel-level entry points (device pointers only).  Used by the parity tests to
  *      check each HIP kernel against the oracle in isolation.  impl: 0 auto, 1 direct VALU,
  *      2 MFMA implicit GEMM in native float32 (v_mfma_f32_32x32x2_f32), 3 MFMA implicit GEMM with bfloat16
- *      operands (the bf16 compute mode), 4 MFMA implicit GEMM, float32 by 3 x bf16 splitting (the models'
- *      default arithmetic). ---- */
+ *      operands rounded in registers, 4 MFMA implicit GEMM, float32 by 3 x bf16 splitting in registers (the
+ *      models' default arithmetic), 5 / 6 the plane kernels (bf16 pieces staged by LDS-DMA from plane tensors;
+ *      3x3 convolutions) in the 3 x bf16 / bf16 arithmetic -- the kernels of the bfloat16 compute mode. ---- */
 int rfi_op_conv3x3(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
                    const float* w_oihw, const float* bias, int cout,
                    const float* in_scale, const float* in_shift, int in_relu, float* y);

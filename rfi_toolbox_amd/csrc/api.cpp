@@ -547,10 +547,13 @@ int rfi_model_set_activation(rfi_model* m, float negative_slope) {
 }
 int rfi_model_set_compute_dtype(rfi_model* m, int dtype) {
     return guarded([&] {
-        RFI_REQUIRE(dtype >= 0 && dtype <= 2, "set_compute_dtype: 0 (native float32 MFMA), 1 (bfloat16 operands) or "
-                                              "2 (float32 by 3 x bfloat16 splitting, the default)");
-        m->compute_bf16 = dtype == 1;
-        m->compute_x3 = dtype == 2;
+        RFI_REQUIRE(dtype >= 0 && dtype <= 4,
+                    "set_compute_dtype: 0 native float32 MFMA, 1 bfloat16 (bf16 activations in HBM, plane kernels), "
+                    "2 float32 by 3 x bfloat16 splitting in registers (default), 3 the same arithmetic on pre-split "
+                    "plane tensors, 4 bfloat16 operands rounded in registers (float32 storage)");
+        m->compute_bf16 = dtype == 1 || dtype == 4;
+        m->compute_x3 = dtype == 2 || dtype == 3;
+        if (m->arch == 0) m->set_planes(dtype == 1 ? 1 : (dtype == 3 ? 3 : 0));
     });
 }
 int rfi_model_set_loss(rfi_model* m, int kind, float alpha, float gamma) {

@@ -695,6 +695,11 @@ bool conv_mfma_eligible(const ConvArgs& a) {
 }
 
 void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
+    if (impl == IMPL_PLANES_X3 || impl == IMPL_PLANES_BF16) {
+        RFI_REQUIRE(a.R == 3 && a.S == 1 && a.zgroups == 1, "conv: the plane kernels cover 3x3 stride-1 convolutions");
+        a.planes = impl == IMPL_PLANES_X3 ? 3 : 1;
+        impl = IMPL_MFMA;
+    }
     if (impl == IMPL_MFMA_BF16) {
         a.bf16 = true;
         impl = IMPL_MFMA;
@@ -710,15 +715,14 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
                     (int64_t)a.N * a.Hout * a.Wout * a.y.pstride < (int64_t)1 << 31 &&
                     (int64_t)a.R * a.R * a.Cin * a.Cout * a.zgroups < (int64_t)1 << 31,
                 "conv: tensor too large for 32-bit element offsets");
+    if (a.planes) {                 // IMPL_PLANES_*: the plane kernels (conv_planes.hip) through temporary plane copies
+        launch_pconv_from_f32(ctx, a, a.planes);
+        return;
+    }
     const bool ok = conv_mfma_eligible(a);
     if (impl == IMPL_MFMA) RFI_REQUIRE(ok, "conv: shape/alignment not eligible for the MFMA kernel");
     if (impl == IMPL_DIRECT || !ok) {
         launch_conv_direct(ctx, a);
-        return;
-    }
-    // 3x3 stride-1 convolutions in the bf16 / 3 x bf16 arithmetic run on the plane kernels (conv_planes.hip)
-    if ((a.bf16 || a.bf16x3) && a.R == 3 && a.S == 1 && a.zgroups == 1 && !getenv("RFI_OLD_CONV")) {
-        launch_pconv_from_f32(ctx, a, a.bf16x3 ? 3 : 1);
         return;
     }
     // 3 x bf16: the filters are read pre-split (ConvArgs::w3); callers that only have float32 weights (the

@@ -273,7 +273,8 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restr
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ c1,
-                                    const float* __restrict__ c2, double* __restrict__ partial, float slope) {
+                                    const float* __restrict__ c2, double* __restrict__ partial, float slope,
+                                    unsigned short* __restrict__ planes, int64_t pl_stride, int P) {
     __shared__ double red[V * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -301,7 +302,22 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restr
                 o[v] = g[v] * (dz - k1[v] - xh * k2[v]);
                 acc[0][v] += (double)o[v];
             }
-            stv<V>(da + r * C + c, o);
+            if (planes) {                      // dY leaves as bf16 pieces for the MFMA consumers (planes.hpp)
+                unsigned short* q = planes + r * pl_stride + (int64_t)(c >> 4) * (P * 16) + (c & 15);
+                float res[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) res[v] = o[v];
+                for (int p = 0; p < P; ++p) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const __bf16 h = (__bf16)res[v];                                  // RNE; NaN stays NaN
+                        q[p * 16 + v] = __builtin_bit_cast(unsigned short, h);
+                        res[v] -= (float)h;
+                    }
+                }
+            } else {
+                stv<V>(da + r * C + c, o);
+            }
         }
     }
     row_lane_reduce<V, 1>(acc, red, CL, RL, cl, rl);
@@ -925,18 +941,19 @@ void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t
 void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t M, int C,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
-                         float* partial_ws, float* dbias, float slope) {
+                         float* partial_ws, float* dbias, float slope, unsigned short* planes_out,
+                         int64_t planes_pstride, int planes_P) {
     ChanGeom g = geom_rows(M, C);
     {
-        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 12);
+        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * (planes_out ? 8 + 2 * planes_P : 12));
         if (g.V == 4)
             hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
                                da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
-                               c1, c2, reinterpret_cast<double*>(partial_ws), slope);
+                               c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
         else
             hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
                                da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
-                               c1, c2, reinterpret_cast<double*>(partial_ws), slope);
+                               c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
         check_launch("bn_bwd_apply");
     }
     if (dbias) {

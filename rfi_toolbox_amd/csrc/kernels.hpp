@@ -55,6 +55,7 @@ struct ConvArgs {
     double algo_flops = -1;           // algorithmic FLOPs for the profile (default: from the shape)
     bool bf16 = false;                // MFMA kernels: operands rounded to bf16 in registers, fp32 accumulate
     bool bf16x3 = false;              // MFMA kernels: float32 operands split into 3 bf16 pieces, 6 bf16 MFMAs per K=16
+    int planes = 0;                   // 1 / 3: run on the plane kernels through temporary plane copies (IMPL_PLANES_*)
     // optional: per-channel (sum, sumsq) of the OUTPUT in the epilogue (BatchNorm statistics).  in: stats
     // = [records][Cout][2] doubles with room for stats_max_records; out: stats_records = records written
     // (0 and stats = null when the launch could not provide them: direct kernel, unaligned output)
@@ -66,7 +67,10 @@ struct ConvArgs {
 #endif
 };
 
-enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 3, IMPL_MFMA_BF16X3 = 4 };
+// 5 / 6: the plane kernels (planes.hpp) in the 3 x bf16 / bf16 arithmetic; callers holding float32 tensors get
+// temporary plane copies (kernel-level ABI, tests)
+enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 3, IMPL_MFMA_BF16X3 = 4,
+                IMPL_PLANES_X3 = 5, IMPL_PLANES_BF16 = 6 };
 
 bool conv_mfma_eligible(const ConvArgs& a);
 // filters [taps][Cout][Cin] -> [taps][Cout][ceil(Cin/16)][h16 | m16 | l16] bf16 records (24 floats each)
@@ -96,6 +100,7 @@ struct WgradArgs {
     double algo_flops = -1;
     bool bf16 = false;                // MFMA kernel: operands rounded to bf16 in registers, fp32 accumulate
     bool bf16x3 = false;              // MFMA kernel: float32 emulated by 3 x bf16 pieces
+    int planes = 0;                   // 1 / 3: plane kernel through temporary plane copies (IMPL_PLANES_*)
 };
 size_t wgrad_slab_floats(const WgradArgs& a, int impl);
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);
@@ -127,7 +132,9 @@ size_t bn_bwd_ws_floats(int64_t M, int C);
 void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t M, int C,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
-                         float* partial_ws, float* dbias, float slope = 0.0f);
+                         float* partial_ws, float* dbias, float slope = 0.0f,
+                         unsigned short* planes_out = nullptr, int64_t planes_pstride = 0, int planes_P = 0);
+// planes_out != null: dy is written as a plane tensor (planes.hpp; P bf16 pieces per value) instead of in place
 
 // ---------------------------------------------------------------- pool / head / loss
 // a = relu(y*scale+shift) -> skip view (full res) and 2x2 max-pooled p

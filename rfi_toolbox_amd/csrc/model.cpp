@@ -45,6 +45,9 @@ rfi_model::~rfi_model() {
     if (!ctx) return;
     ctx->activate();
     for (auto& b : bufs) b.free();
+    for (auto& b : pl) b.free();
+    if (wb_pool) ctx->release(wb_pool);
+    if (wb_descs) ctx->release(wb_descs);
     for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool})
         if (p) ctx->release(p);
     if (relayout_descs) ctx->release(relayout_descs);
@@ -56,8 +59,9 @@ rfi_model::~rfi_model() {
 // ------------------------------------------------------------------------------------ build
 void rfi_model::build() {
     if (const char* e = getenv("RFI_COMPUTE")) {      // arithmetic of new models: f32 (default) | f32mfma | bf16
-        compute_bf16 = std::string(e) == "bf16";
-        compute_x3 = std::string(e) == "f32" || std::string(e) == "f32x3";
+        compute_bf16 = std::string(e) == "bf16" || std::string(e) == "bf16regs";
+        compute_x3 = std::string(e) == "f32" || std::string(e) == "f32x3" || std::string(e) == "f32planes";
+        planesP = std::string(e) == "bf16" ? 1 : (std::string(e) == "f32planes" ? 3 : 0);
     }
     if (arch == 1) return build_cnn3();
     RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
@@ -197,6 +201,18 @@ void rfi_model::build() {
     wd_dirty = true;
     x3_fresh = false;
     reset_channel_state();
+}
+
+void rfi_model::set_planes(int P) {
+    if (P == planesP) return;
+    ctx->activate();
+    RFI_CHECK_HIP(hipStreamSynchronize(ctx->main_stream));
+    RFI_CHECK_HIP(hipStreamSynchronize(ctx->side_stream));
+    for (auto& b : pl) b.free();                  // tensors and filter copies of the other P
+    if (wb_pool) { ctx->release(wb_pool); wb_pool = nullptr; }
+    if (wb_descs) { ctx->release(wb_descs); wb_descs = nullptr; }
+    planesP = P;
+    wd_dirty = true;
 }
 
 void rfi_model::reset_channel_state() {
@@ -366,6 +382,7 @@ void rfi_model::refresh_dgrad_weights() {
         launch_weights_to_x3_batched(ctx, static_cast<const X3Desc*>(x3_descs), x3_n, x3_bytes);
         x3_fresh = true;
     }
+    if (planesP && arch == 0) refresh_plane_weights();     // B-operand-order filters of the plane kernels
     wd_dirty = false;
 }
 
@@ -425,6 +442,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
     prepare(n, h, w);
     refresh_dgrad_weights();          // derived filter copies (dgrad layout, 3 x bf16 records) follow the parameters
     if (arch == 1) return forward_cnn3(x_dev, n, h, w);
+    if (planesP) return forward_planes(x_dev, n, h, w, train_mode);
     const int D = depth;
     View cur = network_input(x_dev, n, h, w);
     for (int l = 1; l <= D; ++l) {
@@ -589,6 +607,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     const int D = depth;
     const int64_t M1 = (int64_t)n * h * w;
     refresh_dgrad_weights();
+    if (planesP) return backward_planes(x_dev, labels_dev, n, h, w);
     // loss -> dlogits -> head
     if (loss_kind == 1)
         launch_focal_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, focal_alpha, focal_gamma, buf(dlogits));

@@ -1,6 +1,6 @@
 // U-Net graph of rfi_toolbox/models/unet.py on top of the HIP kernels (host orchestration).
 #pragma once
-#include "kernels.hpp"
+#include "planes.hpp"
 
 namespace rfi {
 
@@ -9,6 +9,17 @@ struct DevBuf {
     float* p = nullptr;
     size_t n = 0;
     void ensure(rfi_ctx* c, size_t floats);
+    void free();
+};
+
+// a plane tensor (planes.hpp) owned by a model: [pixels][chunks][P][16] bf16 + a zeroed 64-byte tail
+struct PlaneBuf {
+    rfi_ctx* ctx = nullptr;
+    bf16_t* p = nullptr;
+    size_t elems = 0;
+    int64_t pstride = 0;
+    int nchunks = 0;
+    void ensure(rfi_ctx* c, int64_t pixels, int C, int P);
     void free();
 };
 
@@ -34,6 +45,8 @@ struct ConvBN {
     float* wd = nullptr;                // dgrad-layout copy of the weight [9][cin_p][cout]
     float* w3 = nullptr;                // 3 x bf16 records of the forward layout (launch_weights_to_x3)
     float* wd3 = nullptr;               // ... and of the dgrad layout
+    bf16_t* wBf = nullptr;              // plane kernels: filters in MFMA B-operand order, forward ...
+    bf16_t* wBd = nullptr;              // ... and input-gradient direction (planes.hpp)
 };
 
 // ConvTranspose2d(k2,s2)+bias
@@ -120,6 +133,22 @@ struct rfi_model {
     void reset_channel_state();       // running stats 0/1, BN-less layers: scale 1, shift 0
     float* buf(int i) { return bufs[i].p; }
     int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
+
+    // ---- plane data flow (model_planes.cpp): planesP = 0 off (round-1 kernels on float32 tensors), 1 bf16
+    // activations (the bfloat16 compute mode), 3 float32 as three bf16 pieces
+    int planesP = 0;
+    std::vector<rfi::PlaneBuf> pl;
+    std::vector<int> pA1e, pSkip, pPool, pUp, pA1d, pdYa, pdYb, upf;
+    int pXin = -1, pA1b = -1, pdYbottA = -1, pdYbottB = -1;
+    rfi::bf16_t* wb_pool = nullptr;
+    void* wb_descs = nullptr;
+    int wb_n = 0;
+    double wb_bytes = 0;
+    void set_planes(int P);           // switches the data flow; frees plane tensors of another P
+    void prepare_planes(int n, int h, int w);
+    void refresh_plane_weights();
+    void forward_planes(const float* x_dev, int n, int h, int w, bool train_mode);
+    void backward_planes(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w);
 
     // backward-pass overlap: wgrad launches go to the context's side stream (see model.cpp)
     int side_seq = 0;

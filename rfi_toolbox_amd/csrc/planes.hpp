@@ -30,6 +30,10 @@ static inline size_t plane_elems(int64_t pixels, int C, int P) { return (size_t)
 // ---------------------------------------------------------------- producers
 // fp32 [M][C] view (pstride floats per pixel) -> planes; optional BatchNorm-apply + (Leaky)ReLU in flight
 void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P, bf16_t* out, int64_t out_pstride);
+// a = act(y*scale+shift) -> skip planes (full resolution) + 2x2 max-pooled planes (H, W even)
+void launch_bn_relu_pool_planes(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale,
+                                const float* shift, float slope, int P, bf16_t* skip, int64_t skip_pstride,
+                                bf16_t* pooled, int64_t pooled_pstride);
 // planes -> fp32 (tests / debugging): sum of the pieces
 void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, int64_t M, int C, int P, float* out,
                           int out_pstride);
@@ -84,6 +88,8 @@ struct PWgradArgs {
     PlaneSeg xop[2];
     int nseg = 1;
     int seg_c[2] = {0, 0};            // true channel counts of the Xop segments (Cx = seg_c[0] + seg_c[1])
+    int cx_layout = 0;                // cx entries of the dw layout (>= Cx; e.g. the stem's input channels padded to 4):
+                                      // entries Cx .. cx_layout - 1 are written as zeros.  0: = Cx
     PlaneSeg yop;
     int Cy = 0;
     int P = 3;
@@ -99,5 +105,7 @@ struct PWgradArgs {
 };
 size_t pwgrad_slab_floats(const PWgradArgs& a);
 void launch_pwgrad(rfi_ctx* ctx, const PWgradArgs& a);
+void launch_pwgrad_from_f32(rfi_ctx* ctx, const WgradArgs& w, int P);     // float32 tensors in: temporary plane copies
+size_t pwgrad_slab_floats_f32(const WgradArgs& w);
 
 }  // namespace rfi

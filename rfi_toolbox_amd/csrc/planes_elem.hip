@@ -76,6 +76,63 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
     }
 }
 
+// a = act(y * scale + shift) -> skip planes (full resolution) and 2x2 max-pooled planes, 8 channels of one pooled
+// pixel per thread (Encoder.forward, models/unet.py:21-28: `pool(conv(x)), conv(x)`)
+template <int P>
+__global__ __launch_bounds__(256) void bn_relu_pool_planes_kernel(const float* __restrict__ y, int N, int H, int W, int C,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 float slope, bf16_t* __restrict__ skip, int64_t sp,
+                                                                 bf16_t* __restrict__ pooled, int64_t pp) {
+    const int Hp = H >> 1, Wp = W >> 1, groups = plane_chunks(C) * 2;
+    const int64_t total = (int64_t)N * Hp * Wp * groups;
+    const bool vec = (C & 3) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        int64_t t = i / groups;
+        const int px = (int)(t % Wp); t /= Wp;
+        const int py = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        const int c0 = g * 8;
+        float sc[8], sh[8], best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = c0 + e < C ? scale[c0 + e] : 0.0f;
+            sh[e] = c0 + e < C ? shift[c0 + e] : 0.0f;
+            best[e] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t pix = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
+            const float* src = y + pix * C + c0;
+            float v[8];
+            if (vec && c0 + 8 <= C) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? src[e] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = v[e] * sc[e] + sh[e];
+                a = a > 0.0f ? a : (slope != 0.0f ? a * slope : 0.0f);         // torch's (Leaky)ReLU
+                v[e] = a;
+                best[e] = (k == 0 || a > best[e]) ? a : best[e];
+            }
+            u32x4 pc[3];
+            split8<P>(v, pc);
+            bf16_t* o = skip + pix * sp + (int64_t)(g >> 1) * (P * 16) + (g & 1) * 8;
+#pragma unroll
+            for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(o + p * 16) = pc[p];
+        }
+        u32x4 pc[3];
+        split8<P>(best, pc);
+        bf16_t* o = pooled + (((int64_t)n * Hp + py) * Wp + px) * pp + (int64_t)(g >> 1) * (P * 16) + (g & 1) * 8;
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(o + p * 16) = pc[p];
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void planes_to_f32_kernel(const bf16_t* __restrict__ in, int64_t ip, int64_t M, int C,
                                                             float* __restrict__ out, int op) {
@@ -143,6 +200,23 @@ void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P,
     else { if (vec) RFI_AS(1, true); else RFI_AS(1, false); }
 #undef RFI_AS
     check_launch("act_split");
+}
+
+void launch_bn_relu_pool_planes(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale,
+                                const float* shift, float slope, int P, bf16_t* skip, int64_t skip_pstride,
+                                bf16_t* pooled, int64_t pooled_pstride) {
+    RFI_REQUIRE((H & 1) == 0 && (W & 1) == 0, "bn_relu_pool_planes: even H and W (the U-Net levels are)");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * plane_chunks(C) * 2;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 4 + (double)total * 16 * P * 5);
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    if (P == 3)
+        hipLaunchKernelGGL(bn_relu_pool_planes_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, N, H, W, C,
+                           scale, shift, slope, skip, skip_pstride, pooled, pooled_pstride);
+    else
+        hipLaunchKernelGGL(bn_relu_pool_planes_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, N, H, W, C,
+                           scale, shift, slope, skip, skip_pstride, pooled, pooled_pstride);
+    check_launch("bn_relu_pool_planes");
 }
 
 void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, int64_t M, int C, int P, float* out,

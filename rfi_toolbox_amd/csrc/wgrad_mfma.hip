@@ -10,7 +10,9 @@
 // registers into LDS as [pixel][channel] rows; MFMA operands are ds_read_b32 (lane = channel,
 // k = pixel), so one A read feeds all taps.  Waves of a workgroup split either the (cy,cx) 32x32
 // blocks of a BY x BX channel tile or, when that tile is a single block, the tile's pixels.
-#include "kernels.hpp"
+#include <algorithm>
+
+#include "planes.hpp"
 
 namespace rfi {
 
@@ -432,8 +434,10 @@ Plan dispatch(rfi_ctx* ctx, const WgradArgs& a, int what, int cus) {
 }  // namespace
 
 size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
-    if (impl == IMPL_MFMA_BF16 || impl == IMPL_MFMA_BF16X3) impl = IMPL_MFMA;
     size_t need = wgrad_direct_slab_floats(a);
+    if ((impl == IMPL_PLANES_X3 || impl == IMPL_PLANES_BF16) && a.R == 3 && a.S == 1)
+        return std::max(need, pwgrad_slab_floats_f32(a));
+    if (impl == IMPL_MFMA_BF16 || impl == IMPL_MFMA_BF16X3) impl = IMPL_MFMA;
     if (impl != IMPL_DIRECT && wgrad_mfma_eligible(a)) {
         const Plan p = dispatch(nullptr, a, SEL_PLAN, 256);
         // plan with the largest CU count we may meet so the workspace always suffices
@@ -445,6 +449,11 @@ size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
 
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
     WgradArgs a = a_in;
+    if (impl == IMPL_PLANES_X3 || impl == IMPL_PLANES_BF16) {      // plane kernel through temporary plane copies
+        RFI_REQUIRE(a.R == 3 && a.S == 1, "wgrad: the plane kernel covers 3x3 stride-1 convolutions");
+        launch_pwgrad_from_f32(ctx, a, impl == IMPL_PLANES_X3 ? 3 : 1);
+        return;
+    }
     if (impl == IMPL_MFMA_BF16) {
         a.bf16 = true;
         impl = IMPL_MFMA;

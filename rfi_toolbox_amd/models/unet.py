@@ -158,14 +158,20 @@ class HipSegmenter:
         float32 in every mode).  ``"float32"`` (default): float32 by splitting every operand into three
         bfloat16 pieces, six bf16 MFMAs per product block -- float32-level accuracy (same error against
         float64 as the native path) at 2.7x its matrix rate.  ``"float32_mfma"``: the native float32 MFMA
-        (exact fmaf chain).  ``"bfloat16"``: operands rounded to bf16, float32 accumulate -- the mixed
-        precision the reference gets from ``torch.autocast`` on a GPU (train_model.py:131,144)."""
+        (exact fmaf chain).  ``"bfloat16"``: activations stored in HBM as bf16, bf16 MFMA operands, float32
+        accumulate, float32 BatchNorm / loss / optimiser -- the mixed precision the reference gets from
+        ``torch.autocast`` on a GPU (train_model.py:131,144); the 3x3 layers run on the plane kernels (LDS-DMA staged
+        operands).  ``"float32_planes"``: the default arithmetic on pre-split plane tensors (same kernels as
+        bfloat16, three pieces per value).  ``"bfloat16_regs"``: round 1's bf16 mode (float32 storage, operands
+        rounded in registers)."""
         code = {"float32": 2, "fp32": 2, "f32": 2, "float32_3xbf16": 2, "float32_mfma": 0, "f32mfma": 0,
-                "bfloat16": 1, "bf16": 1}.get(str(dtype).replace("torch.", ""))
+                "bfloat16": 1, "bf16": 1, "float32_planes": 3, "f32planes": 3, "bfloat16_regs": 4, "bf16regs": 4
+                }.get(str(dtype).replace("torch.", ""))
         if code is None:
-            raise ValueError(f"compute dtype must be float32, float32_mfma or bfloat16, got {dtype!r}")
+            raise ValueError("compute dtype must be float32, float32_mfma, float32_planes, bfloat16 or bfloat16_regs, "
+                             f"got {dtype!r}")
         check(lib.rfi_model_set_compute_dtype(self._h, code))
-        self.compute_dtype = {2: "float32", 0: "float32_mfma", 1: "bfloat16"}[code]
+        self.compute_dtype = {2: "float32", 0: "float32_mfma", 1: "bfloat16", 3: "float32_planes", 4: "bfloat16_regs"}[code]
         return self
 
     def set_loss(self, kind="bce_dice", alpha=0.25, gamma=2.0):

@@ -21,10 +21,11 @@ CONV_SHAPES = [
 
 
 IMPL_X3 = 4       # MFMA kernel, float32 by 3 x bf16 splitting (the default arithmetic of the models)
+IMPL_PX3 = 5      # plane kernels (LDS-DMA staged bf16 pieces), 3 x bf16 arithmetic; any channel count
 
 
 def _impls(cin):
-    return [IMPL_DIRECT, IMPL_MFMA, IMPL_X3] if cin % 4 == 0 else [IMPL_DIRECT]
+    return [IMPL_DIRECT, IMPL_MFMA, IMPL_X3, IMPL_PX3] if cin % 4 == 0 else [IMPL_DIRECT, IMPL_PX3]
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
@@ -59,7 +60,7 @@ def test_conv3x3_dgrad_wgrad(shape):
     F.conv2d(x, wt, None, padding=1).backward(dy)
     c = ctx()
     dxd, dwd, ddy = c.to_device(nhwc(x.detach())), c.to_device(wt.detach().numpy()), c.to_device(nhwc(dy))
-    for impl in _impls(cin) if cout % 4 == 0 else [IMPL_DIRECT]:
+    for impl in _impls(cin) if cout % 4 == 0 else [IMPL_DIRECT, IMPL_PX3]:
         out = c.empty((n, h, w, cin))
         check(lib.rfi_op_conv3x3_dgrad(c.handle, impl, P(ddy), n, h, w, cout, P(dwd), cin, P(out)))
         assert rel_err(out.numpy(), nhwc(x.grad)) <= TOL, f"dgrad impl={impl}"
@@ -80,7 +81,7 @@ def test_conv3x3_wgrad_with_load_transform():
     c = ctx()
     dx, ddy, dsc, dsh = (c.to_device(nhwc(x)), c.to_device(nhwc(dy)), c.to_device(sc.numpy()),
                          c.to_device(sh.numpy()))      # keep the device buffers alive across the calls
-    for impl in (IMPL_DIRECT, IMPL_MFMA, IMPL_X3):
+    for impl in (IMPL_DIRECT, IMPL_MFMA, IMPL_X3, IMPL_PX3):
         gw = c.empty((cout, cin, 3, 3))
         check(lib.rfi_op_conv3x3_wgrad(c.handle, impl, P(dx), P(ddy), n, h, w, cin, cout, P(dsc), P(dsh), 1, P(gw)))
         assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, f"impl={impl}"
@@ -247,7 +248,7 @@ def test_conv3x3_double_tile_kernels(shape):
     c = ctx()
     dx, dw, db, ddy = c.to_device(nhwc(x)), c.to_device(wt.numpy()), c.to_device(b.numpy()), c.to_device(nhwc(dy))
     dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
-    for impl in (IMPL_MFMA, IMPL_X3):
+    for impl in (IMPL_MFMA, IMPL_X3, IMPL_PX3):
         out = c.empty((n, h, w, cout))
         check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout, P(dsc), P(dsh), 1, P(out)))
         assert rel_err(out.numpy(), nhwc(y.detach())) <= TOL, f"fwd impl={impl}"
@@ -263,7 +264,7 @@ def _wide(shape, g, lo, hi):
     return (torch.randn(shape, generator=g).double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), k)).float()
 
 
-@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3])
+@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3, IMPL_PX3])
 def test_conv3x3_wide_dynamic_range_and_cancellation(impl):
     """The float32-by-3xbf16 arithmetic claims ONE float32 rounding per product (the three dropped piece
     products are <= 2^-24 |a b|), for any finite operands, not just randn.  Operands spanning 2^-60 .. 2^60
@@ -295,7 +296,7 @@ def test_conv3x3_wide_dynamic_range_and_cancellation(impl):
     assert (got[cancel].abs() <= 16 * 2.0 ** -24 * bound[cancel]).all()
 
 
-@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3])
+@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3, IMPL_PX3])
 def test_conv3x3_non_finite_lanes(impl):
     """An inf and a NaN in the input: every output whose 3x3 window contains one of them must come out
     non-finite, every other output must be unaffected.  (The split path turns inf into NaN -- inf - inf in the
@@ -321,7 +322,7 @@ def test_conv3x3_non_finite_lanes(impl):
     assert rel_err(got[ok], nhwc(clean)[0][ok]) <= TOL
 
 
-@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3])
+@pytest.mark.parametrize("impl", [IMPL_MFMA, IMPL_X3, IMPL_PX3])
 def test_conv3x3_tiny_operands_underflow(impl):
     """Operands near the bottom of the float32 range: the low bf16 pieces underflow (bf16 shares float32's
     exponent range), which may cost relative accuracy only where the PRODUCTS are themselves subnormal; results

@@ -11,7 +11,8 @@ from gpu_util import P, check, ctx, lib, nhwc, rel_err
 from test_gpu_ops import CONV_SHAPES, CONVT_SHAPES
 
 pytestmark = pytest.mark.gpu
-BF = 3          # IMPL_MFMA_BF16
+BF = 3          # IMPL_MFMA_BF16: operands rounded to bf16 in registers (the transposed-conv kernels of the bf16 mode)
+PBF = 6         # IMPL_PLANES_BF16: the plane kernels (bf16 activations staged by LDS-DMA), the 3x3 kernels of the bf16 mode
 TOL = 2e-5
 SHAPES = [s for s in CONV_SHAPES if s[3] % 4 == 0 and s[4] % 4 == 0]
 TSHAPES = [s for s in CONVT_SHAPES if s[3] % 4 == 0 and s[4] % 4 == 0]
@@ -38,10 +39,11 @@ def test_conv3x3_forward_bf16(shape, xform):
     c = ctx()
     dx, dw, db = c.to_device(nhwc(x)), c.to_device(wt.numpy()), c.to_device(b.numpy())
     dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
-    dy = c.empty((n, h, w, cout))
-    check(lib.rfi_op_conv3x3(c.handle, BF, P(dx), n, h, w, cin, P(dw), P(db), cout,
-                             P(dsc) if xform else None, P(dsh) if xform else None, 1 if xform else 0, P(dy)))
-    assert rel_err(dy.numpy(), want) <= TOL
+    for impl in (BF, PBF):
+        dy = c.empty((n, h, w, cout))
+        check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout,
+                                 P(dsc) if xform else None, P(dsh) if xform else None, 1 if xform else 0, P(dy)))
+        assert rel_err(dy.numpy(), want) <= TOL, impl
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -54,12 +56,13 @@ def test_conv3x3_dgrad_wgrad_bf16(shape):
     F.conv2d(x, wt, None, padding=1).backward(dy.double())
     c = ctx()
     dxd, dwd, ddy = c.to_device(nhwc(x.detach().float())), c.to_device(wt.detach().float().numpy()), c.to_device(nhwc(dy))
-    out = c.empty((n, h, w, cin))
-    check(lib.rfi_op_conv3x3_dgrad(c.handle, BF, P(ddy), n, h, w, cout, P(dwd), cin, P(out)))
-    assert rel_err(out.numpy(), nhwc(x.grad.float())) <= TOL
-    gw = c.empty((cout, cin, 3, 3))
-    check(lib.rfi_op_conv3x3_wgrad(c.handle, BF, P(dxd), P(ddy), n, h, w, cin, cout, None, None, 0, P(gw)))
-    assert rel_err(gw.numpy(), wt.grad.float().numpy()) <= 5e-5
+    for impl in (BF, PBF):
+        out = c.empty((n, h, w, cin))
+        check(lib.rfi_op_conv3x3_dgrad(c.handle, impl, P(ddy), n, h, w, cout, P(dwd), cin, P(out)))
+        assert rel_err(out.numpy(), nhwc(x.grad.float())) <= TOL, impl
+        gw = c.empty((cout, cin, 3, 3))
+        check(lib.rfi_op_conv3x3_wgrad(c.handle, impl, P(dxd), P(ddy), n, h, w, cin, cout, None, None, 0, P(gw)))
+        assert rel_err(gw.numpy(), wt.grad.float().numpy()) <= 5e-5, impl
 
 
 @pytest.mark.parametrize("shape", TSHAPES)
@@ -97,9 +100,10 @@ def test_wgrad_bf16_with_load_transform():
     F.conv2d(a, wt, None, padding=1).backward(dy.double())
     c = ctx()
     dx, ddy, dsc, dsh = c.to_device(nhwc(x)), c.to_device(nhwc(dy)), c.to_device(sc.numpy()), c.to_device(sh.numpy())
-    gw = c.empty((cout, cin, 3, 3))
-    check(lib.rfi_op_conv3x3_wgrad(c.handle, BF, P(dx), P(ddy), n, h, w, cin, cout, P(dsc), P(dsh), 1, P(gw)))
-    assert rel_err(gw.numpy(), wt.grad.float().numpy()) <= 5e-5
+    for impl in (BF, PBF):
+        gw = c.empty((cout, cin, 3, 3))
+        check(lib.rfi_op_conv3x3_wgrad(c.handle, impl, P(dx), P(ddy), n, h, w, cin, cout, P(dsc), P(dsh), 1, P(gw)))
+        assert rel_err(gw.numpy(), wt.grad.float().numpy()) <= 5e-5, impl
 
 
 # shapes that select the double-tile instantiations of the conv kernel (>= 512 workgroups; see test_gpu_ops.py)
@@ -122,9 +126,10 @@ def test_conv3x3_double_tile_kernels_bf16(shape):
     c = ctx()
     dx, dw, db, ddy = c.to_device(nhwc(x)), c.to_device(wt.numpy()), c.to_device(b.numpy()), c.to_device(nhwc(dy))
     dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
-    out = c.empty((n, h, w, cout))
-    check(lib.rfi_op_conv3x3(c.handle, BF, P(dx), n, h, w, cin, P(dw), P(db), cout, P(dsc), P(dsh), 1, P(out)))
-    assert rel_err(out.numpy(), nhwc(y.detach().float())) <= TOL
-    gx = c.empty((n, h, w, cin))
-    check(lib.rfi_op_conv3x3_dgrad(c.handle, BF, P(ddy), n, h, w, cout, P(dw), cin, P(gx)))
-    assert rel_err(gx.numpy(), nhwc(xin.grad.float())) <= TOL
+    for impl in (BF, PBF):
+        out = c.empty((n, h, w, cout))
+        check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout, P(dsc), P(dsh), 1, P(out)))
+        assert rel_err(out.numpy(), nhwc(y.detach().float())) <= TOL, impl
+        gx = c.empty((n, h, w, cin))
+        check(lib.rfi_op_conv3x3_dgrad(c.handle, impl, P(ddy), n, h, w, cout, P(dw), cin, P(gx)))
+        assert rel_err(gx.numpy(), nhwc(xin.grad.float())) <= TOL, impl
