@@ -431,18 +431,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                         const int co = co0 + g4;
                         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
                         if (a.bias && co < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+                        // BatchNorm-backward sums of the layer whose activated output this tensor is the gradient of
+                        f32x4 bsc = b4, bsh = b4, bmu = b4, bis = b4;
+                        if (st_out && a.bwd_y && co < a.Cout) {
+                            bsc = *reinterpret_cast<const f32x4*>(a.bwd_scale + co);
+                            bsh = *reinterpret_cast<const f32x4*>(a.bwd_shift + co);
+                            bmu = *reinterpret_cast<const f32x4*>(a.bwd_mean + co);
+                            bis = *reinterpret_cast<const f32x4*>(a.bwd_invstd + co);
+                        }
 #pragma unroll
                         for (int ps = 0; ps < 4; ++ps) {
                             const int pp = ps * 8 + (lane >> 3);        // pixel of the m-tile
                             const f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pp * 36 + g4) + b4;
                             const int oy = oyb + pp / TW, ox = ctile.ox0 + pp % TW;
                             if (co < a.Cout && oy < a.H && ox < a.W) {
-                                *reinterpret_cast<f32x4*>(
-                                    a.y.p + (unsigned)(((ctile.n * a.Hout + oy * a.osy + ooy) * a.Wout + ox * a.osx + oox) *
-                                                           a.y.pstride + co)) = v;
+                                const unsigned off = (unsigned)(((ctile.n * a.Hout + oy * a.osy + ooy) * a.Wout + ox * a.osx + oox) *
+                                                                a.y.pstride + co);
+                                *reinterpret_cast<f32x4*>(a.y.p + off) = v;
                                 if (st_out) {
-                                    p1 += v;
-                                    p2 += v * v;
+                                    if (a.bwd_y) {
+                                        const f32x4 yv = *reinterpret_cast<const f32x4*>(a.bwd_y + off);
+                                        const f32x4 z = yv * bsc + bsh, xh = (yv - bmu) * bis;
+                                        f32x4 dz;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.0f ? v[e] : v[e] * a.bwd_slope;
+                                        p1 += dz;
+                                        p2 += dz * xh;
+                                    } else {
+                                        p1 += v;
+                                        p2 += v * v;
+                                    }
                                 }
                             }
                         }
@@ -490,7 +508,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                     }
                 }
             }
-            __syncthreads();          // the staging LDS is about to be overwritten by the next item
+            // the staging LDS is about to be overwritten by the next item: wait for this wave's scratch reads only
+            // (a __syncthreads() would also wait for the output stores to retire: one HBM write latency per tile)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             ctile = ltile;
         }
 #ifdef RFI_DIAG_STAMPS

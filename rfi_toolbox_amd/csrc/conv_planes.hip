@@ -343,7 +343,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
             }
         }
         epilogue_group(g0);
-        __syncthreads();                             // the staging area (aliased by the scratch) is about to be overwritten
+        // the staging area (aliased by the scratch) is about to be overwritten: every wave must be done with its
+        // scratch READS (lgkmcnt), but nobody has to wait for the output stores to retire (a __syncthreads() would
+        // add s_waitcnt vmcnt(0): one exposed HBM write latency per group)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
     if (st_out) {
         __syncthreads();

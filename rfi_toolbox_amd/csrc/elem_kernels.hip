@@ -912,6 +912,14 @@ size_t bn_bwd_ws_floats(int64_t M, int C) {
     return (size_t)kMaxRowBlocks * C * 2 * 2;   // doubles counted as 2 floats
 }
 
+void launch_bn_bwd_finalize_records(rfi_ctx* ctx, const float* partial_ws, int records, int64_t M, int C, float* c1,
+                                    float* c2, float* dgamma, float* dbeta) {
+    ProfScope ps(ctx, FAM_BN);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<const double*>(partial_ws), records, C, (double)M, c1, c2, dgamma, dbeta);
+    check_launch("bn_bwd_finalize");
+}
+
 void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t M, int C,
                           const float* scale, const float* shift, const float* mean,
                           const float* invstd, float* partial_ws, float* c1, float* c2,

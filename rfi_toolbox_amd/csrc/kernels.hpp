@@ -62,6 +62,13 @@ struct ConvArgs {
     double* stats = nullptr;
     int stats_max_records = 0;
     int stats_records = 0;
+    // with `stats`: the output is dA, the gradient w.r.t. the ACTIVATED output of a Conv+BN layer whose raw output
+    // is bwd_y (same shape as the output).  The records then hold the BatchNorm-BACKWARD sums (sum dz, sum dz * xhat;
+    // dz = dA * act'(y*scale+shift), xhat = (y - mean) * invstd) instead of (sum y, sum y^2): bn_bwd_reduce's pass
+    // over dA and Y disappears (launch_bn_bwd_finalize_records finishes them).
+    const float* bwd_y = nullptr;
+    const float *bwd_scale = nullptr, *bwd_shift = nullptr, *bwd_mean = nullptr, *bwd_invstd = nullptr;
+    float bwd_slope = 0.0f;
 #ifdef RFI_DIAG_STAMPS
     unsigned long long* stamps = nullptr;   // diagnostic build only: per-workgroup phase cycle sums
 #endif
@@ -127,6 +134,9 @@ void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t
                           const float* invstd, float* partial_ws, float* c1, float* c2,
                           float* dgamma, float* dbeta, float slope = 0.0f);
 size_t bn_bwd_ws_floats(int64_t M, int C);
+// the same finish when the partial sums came out of the producing conv kernel's epilogue (ConvArgs::bwd_y)
+void launch_bn_bwd_finalize_records(rfi_ctx* ctx, const float* partial_ws, int records, int64_t M, int C, float* c1,
+                                    float* c2, float* dgamma, float* dbeta);
 // backward, pass 2 (in place on da): dy = gamma*invstd * (dz - c1 - xhat*c2); also per-channel
 // sum(dy) -> dbias_conv (partials in ws, finished by the same launch pair)
 void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t M, int C,

@@ -63,6 +63,7 @@ void rfi_model::build() {
         compute_x3 = std::string(e) == "f32" || std::string(e) == "f32x3" || std::string(e) == "f32planes";
         planesP = std::string(e) == "bf16" ? 1 : (std::string(e) == "f32planes" ? 3 : 0);
     }
+    if (const char* e = getenv("RFI_BN_FUSE")) fuse_bn_bwd = e[0] == '1';
     if (arch == 1) return build_cnn3();
     RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
     RFI_REQUIRE(depth >= 1 && depth <= 6, "UNet: depth must be in [1,6]");
@@ -552,15 +553,21 @@ struct SideScope {
 };
 
 // given dA (grad w.r.t. the ACTIVATED output of conv c, overwritten with dY), produce dW/db/dgamma/
-// dbeta into the grad buffer and, if dx != null, the gradient w.r.t. the conv's (activated) input
-void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in, InXform in_xf,
-                      Shape s, float* dx, int dx_pstride_unused) {
-    (void)dx_pstride_unused;
+// dbeta into the grad buffer and, if dx != null, the gradient w.r.t. the conv's (activated) input.
+// `have_records` > 0: the BatchNorm-backward sums of this layer already sit in the workspace (the kernel that
+// produced dA folded them into its epilogue).  `next` / `next_Y`: the Conv+BN layer whose activated output dx is
+// the gradient of (null: none); returns the number of records the dgrad left for it (0: none).
+int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in, InXform in_xf,
+                     Shape s, float* dx, int have_records, ConvBN* next, const float* next_Y) {
     rfi_ctx* ctx = m->ctx;
     const int64_t M = (int64_t)s.N * s.H * s.W;
     float* ws = m->buf(m->ws_red);
-    launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(),
-                         c.c2(), m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
+    if (have_records > 0)
+        launch_bn_bwd_finalize_records(ctx, ws, have_records, M, c.cout, c.c1(), c.c2(), m->grads + c.g_off,
+                                       m->grads + c.be_off);
+    else
+        launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(),
+                             c.c2(), m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
     launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
                         m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope);
     WgradArgs wa;
@@ -583,6 +590,7 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
         launch_wgrad(ctx, wa);
         side.end();
     }
+    int records = 0;
     if (dx) {
         ConvArgs a;
         a.x = View{dA, c.cout};
@@ -596,8 +604,18 @@ void backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View i
         a.R = 3; a.S = 1; a.pad = 1;
         a.bf16 = m->compute_bf16;
         a.bf16x3 = m->compute_x3;
+        if (next && m->fuse_bn_bwd) {       // dx is next's dA: fold its BatchNorm-backward sums into this epilogue
+            a.stats = reinterpret_cast<double*>(ws);
+            a.stats_max_records = (int)(bn_stats_ws_floats(next->cout) / ((size_t)next->cout * 4));
+            a.bwd_y = next_Y;
+            a.bwd_scale = next->scale(); a.bwd_shift = next->shift();
+            a.bwd_mean = next->mean(); a.bwd_invstd = next->invstd();
+            a.bwd_slope = m->act_slope;
+        }
         launch_conv(ctx, a);
+        records = a.stats_records;
     }
+    return records;
 }
 
 }  // namespace
@@ -621,6 +639,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
                         grads + head_b_off, act_slope);
     }
     // decoders, shallow to deep
+    int pending_records = 0;          // BatchNorm-backward records a producing kernel left for the next layer
     for (int l = 1; l <= D; ++l) {
         const int k = D - l;
         Shape s{n, h >> (l - 1), w >> (l - 1)};
@@ -629,10 +648,11 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         // conv2: input = act(decY1) ; conv1: input = concat (materialised)
-        backward_conv_bn(this, c2, buf(gA[l]), buf(decY2[l]), View{buf(decY1[l]), c1.cout}, bn_xf(c1), s,
-                         buf(gB[l]), 0);
+        int rec = backward_conv_bn(this, c2, buf(gA[l]), buf(decY2[l]), View{buf(decY1[l]), c1.cout}, bn_xf(c1), s,
+                                   buf(gB[l]), pending_records, &c1, buf(decY1[l]));
         backward_conv_bn(this, c1, buf(gB[l]), buf(decY1[l]), View{buf(concat[l]), 2 * u.cout}, InXform{}, s,
-                         buf(dconcat[l]), 0);
+                         buf(dconcat[l]), rec, nullptr, nullptr);
+        pending_records = 0;
         // up-conv: dUp = dconcat[..., 0:C]
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
         ConvBN& prevBN = (l == D) ? convs[2 * D + 1] : convs[2 * D + 2 + 2 * (k - 1) + 1];
@@ -670,17 +690,26 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         a.R = 2; a.S = 2; a.pad = 0;
         a.bf16 = compute_bf16;
         a.bf16x3 = compute_x3;
+        if (fuse_bn_bwd) {                  // dprev is prevBN's dA: its BatchNorm-backward sums come out of this epilogue
+            a.stats = reinterpret_cast<double*>(buf(ws_red));
+            a.stats_max_records = (int)(bn_stats_ws_floats(prevBN.cout) / ((size_t)prevBN.cout * 4));
+            a.bwd_y = prevY;
+            a.bwd_scale = prevBN.scale(); a.bwd_shift = prevBN.shift();
+            a.bwd_mean = prevBN.mean(); a.bwd_invstd = prevBN.invstd();
+            a.bwd_slope = act_slope;
+        }
         launch_conv(ctx, a);
+        pending_records = a.stats_records;
     }
     // bottleneck
     {
         Shape s{n, h >> D, w >> D};
         ConvBN& c1 = convs[2 * D];
         ConvBN& c2 = convs[2 * D + 1];
-        backward_conv_bn(this, c2, buf(gBottA), buf(bottY2), View{buf(bottY1), c1.cout}, bn_xf(c1), s,
-                         buf(gBottB), 0);
+        int rec = backward_conv_bn(this, c2, buf(gBottA), buf(bottY2), View{buf(bottY1), c1.cout}, bn_xf(c1), s,
+                                   buf(gBottB), pending_records, &c1, buf(bottY1));
         backward_conv_bn(this, c1, buf(gBottB), buf(bottY1), View{buf(pool[D]), c1.cin}, InXform{}, s,
-                         buf(dpool[D]), 0);
+                         buf(dpool[D]), rec, nullptr, nullptr);
     }
     // encoders, deep to shallow
     for (int l = D; l >= 1; --l) {
@@ -689,12 +718,12 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         ConvBN& c2 = convs[2 * (l - 1) + 1];
         launch_pool_bwd_merge(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
                               View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
-        backward_conv_bn(this, c2, buf(gA[l]), buf(encY2[l]), View{buf(encY1[l]), c1.cout}, bn_xf(c1), s,
-                         buf(gB[l]), 0);
+        int rec = backward_conv_bn(this, c2, buf(gA[l]), buf(encY2[l]), View{buf(encY1[l]), c1.cout}, bn_xf(c1), s,
+                                   buf(gB[l]), 0, &c1, buf(encY1[l]));
         View in = (l == 1) ? (c1.cin_p == in_ch ? View{x_dev, in_ch} : View{buf(x_pad), c1.cin_p})
                            : View{buf(pool[l - 1]), c1.cin};
         backward_conv_bn(this, c1, buf(gB[l]), buf(encY1[l]), in, InXform{}, s,
-                         (l == 1) ? nullptr : buf(dpool[l - 1]), 0);
+                         (l == 1) ? nullptr : buf(dpool[l - 1]), rec, nullptr, nullptr);
     }
     side_join();
 }
