@@ -22,6 +22,7 @@
 // The epilogue transposes the accumulators through LDS into 16-byte stores of whole pixel rows, adds the bias and
 // folds the BatchNorm statistics of the output (sum y, sum y^2 per channel; fp64 per workgroup record).
 #include <algorithm>
+#include <vector>
 
 #include "planes.hpp"
 
@@ -40,15 +41,18 @@ struct PConvDev {
     unsigned x_zero[2];              // byte offset of >= 64 zero bytes inside each segment's allocation
     unsigned wb_zero;                // ... and inside the filter allocation
     int diag;                        // RFI_PCONV_DIAG: 1 skip the MFMA phase, 2 skip the DMA (timing experiments only)
+    unsigned long long* stamps;      // RFI_DIAG_STAMPS build: per-wave phase cycle sums
 };
 
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G>
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1>
 struct PCfg {
     static constexpr int NW = WM * WN, NT = NW * 64;
     static constexpr int BM = TH * TW, BN = WN * NTL * 32;
     static constexpr int HH = TH * S + R - S, HW = TW * S + R - S, HP = HH * HW;
     static constexpr int NTAP = R * R;
-    static constexpr int RS = 2 * P + 1;                    // 16-byte slots per halo pixel (2P data + 1 pad)
+    static constexpr int RS = 2 * P + PAD;                  // 16-byte slots per halo pixel (2P data + PAD pad: with the pad
+                                                            // the b128 reads of 64 consecutive pixels are conflict free,
+                                                            // without it they are 2-way but 1/(2P+1) less is staged)
     static constexpr int ROWB = RS * 16;
     static constexpr int A_SLOTS = HP * RS;
     static constexpr int A_ITEMS = (A_SLOTS + NT - 1) / NT;
@@ -86,9 +90,9 @@ __device__ __forceinline__ f32x16 mma(const bf16x8 (&a)[P], const bf16x8 (&b)[P]
 // other workgroup's MFMAs, LDS reads and output stores fill the wait).  A workgroup walks its tiles in GROUPS of
 // G: for each K chunk the filter tile is staged ONCE and used by the G tiles of the group (G sets of
 // accumulators), so the filter traffic per MFMA drops G-fold.
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G>
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
-    using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G>;
+    using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>;
     const PConvArgs& a = d.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -306,49 +310,92 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
 
     const unsigned char* const sA = smem;
     const unsigned char* const sB = smem + C::A_BYTES;
+#ifdef RFI_DIAG_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long nitem_ = 0;
+#define RFI_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define RFI_ACC(i, a_, b_) st_[i] += (b_) - (a_)
+#else
+#define RFI_T(v)
+#define RFI_ACC(i, a_, b_)
+#endif
     for (int g0 = 0; g0 < my_tiles; g0 += G) {
         const int gcount = my_tiles - g0 < G ? my_tiles - g0 : G;
         for (int kc = 0; kc < d.nkc; ++kc) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (g < gcount) {
+                    RFI_T(t0);
                     if (!(d.diag & 2) || (g0 == 0 && kc == 0 && g == 0)) {
                         issue_A(g0 + g, kc);
                         if (g == 0) issue_B(kc);     // the filter tile of the chunk serves every tile of the group
                     }
+                    RFI_T(t1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    RFI_T(t2);
                     __syncthreads();                 // s_waitcnt vmcnt(0) + barrier: every wave's pieces have landed
+                    RFI_T(t3);
                     if (!(d.diag & 1)) {
-#pragma unroll
-                        for (int tap = 0; tap < C::NTAP; ++tap) {
+                        // software pipeline over the taps: the fragments of tap t+1 are read from LDS BEFORE the MFMAs
+                        // of tap t are issued, so their LDS latency hides under those MFMAs (hipcc otherwise sinks every
+                        // ds_read to just before its first use and the matrix pipe idles for one LDS round trip per
+                        // fragment: measured 66 % duty in this phase).  The fences pin "reads of t+1, then MFMAs of t".
+                        bf16x8 afr[2][MT][P], bfr[2][NTL][P];
+                        auto load_frags = [&](int tap, bf16x8 (&af)[MT][P], bf16x8 (&bf)[NTL][P]) {
                             const int tr = tap / R, ts = tap % R;
-                            bf16x8 bf[NTL][P];
 #pragma unroll
                             for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                                 for (int p = 0; p < P; ++p)
                                     bf[nt][p] = *reinterpret_cast<const bf16x8*>(sB + b_base + ((tap * C::NCBL + nt) * P + p) * 1024);
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) {
-                                bf16x8 af[P];
+                            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                                 for (int p = 0; p < P; ++p)
-                                    af[p] = *reinterpret_cast<const bf16x8*>(sA + a_base[mt] + (tr * C::HW + ts) * C::ROWB + p * 32);
+                                    af[mt][p] = *reinterpret_cast<const bf16x8*>(sA + a_base[mt] + (tr * C::HW + ts) * C::ROWB + p * 32);
+                        };
+                        load_frags(0, afr[0], bfr[0]);
 #pragma unroll
-                                for (int nt = 0; nt < NTL; ++nt) acc[g][mt][nt] = mma<P>(af, bf[nt], acc[g][mt][nt]);
-                            }
+                        for (int tap = 0; tap < C::NTAP; ++tap) {
+                            if (tap + 1 < C::NTAP) load_frags(tap + 1, afr[(tap + 1) & 1], bfr[(tap + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NTL; ++nt)
+                                    acc[g][mt][nt] = mma<P>(afr[tap & 1][mt], bfr[tap & 1][nt], acc[g][mt][nt]);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    RFI_T(t4);
                     __syncthreads();                 // every wave is done reading the halo tile (and, after the last tile
-                }                                    // of the group, the filter tile)
+                    RFI_T(t5);                       // of the group, the filter tile)
+#ifdef RFI_DIAG_STAMPS
+                    RFI_ACC(0, t0, t1); RFI_ACC(1, t1, t2); RFI_ACC(2, t2, t3); RFI_ACC(3, t3, t4); RFI_ACC(4, t4, t5);
+                    ++nitem_;
+#endif
+                }
             }
         }
+        RFI_T(te0);
         epilogue_group(g0);
         // the staging area (aliased by the scratch) is about to be overwritten: every wave must be done with its
         // scratch READS (lgkmcnt), but nobody has to wait for the output stores to retire (a __syncthreads() would
         // add s_waitcnt vmcnt(0): one exposed HBM write latency per group)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef RFI_DIAG_STAMPS
+        { RFI_T(te1); RFI_ACC(5, te0, te1); }
+#endif
     }
+#ifdef RFI_DIAG_STAMPS
+    if (d.stamps && lane == 0) {
+        unsigned long long* o = d.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * C::NW + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = st_[i];
+        o[6] = nitem_;
+        o[7] = (unsigned long long)my_tiles;
+    }
+#endif
     if (st_out) {
         __syncthreads();
         if (tid < C::BN && n0 + tid < a.Cout) {      // channel tid of the tile: waves (m, wn_c) cover it
@@ -366,9 +413,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     }
 }
 
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G>
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1>
 void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
-    using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G>;
+    using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>;
     PConvArgs& a = d.a;
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
     const int ychunks = (int)cdiv(d.ncb, C::NCBL);
@@ -387,19 +434,45 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
     else { a.stats = nullptr; a.stats_records = 0; }
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
-    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+#ifdef RFI_DIAG_STAMPS
+    {
+        const size_t nw = (size_t)GX * ychunks * C::NW;
+        RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d.stamps), nw * 64));
+        RFI_CHECK_HIP(hipMemsetAsync(d.stamps, 0, nw * 64, ctx->stream));
+        hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+        std::vector<unsigned long long> hs(nw * 8);
+        RFI_CHECK_HIP(hipMemcpyAsync(hs.data(), d.stamps, nw * 64, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) sm[i] += (double)hs[w * 8 + i];
+        std::fprintf(stderr, "[stamps] pconv P%d tile %dx%d grid %dx%d items/wave %.1f tiles/wg %.1f | cycles per item: issue %.0f "
+                     "vmwait %.0f bar1 %.0f mfma %.0f bar2 %.0f | epilogue per group %.0f\n", P, TH, TW, GX, ychunks, sm[6] / nw,
+                     sm[7] / nw, sm[0] / sm[6], sm[1] / sm[6], sm[2] / sm[6], sm[3] / sm[6], sm[4] / sm[6], sm[5] / (sm[7] / G));
+        RFI_CHECK_HIP(hipFree(d.stamps));
+        d.stamps = nullptr;
+        return;
+    }
+#endif
+    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
     check_launch("pconv");
 }
 
+// Tile choice by output width.  Measured and NOT kept (round 2, gpurun_out/r2k-r2m): groups of 4 tiles, 64-channel
+// workgroup tiles, halo rows without the pad slot (-20..-38 % staged bytes per MFMA: +-3 %); a start delay for the
+// second workgroup of each CU (no effect); one 8-wave workgroup per CU with every buffer doubled and the prefetch
+// DMA issued between the MFMAs of the previous item (same time for float32 pieces, 15-30 % slower for bf16).  The
+// kernel sits at 1.0-1.2 PFLOP/s of executed bf16 MFMA on the deep layers (the float32-by-3xbf16 arithmetic: x 1/6),
+// which is where the best known hand-scheduled GEMM of the CDNA4 guide ends on random data (1.32-1.34 PFLOP/s at a
+// sustained 1.9 GHz); the 32-channel layers are bound by HBM (6 B per activation element in, 4 B out).
 template <int P>
 void dispatch(rfi_ctx* ctx, PConvDev& d) {
     const PConvArgs& a = d.a;
-    if (a.W >= 32) launch_cfg<3, 1, 8, 32, 4, 1, 2, 1, P, 2>(ctx, d);
-    else if (a.W >= 16) launch_cfg<3, 1, 16, 16, 4, 1, 2, 1, P, 2>(ctx, d);
-    else launch_cfg<3, 1, 8, 8, 2, 2, 1, 1, P, 2>(ctx, d);
+    if (a.W >= 32) launch_cfg<3, 1, 8, 32, 4, 1, 2, 1, P, 2, 1>(ctx, d);
+    else if (a.W >= 16) launch_cfg<3, 1, 16, 16, 4, 1, 2, 1, P, 2, 1>(ctx, d);
+    else launch_cfg<3, 1, 8, 8, 2, 2, 1, 1, P, 2, 1>(ctx, d);
 }
 
 }  // namespace
@@ -424,6 +497,7 @@ void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
     d.wb_zero = (unsigned)wbytes;                      // ... and so is every wB tensor
     static const int diag = getenv("RFI_PCONV_DIAG") ? atoi(getenv("RFI_PCONV_DIAG")) : 0;
     d.diag = diag;
+    d.stamps = nullptr;
     RFI_REQUIRE((int64_t)a.N * a.Hout * a.Wout * a.y_pstride < (int64_t)1 << 31, "pconv: output too large for 32-bit offsets");
     const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cout * 9 * 16.0 * d.nkc;
     std::string label;
