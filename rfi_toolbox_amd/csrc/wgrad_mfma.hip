@@ -18,6 +18,10 @@ namespace rfi {
 
 void launch_wgrad_direct(rfi_ctx* ctx, const WgradArgs& a);
 size_t wgrad_direct_slab_floats(const WgradArgs& a);
+// wgrad_split.hip: the 3 x bf16 arithmetic with the operands split once at staging time (3x3 layers)
+bool wgrad_split_eligible(const WgradArgs& a);
+size_t wgrad_split_slab_floats(const WgradArgs& a);
+void launch_wgrad_split(rfi_ctx* ctx, const WgradArgs& a);
 
 namespace {
 
@@ -438,6 +442,7 @@ size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
     if ((impl == IMPL_PLANES_X3 || impl == IMPL_PLANES_BF16) && a.R == 3 && a.S == 1)
         return std::max(need, pwgrad_slab_floats_f32(a));
     if (impl == IMPL_MFMA_BF16 || impl == IMPL_MFMA_BF16X3) impl = IMPL_MFMA;
+    if (impl != IMPL_DIRECT && wgrad_split_eligible(a)) need = std::max(need, wgrad_split_slab_floats(a));
     if (impl != IMPL_DIRECT && wgrad_mfma_eligible(a)) {
         const Plan p = dispatch(nullptr, a, SEL_PLAN, 256);
         // plan with the largest CU count we may meet so the workspace always suffices
@@ -470,6 +475,11 @@ void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
     if (impl == IMPL_MFMA) RFI_REQUIRE(ok, "wgrad: shape/alignment not eligible for the MFMA kernel");
     if (impl == IMPL_DIRECT || !ok) {
         launch_wgrad_direct(ctx, a);
+        return;
+    }
+    static const bool old_x3 = getenv("RFI_OLD_WGRAD") != nullptr;       // round 1's split-per-fragment kernel (A/B runs)
+    if (a.bf16x3 && !old_x3 && wgrad_split_eligible(a)) {
+        launch_wgrad_split(ctx, a);
         return;
     }
     dispatch(ctx, a, SEL_LAUNCH, 256);   // MI355X: 256 CUs (the plan fixes the slab workspace size)

@@ -169,22 +169,60 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
     for (int k = 0; k < my_tiles; ++k) {
         issue_tile(split + k * d.nsplit);
         __syncthreads();                             // s_waitcnt vmcnt(0) + barrier: the images have landed
+        if constexpr (P == 3) {       // (the pipelined form below spills here: 144 accumulators + two fragment sets of 3 planes)
 #pragma unroll
-        for (int kk = 0; kk < C::KS_W; ++kk) {
-            const int t0 = (ps * C::KS_W + kk) * 16 + 8 * kh + q, t1 = t0 + 4;
-            bf16x8 af[P];
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-                af[p] = tr_frag(yimg + ypix(t0) * C::ROW + p * 64, yimg + ypix(t1) * C::ROW + p * 64);
-            const int x0 = xpix(t0), x1 = xpix(t1);
-#pragma unroll
-            for (int tap = 0; tap < C::NTAP; ++tap) {
-                const int toff = ((tap / R) * C::HW + (tap % R)) * C::ROW;
-                bf16x8 bf[P];
-#pragma unroll
+            for (int kk = 0; kk < C::KS_W; ++kk) {
+                const int t0 = (ps * C::KS_W + kk) * 16 + 8 * kh + q, t1 = t0 + 4;
+                bf16x8 af[P];
+    #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    bf[p] = tr_frag(ximg + x0 * C::ROW + toff + p * 64, ximg + x1 * C::ROW + toff + p * 64);
-                acc[tap] = mma<P>(af, bf, acc[tap]);
+                    af[p] = tr_frag(yimg + ypix(t0) * C::ROW + p * 64, yimg + ypix(t1) * C::ROW + p * 64);
+                const int x0 = xpix(t0), x1 = xpix(t1);
+    #pragma unroll
+                for (int tap = 0; tap < C::NTAP; ++tap) {
+                    const int toff = ((tap / R) * C::HW + (tap % R)) * C::ROW;
+                    bf16x8 bf[P];
+    #pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        bf[p] = tr_frag(ximg + x0 * C::ROW + toff + p * 64, ximg + x1 * C::ROW + toff + p * 64);
+                    acc[tap] = mma<P>(af, bf, acc[tap]);
+                }
+            }
+        } else {
+        // software pipeline over (k-step, tap): the Xop fragment of the NEXT tap is read from LDS before the MFMAs of
+            // the current one are issued (hipcc otherwise sinks each transposing read to just before its use and the matrix
+            // pipe idles for an LDS round trip per tap); the fences pin "reads of the next tap, then MFMAs of this one"
+            {
+                bf16x8 af[P], bfr[2][P];
+                auto load_a = [&](int kk) {
+                    const int t0 = (ps * C::KS_W + kk) * 16 + 8 * kh + q, t1 = t0 + 4;
+    #pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        af[p] = tr_frag(yimg + ypix(t0) * C::ROW + p * 64, yimg + ypix(t1) * C::ROW + p * 64);
+                };
+                auto load_b = [&](int kk, int tap, bf16x8 (&bf)[P]) {
+                    const int t0 = (ps * C::KS_W + kk) * 16 + 8 * kh + q, t1 = t0 + 4;
+                    const int x0 = xpix(t0), x1 = xpix(t1);
+                    const int toff = ((tap / R) * C::HW + (tap % R)) * C::ROW;
+    #pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        bf[p] = tr_frag(ximg + x0 * C::ROW + toff + p * 64, ximg + x1 * C::ROW + toff + p * 64);
+                };
+                load_b(0, 0, bfr[0]);
+    #pragma unroll
+                for (int kk = 0; kk < C::KS_W; ++kk) {
+                    load_a(kk);
+    #pragma unroll
+                    for (int tap = 0; tap < C::NTAP; ++tap) {
+                        constexpr int NT_ = C::NTAP;
+                        const int cur = (kk * NT_ + tap) & 1;
+                        if (tap + 1 < NT_) load_b(kk, tap + 1, bfr[cur ^ 1]);
+                        else if (kk + 1 < C::KS_W) load_b(kk + 1, 0, bfr[cur ^ 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[tap] = mma<P>(af, bfr[cur], acc[tap]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
         }
         __syncthreads();                             // everybody is done reading before the next tile is staged
