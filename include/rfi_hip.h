@@ -194,6 +194,13 @@ int rfi_comm_init(rfi_ctx* ctx, const void* id_buf128, int rank, int world_size)
 int rfi_comm_destroy(rfi_ctx* ctx);
 int rfi_comm_allreduce_sum_f32(rfi_ctx* ctx, float* dptr, int64_t count);
 int rfi_model_allreduce_grads(rfi_model* m);   /* all-reduce(sum) of the grad buffer */
+/* Inside rfi_train_step / rfi_train_step_async the exchange is BUCKETED and overlapped with the backward pass:
+ * contiguous ranges of the flat gradient buffer (head + decoder1, decoder2, ..., bottleneck, encoderD, ..., encoder1
+ * -- the order the backward pass finishes them) are all-reduced on a separate HIP stream as soon as their last
+ * producer kernel has been enqueued.  rfi_comm_emulate(ctx, W) (tests on ONE GPU; W >= 2, 0 = off) replaces every
+ * bucket's all-reduce by "multiply the range by W" and the step applies grad_scale = 1/W: the step then equals the
+ * plain step bit for bit iff every element is exchanged exactly once, after its producers and before clip + Adam. */
+int rfi_comm_emulate(rfi_ctx* ctx, int world);
 
 /* ---- preprocessing: replaces the per-patch hot loop of Preprocessor.create_dataset
  *      (preprocessing/preprocessor.py:366-384: _extract_channels_from_complex :562-606 /

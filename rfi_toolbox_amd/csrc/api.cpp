@@ -101,6 +101,7 @@ int rfi_ctx_create(int device_id, rfi_ctx** out) {
         RFI_CHECK_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr_greatest));
         c->main_stream = c->stream;
         RFI_CHECK_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, pr_least));
+        RFI_CHECK_HIP(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, pr_least));
         RFI_CHECK_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
         c->side_done.resize(4);
         for (auto& e : c->side_done) RFI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -129,6 +130,9 @@ int rfi_ctx_destroy(rfi_ctx* ctx) {
         hipStreamSynchronize(ctx->side_stream);
         hipEventDestroy(ctx->fork_ev);
         for (auto e : ctx->side_done) hipEventDestroy(e);
+        hipStreamSynchronize(ctx->comm_stream);
+        for (auto e : ctx->bucket_ev) hipEventDestroy(e);
+        hipStreamDestroy(ctx->comm_stream);
         hipStreamDestroy(ctx->side_stream);
         hipStreamDestroy(ctx->main_stream);
         delete ctx;
@@ -617,15 +621,21 @@ void check_hyper(const rfi_hyper* hp) {
     RFI_REQUIRE(hp->beta1 >= 0 && hp->beta1 < 1 && hp->beta2 >= 0 && hp->beta2 < 1, "Adam: betas must be in [0,1)");
 }
 
-void comm_allreduce_sum(rfi_ctx* ctx, float* dptr, int64_t count);   // RCCL section below; throws
 
 // The optimiser half of a full training step, shared by rfi_train_step and rfi_train_step_async: when the
 // context holds a communicator of more than one rank the flat gradient buffer is summed over the ranks
 // (RCCL, on this context's stream) and clip + Adam see the MEAN gradient (grad_scale = 1 / world).
+void backward_with_exchange(rfi_model* m, const float* x, const uint8_t* y, int n, int h, int w) {
+    struct Flag { rfi_model* m; ~Flag() { m->exchange_in_backward = false; } } flag{m};
+    m->exchange_in_backward = true;               // the buckets leave as the backward pass finishes them
+    m->backward(x, y, n, h, w);
+}
 void exchange_and_apply(rfi_model* m, const rfi_hyper& hp) {
-    if (m->ctx->nccl_comm && m->ctx->world > 1) {
-        comm_allreduce_sum(m->ctx, m->grads, (int64_t)m->n_flat);
-        m->apply(hp, 1.0f / (float)m->ctx->world);
+    if (m->ctx->exchange_active()) {
+        // the buckets were all-reduced on the communication stream while the backward pass ran (rfi_model::
+        // bucket_ready); exchange_join makes the main stream wait for the last of them
+        m->exchange_join();
+        m->apply(hp, 1.0f / (float)m->ctx->exchange_world());
     } else {
         m->apply(hp, 1.0f);
     }
@@ -686,7 +696,7 @@ int rfi_train_step(rfi_model* m, const float* x, int x_mem, const uint8_t* label
         const uint8_t* yd = stage_labels(m, labels, labels_mem, n, h, w);
         m->forward(xd, n, h, w, true);
         m->loss_forward(yd, n, h, w);
-        m->backward(xd, yd, n, h, w);
+        backward_with_exchange(m, xd, yd, n, h, w);
         exchange_and_apply(m, *hp);
         RFI_CHECK_HIP(hipMemcpyAsync(m->ctx->pinned, m->d_scalars, 2 * sizeof(float), hipMemcpyDeviceToHost,
                                      m->ctx->stream));
@@ -704,7 +714,7 @@ int rfi_train_step_async(rfi_model* m, const float* x_dev, const uint8_t* labels
         m->prepare(n, h, w);
         m->forward(x_dev, n, h, w, true);
         m->loss_forward(labels_dev, n, h, w);
-        m->backward(x_dev, labels_dev, n, h, w);
+        backward_with_exchange(m, x_dev, labels_dev, n, h, w);
         exchange_and_apply(m, *hp);
     });
 }
@@ -937,6 +947,32 @@ void comm_allreduce_sum(rfi_ctx* ctx, float* dptr, int64_t count) {
 int rfi_comm_allreduce_sum_f32(rfi_ctx* ctx, float* dptr, int64_t count) {
     return guarded([&] { comm_allreduce_sum(ctx, dptr, count); });
 }
+int rfi_comm_emulate(rfi_ctx* ctx, int world) {
+    return guarded([&] {
+        RFI_REQUIRE(world == 0 || world >= 2, "rfi_comm_emulate: world must be 0 (off) or >= 2");
+        RFI_REQUIRE(!(ctx->nccl_comm && ctx->world > 1), "rfi_comm_emulate: a real communicator is active");
+        ctx->activate();
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->main_stream));
+        ctx->comm_emulate = world;
+    });
+}
+}  // extern "C"
+namespace rfi {
+// one bucket of the gradient exchange, on the context's communication stream (the caller orders it by events)
+void comm_bucket_allreduce(rfi_ctx* ctx, float* dptr, int64_t count) {
+    hipStream_t keep = ctx->stream;
+    ctx->stream = ctx->comm_stream;
+    struct Restore { rfi_ctx* c; hipStream_t s; ~Restore() { c->stream = s; } } restore{ctx, keep};
+    if (ctx->comm_emulate > 1) {
+        launch_scale_inplace(ctx, dptr, count, (float)ctx->comm_emulate);
+        return;
+    }
+    load_nccl();
+    ProfScope ps(ctx, FAM_COMM, 0, (double)count * 4);
+    nccl_check(g_nccl.AllReduce(dptr, dptr, (size_t)count, 7, 0, ctx->nccl_comm, ctx->comm_stream), "ncclAllReduce");
+}
+}  // namespace rfi
+extern "C" {
 int rfi_model_allreduce_grads(rfi_model* m) {
     return rfi_comm_allreduce_sum_f32(m->ctx, m->grads, (int64_t)m->n_flat);
 }

@@ -113,9 +113,19 @@ struct rfi_ctx {
     hipEvent_t fork_ev = nullptr;
     std::vector<hipEvent_t> side_done;   // ring, one per in-flight side launch
     bool overlap = true;
-    // RCCL
+    // RCCL.  The gradient exchange is BUCKETED: contiguous ranges of the flat gradient buffer are all-reduced on
+    // comm_stream as soon as the backward pass has finished them (reverse layer order), next to the remaining
+    // backward kernels.  comm_emulate > 1 (rfi_comm_emulate, tests on one GPU): no communicator; every "all-reduce"
+    // multiplies its range by comm_emulate, so with grad_scale = 1 / comm_emulate a step must reproduce the plain
+    // step bit for bit iff every element is exchanged exactly once and in order with its producers and consumers.
     void* nccl_comm = nullptr;
     int rank = 0, world = 1;
+    int comm_emulate = 0;
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> bucket_ev;   // pool: (main, side, done) events of the buckets of one step
+    size_t bucket_ev_used = 0;
+    bool exchange_active() const { return (nccl_comm && world > 1) || comm_emulate > 1; }
+    int exchange_world() const { return comm_emulate > 1 ? comm_emulate : world; }
 
     void* alloc(size_t bytes);
     void release(void* p);

@@ -548,6 +548,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
 // LDS bytes -> resident workgroups per CU (160 KiB LDS, <= 8 waves/SIMD is never the limit here)
 static int occupancy_for(size_t lds_bytes) {
+    static const int cap = getenv("RFI_CONV_OCC") ? atoi(getenv("RFI_CONV_OCC")) : 0;     // tuning experiments
+    if (cap > 0) return cap;
     int o = (int)((160 * 1024) / lds_bytes);
     return o < 1 ? 1 : (o > 3 ? 3 : o);   // VGPRs: <= 215 for the 72 KB tiles (2 waves/SIMD), <= 151 for the others (3)
 }

@@ -842,6 +842,9 @@ __global__ void adam_kernel(AdamArgs a) {
 
 // out[i] = sum_{k<count} slabs[(base + k*kstride) * n + i]; grid.y selects the group:
 // base = blockIdx.y * group, out row = blockIdx.y * out_rowstride (in units of n)
+__global__ void scale_inplace_kernel(float* __restrict__ x, int64_t n, float f) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= f;
+}
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, int group, int kstride,
                                     int64_t n, float* __restrict__ out, int64_t out_rowstride) {
     const int base = blockIdx.y * group;
@@ -1213,6 +1216,12 @@ void launch_adam(rfi_ctx* ctx, const AdamArgs& a) {
     check_launch("adam");
 }
 
+void launch_scale_inplace(rfi_ctx* ctx, float* x, int64_t n, float f) {
+    if (n <= 0) return;
+    ProfScope ps(ctx, FAM_COMM, 0, (double)n * 8);
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, x, n, f);
+    check_launch("scale_inplace");
+}
 void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n, float* out) {
     // fold groups of 32 slabs in place (each group's sum lands in the group's first slab) until
     // at most 32 partial slabs remain, then sum those into `out`.  Fixed order -> reproducible.

@@ -242,6 +242,8 @@ void launch_confusion(rfi_ctx* ctx, const void* pred, int pred_dtype, const void
 void launch_threshold(rfi_ctx* ctx, const float* logits, int64_t count, float threshold,
                       uint8_t* mask);
 
+// x[i] *= f  (the emulated gradient exchange of the single-GPU tests, rfi_comm_emulate)
+void launch_scale_inplace(rfi_ctx* ctx, float* x, int64_t n, float f);
 // generic: out[i] = sum_s slabs[s*n + i]
 void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n, float* out);
 

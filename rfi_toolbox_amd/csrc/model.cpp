@@ -541,6 +541,36 @@ void rfi_model::side_join() {
     side_seq = 0;
 }
 
+namespace rfi { void comm_bucket_allreduce(rfi_ctx* ctx, float* dptr, int64_t count); }
+
+static hipEvent_t bucket_event(rfi_ctx* ctx) {
+    if (ctx->bucket_ev_used == ctx->bucket_ev.size()) {
+        hipEvent_t e;
+        RFI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->bucket_ev.push_back(e);
+    }
+    return ctx->bucket_ev[ctx->bucket_ev_used++];
+}
+void rfi_model::bucket_ready(size_t lo, size_t hi) {
+    if (!exchange_in_backward || !ctx->exchange_active() || hi <= lo) return;
+    hipEvent_t em = bucket_event(ctx);
+    RFI_CHECK_HIP(hipEventRecord(em, ctx->main_stream));
+    RFI_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, em, 0));
+    if (ctx->overlap) {                           // weight gradients and their slab reductions run on the side stream
+        hipEvent_t es = bucket_event(ctx);
+        RFI_CHECK_HIP(hipEventRecord(es, ctx->side_stream));
+        RFI_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, es, 0));
+    }
+    comm_bucket_allreduce(ctx, grads + lo, (int64_t)(hi - lo));
+}
+void rfi_model::exchange_join() {
+    if (!ctx->exchange_active()) return;
+    hipEvent_t e = bucket_event(ctx);
+    RFI_CHECK_HIP(hipEventRecord(e, ctx->comm_stream));
+    RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, e, 0));
+    ctx->bucket_ev_used = 0;                      // the pool is reused by the next step
+}
+
 namespace {
 
 // launches inside a SideScope go to the side stream; if one throws, the context's stream is put back
@@ -621,7 +651,11 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
 }  // namespace
 
 void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
-    if (arch == 1) return backward_cnn3(x_dev, labels_dev, n, h, w);
+    if (arch == 1) {
+        backward_cnn3(x_dev, labels_dev, n, h, w);
+        bucket_ready(0, n_flat);                  // three layers: one bucket
+        return;
+    }
     const int D = depth;
     const int64_t M1 = (int64_t)n * h * w;
     refresh_dgrad_weights();
@@ -700,6 +734,8 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         }
         launch_conv(ctx, a);
         pending_records = a.stats_records;
+        // gradients of decoder level l (and, for l = 1, of the head) are complete: exchange them now
+        bucket_ready(u.w_off, l == 1 ? n_flat : ups[k + 1].w_off);
     }
     // bottleneck
     {
@@ -710,6 +746,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
                                    buf(gBottB), pending_records, &c1, buf(bottY1));
         backward_conv_bn(this, c1, buf(gBottB), buf(bottY1), View{buf(pool[D]), c1.cin}, InXform{}, s,
                          buf(dpool[D]), rec, nullptr, nullptr);
+        bucket_ready(c1.w_off, ups[0].w_off);
     }
     // encoders, deep to shallow
     for (int l = D; l >= 1; --l) {
@@ -724,6 +761,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
                            : View{buf(pool[l - 1]), c1.cin};
         backward_conv_bn(this, c1, buf(gB[l]), buf(encY1[l]), in, InXform{}, s,
                          (l == 1) ? nullptr : buf(dpool[l - 1]), rec, nullptr, nullptr);
+        bucket_ready(c1.w_off, convs[2 * l].w_off);       // convs[2 l] = first conv of the next level / the bottleneck
     }
     side_join();
 }

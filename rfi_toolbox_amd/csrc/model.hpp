@@ -157,6 +157,11 @@ struct rfi_model {
     void side_begin();                // side stream waits for everything enqueued on the main stream so far
     void side_end();                  // marks the side launch; bounds the main stream's run-ahead
     void side_join();                 // main stream waits for all side work
+    // bucketed gradient exchange (common.hpp): grads[lo, hi) are final once everything enqueued so far on the main
+    // and side streams has run -> all-reduce them on the communication stream; exchange_join: main waits for all
+    bool exchange_in_backward = false;   // set by the full-step entry points only (the split API exchanges explicitly)
+    void bucket_ready(size_t lo, size_t hi);
+    void exchange_join();
     // BN-apply + activation of layer c as a load transform for its consumers (slope 0 = ReLU)
     rfi::InXform bn_xf(const rfi::ConvBN& c) const { return rfi::act_xform(c.scale(), c.shift(), act_slope); }
     void refresh_dgrad_weights();

@@ -352,12 +352,14 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         a.bf16 = compute_bf16;
         a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
+        bucket_ready(u.w_off, l == 1 ? n_flat : ups[k + 1].w_off);      // decoder level l (+ head) is complete
     }
     {                                             // bottleneck
         Shape s{n, h >> D, w >> D};
         const PlaneSeg a1 = seg_of(pl[pA1b]), p4 = seg_of(pl[pPool[D]]);
         backward_pconv_bn(this, convs[2 * D + 1], buf(gBottA), buf(bottY2), &a1, 1, s, buf(gBottB), pl[pdYbottA]);
         backward_pconv_bn(this, convs[2 * D], buf(gBottB), buf(bottY1), &p4, 1, s, buf(dpool[D]), pl[pdYbottB]);
+        bucket_ready(convs[2 * D].w_off, ups[0].w_off);
     }
     for (int l = D; l >= 1; --l) {                // encoders, deep to shallow
         Shape s{n, h >> (l - 1), w >> (l - 1)};
@@ -369,6 +371,7 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         backward_pconv_bn(this, c2, buf(gA[l]), buf(encY2[l]), &a1, 1, s, buf(gB[l]), pl[pdYa[l]]);
         const PlaneSeg in = seg_of(l == 1 ? pl[pXin] : pl[pPool[l - 1]]);
         backward_pconv_bn(this, c1, buf(gB[l]), buf(encY1[l]), &in, 1, s, (l == 1) ? nullptr : buf(dpool[l - 1]), pl[pdYb[l]]);
+        bucket_ready(c1.w_off, convs[2 * l].w_off);
     }
     side_join();
 }

@@ -298,7 +298,8 @@ template <int R, int S, int BYB, int BXB, int TH, int TW>
 Plan plan_cfg(const WgradArgs& a) {
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
     const int chunks = (int)cdiv(a.Cy, 32 * BYB) * (int)cdiv(a.Cx, 32 * BXB);
-    int nsplit = (int)cdiv(512, chunks);             // two workgroups per CU in total
+    static const int wgs = getenv("RFI_WGRAD_WGS") ? atoi(getenv("RFI_WGRAD_WGS")) : 512;    // tuning experiments
+    int nsplit = (int)cdiv(wgs, chunks);             // two workgroups per CU in total
     if (nsplit > ntiles) nsplit = ntiles;
     if (nsplit < 1) nsplit = 1;
     return Plan{nsplit, (int64_t)R * R * a.tap_stride};

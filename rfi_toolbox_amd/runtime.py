@@ -132,6 +132,10 @@ class Context:
         check(lib.rfi_comm_unique_id(buf))
         return buf.raw
 
+    def comm_emulate(self, world: int):
+        """Single-GPU test mode of the bucketed gradient exchange (0 = off): see include/rfi_hip.h."""
+        check(lib.rfi_comm_emulate(self.handle, int(world)))
+
     def comm_destroy(self):
         if self._comm:
             check(lib.rfi_comm_destroy(self.handle))

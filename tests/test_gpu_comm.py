@@ -211,3 +211,41 @@ def test_rccl_two_ranks_public_train_step(tmp_path):
     if n.value < 2:
         pytest.skip("needs >= 2 GPUs in one box (the build/test pool has 1-GPU boxes)")
     _check_against_emulation(_launch_ddp(2, tmp_path), 2, 2)
+
+
+@pytest.mark.parametrize("mode", ["float32", "bfloat16"])
+def test_bucketed_exchange_emulation_is_bitwise_neutral(mode):
+    """The bucketed, overlapped gradient exchange on ONE GPU (include/rfi_hip.h, rfi_comm_emulate): every bucket's
+    all-reduce is replaced by 'multiply the range by 2' on the communication stream and the step applies
+    grad_scale = 1/2.  Scaling by powers of two is exact, so weights, Adam moments and the reported gradient norm
+    must equal the plain step bit for bit -- iff every element of the flat gradient buffer is exchanged exactly
+    once, after its last producer (main and side streams) and before clip + Adam.  Three steps, so that a stale
+    event or a bucket racing the next step's backward pass would show."""
+    ctx = Context.get(0)
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(4, 64, 64, 3, generator=g)
+    y = (torch.rand(4, 64, 64, generator=g) > 0.7).to(torch.uint8)
+    dx, dy = ctx.to_device(x.numpy()), ctx.to_device(y.numpy())
+    hp = Hyper(1e-3, 0.9, 0.999, 1e-8, 1e-5, 1.0)
+    out = []
+    try:
+        for world in (0, 2):
+            ctx.comm_emulate(world)
+            torch.manual_seed(23)
+            m = UNet(3, 1, 16).set_compute_dtype(mode)
+            stats = []
+            for i in range(3):
+                if i == 1:
+                    m.train_step_async(dx.ptr, dy.ptr, 4, 64, 64, hp)        # both full-step entry points
+                    stats.append(m.last_loss())
+                else:
+                    stats.append((m.train_step(x, y, lr=1e-3), m.last_loss()[1]))
+            out.append((stats, m.state_dict(), m.adam_state("bottleneck.conv.3.weight"), m.adam_state("final_conv.bias")))
+    finally:
+        ctx.comm_emulate(0)
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    for i in (2, 3):
+        np.testing.assert_array_equal(out[0][i][0], out[1][i][0])
+        np.testing.assert_array_equal(out[0][i][1], out[1][i][1])
