@@ -290,6 +290,19 @@ int rfi_op_convt2x2_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h,
                           const float* w_iohw, int cin, float* dx);
 int rfi_op_convt2x2_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy, int n, int h,
                           int w, int cin, int cout, float* dw_iohw);
+/* Building blocks of the Mask R-CNN path of BASELINE.json configs[3].  NOT in the reference
+ * (no detector code exists there, docs/API.md:180 and README.md:90 only name one); defined by the published
+ * algorithms: RoIAlign (He et al. 2017; the sampling rules of the public torchvision.ops.roi_align: rois =
+ * r x (batch index, x1, y1, x2, y2), bilinear samples, sampling_ratio <= 0 -> ceil(roi extent / bins), `aligned`
+ * shifts by half a pixel) over an NHWC float32 feature map, out [r][ph][pw][c]; and the FPN top-down merge (Lin et
+ * al. 2017): out = lateral + nearest-neighbour 2x upsampling of top [n][ceil(h/2)][ceil(w/2)][c].  Device pointers. */
+int rfi_op_roi_align(rfi_ctx* ctx, const float* x, int n, int h, int w, int c, const float* rois, int r,
+                     float spatial_scale, int ph, int pw, int sampling_ratio, int aligned, float* out);
+int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, const float* rois,
+                              int r, float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
+                              float* dx);
+int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out);
+int rfi_op_fpn_merge_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, float* dtop);
 int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean, float* var_biased);
 /* a = relu(y*scale+shift): skip (n,h,w,c) and 2x2 max-pooled (n,h/2,w/2,c) */
 int rfi_op_bn_relu_pool(rfi_ctx* ctx, const float* y, int n, int h, int w, int c, const float* scale,

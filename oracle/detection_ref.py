@@ -1,0 +1,108 @@
+"""NumPy oracle of the detection building blocks (RoIAlign, FPN top-down merge).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED BY THE REFERENCE: preshanth/rfi_toolbox contains no detector (README.md:90 and docs/API.md:180 only
+name a "detector"), and torchvision is absent from this image, so these functions restate the PUBLISHED algorithms
+-- RoIAlign of He et al. 2017 with the sampling rules of the public torchvision.ops.roi_align, and the top-down
+pathway of Lin et al. 2017 -- in plain float64 loops.  Feature maps are NHWC like every tensor of the path."""
+import math
+
+import numpy as np
+
+
+def _bilinear(feat, y, x):
+    """feat (H, W, C); torchvision's rule: outside [-1, H] x [-1, W] -> 0, else clamp and interpolate."""
+    H, W, _ = feat.shape
+    if y < -1.0 or y > H or x < -1.0 or x > W:
+        return None
+    y, x = max(y, 0.0), max(x, 0.0)
+    y0, x0 = int(y), int(x)
+    if y0 >= H - 1:
+        y1 = y0 = H - 1
+        y = float(y0)
+    else:
+        y1 = y0 + 1
+    if x0 >= W - 1:
+        x1 = x0 = W - 1
+        x = float(x0)
+    else:
+        x1 = x0 + 1
+    ly, lx = y - y0, x - x0
+    hy, hx = 1.0 - ly, 1.0 - lx
+    return (y0, x0, y1, x1), (hy * hx, hy * lx, ly * hx, ly * lx)
+
+
+def _geom(roi, scale, PH, PW, sr, aligned):
+    off = 0.5 if aligned else 0.0
+    x1, y1 = roi[1] * scale - off, roi[2] * scale - off
+    rw, rh = roi[3] * scale - off - x1, roi[4] * scale - off - y1
+    if not aligned:
+        rw, rh = max(rw, 1.0), max(rh, 1.0)
+    gh = sr if sr > 0 else int(math.ceil(rh / PH))
+    gw = sr if sr > 0 else int(math.ceil(rw / PW))
+    return int(roi[0]), y1, x1, rh / PH, rw / PW, gh, gw
+
+
+def roi_align(x, rois, spatial_scale, output_size, sampling_ratio=2, aligned=False):
+    """x (N, H, W, C) float; rois (R, 5) = (batch index, x1, y1, x2, y2) -> (R, PH, PW, C) float64."""
+    PH, PW = output_size
+    x = np.asarray(x, np.float64)
+    out = np.zeros((len(rois), PH, PW, x.shape[-1]))
+    for r, roi in enumerate(np.asarray(rois, np.float64)):
+        n, y1, x1, bh, bw, gh, gw = _geom(roi, spatial_scale, PH, PW, sampling_ratio, aligned)
+        for ph in range(PH):
+            for pw in range(PW):
+                acc = np.zeros(x.shape[-1])
+                for iy in range(gh):
+                    yy = y1 + ph * bh + (iy + 0.5) * bh / gh
+                    for ix in range(gw):
+                        xx = x1 + pw * bw + (ix + 0.5) * bw / gw
+                        b = _bilinear(x[n], yy, xx)
+                        if b is None:
+                            continue
+                        (y0, x0, y1_, x1_), (w00, w01, w10, w11) = b
+                        acc += w00 * x[n, y0, x0] + w01 * x[n, y0, x1_] + w10 * x[n, y1_, x0] + w11 * x[n, y1_, x1_]
+                out[r, ph, pw] = acc / max(gh * gw, 1)
+    return out
+
+
+def roi_align_backward(dout, shape, rois, spatial_scale, output_size, sampling_ratio=2, aligned=False):
+    """Adjoint of roi_align: dout (R, PH, PW, C) -> dx `shape` = (N, H, W, C)."""
+    PH, PW = output_size
+    dx = np.zeros(shape)
+    dout = np.asarray(dout, np.float64)
+    for r, roi in enumerate(np.asarray(rois, np.float64)):
+        n, y1, x1, bh, bw, gh, gw = _geom(roi, spatial_scale, PH, PW, sampling_ratio, aligned)
+        for ph in range(PH):
+            for pw in range(PW):
+                g = dout[r, ph, pw] / max(gh * gw, 1)
+                for iy in range(gh):
+                    yy = y1 + ph * bh + (iy + 0.5) * bh / gh
+                    for ix in range(gw):
+                        xx = x1 + pw * bw + (ix + 0.5) * bw / gw
+                        b = _bilinear(dx[n], yy, xx)
+                        if b is None:
+                            continue
+                        (y0, x0, y1_, x1_), (w00, w01, w10, w11) = b
+                        dx[n, y0, x0] += w00 * g
+                        dx[n, y0, x1_] += w01 * g
+                        dx[n, y1_, x0] += w10 * g
+                        dx[n, y1_, x1_] += w11 * g
+    return dx
+
+
+def fpn_merge(lateral, top):
+    """lateral (N, H, W, C) + nearest-neighbour 2x upsampling of top (N, ceil(H/2), ceil(W/2), C)."""
+    lateral, top = np.asarray(lateral, np.float64), np.asarray(top, np.float64)
+    H, W = lateral.shape[1:3]
+    up = np.repeat(np.repeat(top, 2, axis=1), 2, axis=2)[:, :H, :W]
+    return lateral + up
+
+
+def fpn_merge_backward_top(dout):
+    """Gradient w.r.t. `top`: every coarse pixel sums its (up to) 2x2 children."""
+    dout = np.asarray(dout, np.float64)
+    N, H, W, C = dout.shape
+    Ht, Wt = (H + 1) // 2, (W + 1) // 2
+    pad = np.zeros((N, 2 * Ht, 2 * Wt, C))
+    pad[:, :H, :W] = dout
+    return pad.reshape(N, Ht, 2, Wt, 2, C).sum(axis=(2, 4))

@@ -96,6 +96,10 @@ _PROTOS = {
     "rfi_comm_init": (_i, [_vp, _vp, _i, _i]),
     "rfi_comm_destroy": (_i, [_vp]),
     "rfi_comm_emulate": (_i, [_vp, _i]),
+    "rfi_op_roi_align": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _i, _i, _i, _i, _vp]),
+    "rfi_op_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _i, _i, _i, _i, _vp]),
+    "rfi_op_fpn_merge": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rfi_op_fpn_merge_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rfi_comm_allreduce_sum_f32": (_i, [_vp, _vp, _i64]),
     "rfi_model_allreduce_grads": (_i, [_vp]),
     "rfi_preprocess_patches": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i]),

@@ -1403,6 +1403,32 @@ int rfi_op_convt2x2_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* d
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     });
 }
+int rfi_op_roi_align(rfi_ctx* ctx, const float* x, int n, int h, int w, int c, const float* rois, int r,
+                     float spatial_scale, int ph, int pw, int sampling_ratio, int aligned, float* out) {
+    return guarded([&] {
+        ctx->activate();
+        launch_roi_align_fwd(ctx, x, n, h, w, c, rois, r, spatial_scale, ph, pw, sampling_ratio, aligned != 0, out);
+    });
+}
+int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, const float* rois, int r,
+                              float spatial_scale, int ph, int pw, int sampling_ratio, int aligned, float* dx) {
+    return guarded([&] {
+        ctx->activate();
+        launch_roi_align_bwd(ctx, dout, n, h, w, c, rois, r, spatial_scale, ph, pw, sampling_ratio, aligned != 0, dx);
+    });
+}
+int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out) {
+    return guarded([&] {
+        ctx->activate();
+        launch_fpn_merge_fwd(ctx, lateral, top, n, h, w, c, out);
+    });
+}
+int rfi_op_fpn_merge_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, float* dtop) {
+    return guarded([&] {
+        ctx->activate();
+        launch_fpn_merge_bwd_top(ctx, dout, n, h, w, c, dtop);
+    });
+}
 int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean, float* var_biased) {
     return guarded([&] {
         ctx->activate();

@@ -1,0 +1,192 @@
+// Building blocks of the Mask R-CNN path named by BASELINE.json configs[3].  NOT in the
+// reference (it has no detector code; torchvision is absent from this image): defined by the published algorithms
+// (He et al. 2017, "Mask R-CNN", RoIAlign; Lin et al. 2017, "Feature Pyramid Networks", top-down pathway) and
+// checked against oracle/detection_ref.py -- parity unpinned by the reference.  NHWC float32 like every other
+// tensor of the path.  Both are HBM-bound gather / elementwise kernels: 16-byte channel-contiguous accesses.
+#include "kernels.hpp"
+
+namespace rfi {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Bilin { int y0, x0, y1, x1; float w00, w01, w10, w11; bool ok; };
+// torchvision's roi_align sampling rule: a point outside [-1, H] x [-1, W] contributes nothing; otherwise it is
+// clamped to the image and interpolated bilinearly
+__device__ __forceinline__ Bilin bilin(float y, float x, int H, int W) {
+    Bilin b;
+    b.ok = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int y0 = (int)y, x0 = (int)x, y1, x1;
+    if (y0 >= H - 1) { y1 = y0 = H - 1; y = (float)y0; } else y1 = y0 + 1;
+    if (x0 >= W - 1) { x1 = x0 = W - 1; x = (float)x0; } else x1 = x0 + 1;
+    const float ly = y - y0, lx = x - x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    b.y0 = y0; b.x0 = x0; b.y1 = y1; b.x1 = x1;
+    b.w00 = hy * hx; b.w01 = hy * lx; b.w10 = ly * hx; b.w11 = ly * lx;
+    return b;
+}
+
+struct RoiGeom { float y1, x1, bh, bw; int n; int gh, gw; };
+__device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ rois, int r, float scale, int PH, int PW, int sr, bool aligned) {
+    const float* q = rois + (int64_t)r * 5;                       // (batch index, x1, y1, x2, y2) in image coordinates
+    const float off = aligned ? 0.5f : 0.0f;
+    RoiGeom g;
+    g.n = (int)q[0];
+    g.x1 = q[1] * scale - off;
+    g.y1 = q[2] * scale - off;
+    float rw = q[3] * scale - off - g.x1, rh = q[4] * scale - off - g.y1;
+    if (!aligned) { rw = fmaxf(rw, 1.0f); rh = fmaxf(rh, 1.0f); }
+    g.bh = rh / PH;
+    g.bw = rw / PW;
+    g.gh = sr > 0 ? sr : (int)ceilf(rh / PH);
+    g.gw = sr > 0 ? sr : (int)ceilf(rw / PW);
+    return g;
+}
+
+// thread = (roi, ph, pw, 4 channels)
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                           const float* __restrict__ rois, int R, float scale, int PH, int PW,
+                                                           int sr, int aligned, float* __restrict__ out) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)R * PH * PW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t t = i / C4;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH);
+        const int r = (int)(t / PH);
+        const RoiGeom g = roi_geom(rois, r, scale, PH, PW, sr, aligned != 0);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (g.n >= 0 && g.n < N) {
+            const float* xb = x + (int64_t)g.n * H * W * C + c;
+            for (int iy = 0; iy < g.gh; ++iy) {
+                const float yy = g.y1 + ph * g.bh + (iy + 0.5f) * g.bh / g.gh;
+                for (int ix = 0; ix < g.gw; ++ix) {
+                    const float xx = g.x1 + pw * g.bw + (ix + 0.5f) * g.bw / g.gw;
+                    const Bilin b = bilin(yy, xx, H, W);
+                    if (!b.ok) continue;
+                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)b.y0 * W + b.x0) * C);
+                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)b.y0 * W + b.x1) * C);
+                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)b.y1 * W + b.x0) * C);
+                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)b.y1 * W + b.x1) * C);
+                    acc += v00 * b.w00 + v01 * b.w01 + v10 * b.w10 + v11 * b.w11;
+                }
+            }
+            acc = acc * (1.0f / (float)(g.gh * g.gw > 0 ? g.gh * g.gw : 1));
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+    }
+}
+
+// backward: scatter dout / count through the same bilinear weights (float atomics: the sum over overlapping
+// RoIs is order dependent in the last bits, like the published implementations)
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restrict__ dout, int N, int H, int W, int C,
+                                                           const float* __restrict__ rois, int R, float scale, int PH, int PW,
+                                                           int sr, int aligned, float* __restrict__ dx) {
+    const int64_t total = (int64_t)R * PH * PW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH);
+        const int r = (int)(t / PH);
+        const RoiGeom g = roi_geom(rois, r, scale, PH, PW, sr, aligned != 0);
+        if (g.n < 0 || g.n >= N) continue;
+        const float gv = dout[i] / (float)(g.gh * g.gw > 0 ? g.gh * g.gw : 1);
+        float* db = dx + (int64_t)g.n * H * W * C + c;
+        for (int iy = 0; iy < g.gh; ++iy) {
+            const float yy = g.y1 + ph * g.bh + (iy + 0.5f) * g.bh / g.gh;
+            for (int ix = 0; ix < g.gw; ++ix) {
+                const float xx = g.x1 + pw * g.bw + (ix + 0.5f) * g.bw / g.gw;
+                const Bilin b = bilin(yy, xx, H, W);
+                if (!b.ok) continue;
+                atomicAdd(db + ((int64_t)b.y0 * W + b.x0) * C, gv * b.w00);
+                atomicAdd(db + ((int64_t)b.y0 * W + b.x1) * C, gv * b.w01);
+                atomicAdd(db + ((int64_t)b.y1 * W + b.x0) * C, gv * b.w10);
+                atomicAdd(db + ((int64_t)b.y1 * W + b.x1) * C, gv * b.w11);
+            }
+        }
+    }
+}
+
+// FPN top-down pathway: out = lateral + nearest-neighbour 2x upsampling of the coarser level
+__global__ __launch_bounds__(256) void fpn_merge_fwd_kernel(const float* __restrict__ lateral, const float* __restrict__ top,
+                                                           int N, int H, int W, int C, float* __restrict__ out) {
+    const int C4 = C / 4, Ht = (H + 1) / 2, Wt = (W + 1) / 2;
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t t = i / C4;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lateral + i * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(top + (((int64_t)n * Ht + (y >> 1)) * Wt + (x >> 1)) * C + c);
+        *reinterpret_cast<f32x4*>(out + i * 4) = a + b;
+    }
+}
+// backward w.r.t. the coarser level: every coarse pixel gathers its (up to) 2x2 children in fixed order (no atomics);
+// the gradient w.r.t. the lateral input is dout itself
+__global__ __launch_bounds__(256) void fpn_merge_bwd_top_kernel(const float* __restrict__ dout, int N, int H, int W, int C,
+                                                               float* __restrict__ dtop) {
+    const int C4 = C / 4, Ht = (H + 1) / 2, Wt = (W + 1) / 2;
+    const int64_t total = (int64_t)N * Ht * Wt * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t t = i / C4;
+        const int xt = (int)(t % Wt); t /= Wt;
+        const int yt = (int)(t % Ht);
+        const int n = (int)(t / Ht);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = 2 * yt + (k >> 1), x = 2 * xt + (k & 1);
+            if (y < H && x < W) acc += *reinterpret_cast<const f32x4*>(dout + (((int64_t)n * H + y) * W + x) * C + c);
+        }
+        *reinterpret_cast<f32x4*>(dtop + i * 4) = acc;
+    }
+}
+
+int grid_of(int64_t total) {
+    int64_t b = cdiv(total, 256);
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+void launch_roi_align_fwd(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, const float* rois, int R, float scale,
+                          int PH, int PW, int sampling_ratio, bool aligned, float* out) {
+    RFI_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, "roi_align: C % 4 == 0 and positive sizes");
+    if (R == 0) return;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)R * PH * PW * C * 4 * 5);
+    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(grid_of((int64_t)R * PH * PW * C / 4)), dim3(256), 0, ctx->stream, x, N, H, W, C,
+                       rois, R, scale, PH, PW, sampling_ratio, aligned ? 1 : 0, out);
+    check_launch("roi_align_fwd");
+}
+void launch_roi_align_bwd(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, const float* rois, int R, float scale,
+                          int PH, int PW, int sampling_ratio, bool aligned, float* dx) {
+    RFI_REQUIRE(N > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, "roi_align: positive sizes");
+    RFI_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)N * H * W * C * sizeof(float), ctx->stream));
+    if (R == 0) return;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)R * PH * PW * C * 4 * 5);
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(grid_of((int64_t)R * PH * PW * C)), dim3(256), 0, ctx->stream, dout, N, H, W, C,
+                       rois, R, scale, PH, PW, sampling_ratio, aligned ? 1 : 0, dx);
+    check_launch("roi_align_bwd");
+}
+void launch_fpn_merge_fwd(rfi_ctx* ctx, const float* lateral, const float* top, int N, int H, int W, int C, float* out) {
+    RFI_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, "fpn_merge: C % 4 == 0 and positive sizes");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 9);
+    hipLaunchKernelGGL(fpn_merge_fwd_kernel, dim3(grid_of((int64_t)N * H * W * C / 4)), dim3(256), 0, ctx->stream, lateral, top, N,
+                       H, W, C, out);
+    check_launch("fpn_merge_fwd");
+}
+void launch_fpn_merge_bwd_top(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, float* dtop) {
+    RFI_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, "fpn_merge: C % 4 == 0 and positive sizes");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 5);
+    hipLaunchKernelGGL(fpn_merge_bwd_top_kernel, dim3(grid_of((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4)), dim3(256), 0,
+                       ctx->stream, dout, N, H, W, C, dtop);
+    check_launch("fpn_merge_bwd_top");
+}
+
+}  // namespace rfi

@@ -244,6 +244,16 @@ void launch_threshold(rfi_ctx* ctx, const float* logits, int64_t count, float th
 
 // x[i] *= f  (the emulated gradient exchange of the single-GPU tests, rfi_comm_emulate)
 void launch_scale_inplace(rfi_ctx* ctx, float* x, int64_t n, float f);
+// ---------------------------------------------------------------- detection building blocks (detect_kernels.hip)
+// RoIAlign over an NHWC feature map; rois = R x (batch index, x1, y1, x2, y2) float32 in image coordinates
+void launch_roi_align_fwd(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, const float* rois, int R, float scale,
+                          int PH, int PW, int sampling_ratio, bool aligned, float* out);      // out [R][PH][PW][C]
+void launch_roi_align_bwd(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, const float* rois, int R, float scale,
+                          int PH, int PW, int sampling_ratio, bool aligned, float* dx);       // dx [N][H][W][C], zeroed here
+// FPN top-down merge: out = lateral + nearest 2x upsampling of top ([N][ceil(H/2)][ceil(W/2)][C])
+void launch_fpn_merge_fwd(rfi_ctx* ctx, const float* lateral, const float* top, int N, int H, int W, int C, float* out);
+void launch_fpn_merge_bwd_top(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, float* dtop);
+
 // generic: out[i] = sum_s slabs[s*n + i]
 void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n, float* out);
 

@@ -1,0 +1,68 @@
+"""Building blocks of the Mask R-CNN path named by BASELINE.json configs[3]: RoIAlign and the FPN
+top-down merge as HIP kernels behind the C ABI (include/rfi_hip.h).  Not in the reference (it has no detector code):
+builder-defined from the published algorithms; NHWC float32 feature maps, device-resident (`DeviceArray`) or NumPy."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .._lib import check, lib
+from ..runtime import Context, DeviceArray
+
+
+def _dev(ctx, a):
+    return a if isinstance(a, DeviceArray) else ctx.to_device(np.ascontiguousarray(a, np.float32))
+
+
+def _p(d):
+    return C.c_void_p(d.ptr)
+
+
+def roi_align(x, rois, spatial_scale=1.0, output_size=(7, 7), sampling_ratio=2, aligned=False, device=None, to_host=True):
+    """x (N, H, W, C) float32, C % 4 == 0; rois (R, 5) = (batch index, x1, y1, x2, y2) -> (R, PH, PW, C)."""
+    ctx = Context.get(device)
+    dx, dr = _dev(ctx, x), _dev(ctx, np.asarray(rois, np.float32).reshape(-1, 5))
+    n, h, w, c = dx.shape
+    ph, pw = output_size
+    out = ctx.empty((dr.shape[0], ph, pw, c), np.float32)
+    check(lib.rfi_op_roi_align(ctx.handle, _p(dx), n, h, w, c, _p(dr), dr.shape[0], float(spatial_scale), ph, pw,
+                               int(sampling_ratio), 1 if aligned else 0, _p(out)))
+    ctx.synchronize()
+    return out.numpy() if to_host else out
+
+
+def roi_align_backward(dout, input_shape, rois, spatial_scale=1.0, sampling_ratio=2, aligned=False, device=None, to_host=True):
+    ctx = Context.get(device)
+    dd, dr = _dev(ctx, dout), _dev(ctx, np.asarray(rois, np.float32).reshape(-1, 5))
+    n, h, w, c = input_shape
+    r, ph, pw, _ = dd.shape
+    dx = ctx.empty((n, h, w, c), np.float32)
+    check(lib.rfi_op_roi_align_backward(ctx.handle, _p(dd), n, h, w, c, _p(dr), r, float(spatial_scale), ph, pw,
+                                        int(sampling_ratio), 1 if aligned else 0, _p(dx)))
+    ctx.synchronize()
+    return dx.numpy() if to_host else dx
+
+
+def fpn_merge(lateral, top, device=None, to_host=True):
+    """lateral (N, H, W, C) + nearest-neighbour 2x upsampling of top (N, ceil(H/2), ceil(W/2), C)."""
+    ctx = Context.get(device)
+    dl, dt = _dev(ctx, lateral), _dev(ctx, top)
+    n, h, w, c = dl.shape
+    if dt.shape != (n, (h + 1) // 2, (w + 1) // 2, c):
+        raise ValueError(f"top must be {(n, (h + 1) // 2, (w + 1) // 2, c)}, got {dt.shape}")
+    out = ctx.empty((n, h, w, c), np.float32)
+    check(lib.rfi_op_fpn_merge(ctx.handle, _p(dl), _p(dt), n, h, w, c, _p(out)))
+    ctx.synchronize()
+    return out.numpy() if to_host else out
+
+
+def fpn_merge_backward(dout, device=None, to_host=True):
+    """-> (d_lateral, d_top): d_lateral is dout itself, d_top sums each coarse pixel's 2x2 children."""
+    ctx = Context.get(device)
+    dd = _dev(ctx, dout)
+    n, h, w, c = dd.shape
+    dtop = ctx.empty((n, (h + 1) // 2, (w + 1) // 2, c), np.float32)
+    check(lib.rfi_op_fpn_merge_backward(ctx.handle, _p(dd), n, h, w, c, _p(dtop)))
+    ctx.synchronize()
+    return (dd.numpy(), dtop.numpy()) if to_host else (dd, dtop)
