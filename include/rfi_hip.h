@@ -81,6 +81,16 @@ int rfi_unet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_fe
  * Conv3x3(width->width,p1)+ReLU -> Conv1x1(width->out) logits.  Entries: encoder.0.weight/bias,
  * encoder.2.weight/bias, decoder.0.weight/bias.  Every rfi_model_* / rfi_train_* call below applies. */
 int rfi_cnn3_create(rfi_ctx* ctx, int in_channels, int out_channels, int width, rfi_model** out);
+/* "U-Net with a ResNet-18 encoder" of BASELINE.json configs[2] (not a reference class and
+ * no torchvision / segmentation_models_pytorch here: builder-defined, oracle/resnet_unet_ref.py).  stem Conv3x3(bias
+ * =False)+BN+ReLU at full resolution; layer1..4 of two BasicBlocks each (widths f, 2f, 4f, 8f; stride 2 + 1x1
+ * projection entering layers 2-4); then the reference's bottleneck / DecoderBlocks / final_conv (models/unet.py:30-77)
+ * with the four stage outputs as skips.  H and W must be multiples of 16; init_features a multiple of 4.
+ * Entries: stem.0.weight, stem.1.*, layer{l}.{b}.conv1.weight, .bn1.*, .conv2.weight, .bn2.*, .downsample.0.weight,
+ * .downsample.1.*, bottleneck.conv.*, decoder{l}.up.*, decoder{l}.conv.conv.*, final_conv.*.  Compute modes:
+ * 2 (float32 by 3 x bf16, default), 0 (native float32 MFMA), 4 (bf16 operands); 1 / 3 run as 4 / 2 (the plane
+ * data flow exists for the plain U-Net only). */
+int rfi_unet_resnet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_features, rfi_model** out);
 int rfi_model_destroy(rfi_model* m);
 /* variants of models/unet.py:120-268 on the same graph: UNetDifferentActivation's activation
  * (0 = ReLU, 0 < s < 1 = LeakyReLU(negative_slope=s), after every BatchNorm) and UNetOverfit's head
@@ -284,6 +294,15 @@ int rfi_op_conv3x3_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h, 
 int rfi_op_conv3x3_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy, int n, int h,
                          int w, int cin, int cout, const float* in_scale, const float* in_shift,
                          int in_relu, float* dw_oihw);
+/* stride-2 convolutions of the ResNet-style encoder (ksize 3: Conv2d(k3, s2, p1, bias=False) run as a 2x2 stride-1
+ * convolution on the space-to-depth input; ksize 1: Conv2d(k1, s2, bias=False), the projection shortcut).  h, w =
+ * INPUT size (even), cin % 4 == 0; y / dy are n x h/2 x w/2 x cout, dx is n x h x w x cin. */
+int rfi_op_conv_s2(rfi_ctx* ctx, int impl, int ksize, const float* x, int n, int h, int w, int cin,
+                   const float* w_oihw, int cout, float* y);
+int rfi_op_conv_s2_dgrad(rfi_ctx* ctx, int impl, int ksize, const float* dy, int n, int h, int w, int cout,
+                         const float* w_oihw, int cin, float* dx);
+int rfi_op_conv_s2_wgrad(rfi_ctx* ctx, int impl, int ksize, const float* x, const float* dy, int n, int h, int w,
+                         int cin, int cout, float* dw_oihw);
 int rfi_op_convt2x2(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
                     const float* w_iohw, const float* bias, int cout, float* y);
 int rfi_op_convt2x2_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h, int w, int cout,

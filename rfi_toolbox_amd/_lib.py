@@ -63,6 +63,7 @@ _PROTOS = {
     "rfi_profile_dump": (_i, [_vp, _cp]),
     "rfi_unet_create": (_i, [_vp, _i, _i, _i, _i, _pvp]),
     "rfi_cnn3_create": (_i, [_vp, _i, _i, _i, _pvp]),
+    "rfi_unet_resnet_create": (_i, [_vp, _i, _i, _i, _pvp]),
     "rfi_model_set_activation": (_i, [_vp, _f]),
     "rfi_model_set_compute_dtype": (_i, [_vp, _i]),
     "rfi_model_set_head_sigmoid": (_i, [_vp, _i]),
@@ -112,6 +113,9 @@ _PROTOS = {
     "rfi_confusion_counts": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i64, _pi64, _pi64, _pi64]),
     "rfi_threshold_logits": (_i, [_vp, _vp, _i64, _f, _vp]),
     "rfi_op_conv3x3": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "rfi_op_conv_s2": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "rfi_op_conv_s2_dgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "rfi_op_conv_s2_wgrad": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rfi_op_conv3x3_dgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "rfi_op_conv3x3_wgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "rfi_op_convt2x2": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),

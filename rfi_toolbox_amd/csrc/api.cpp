@@ -298,6 +298,26 @@ int rfi_cnn3_create(rfi_ctx* ctx, int in_channels, int out_channels, int width, 
         *out = m;
     });
 }
+int rfi_unet_resnet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_features, rfi_model** out) {
+    return guarded([&] {
+        RFI_REQUIRE(ctx && out, "rfi_unet_resnet_create: null argument");
+        auto* m = new rfi_model();
+        m->ctx = ctx;
+        m->arch = 2;
+        m->in_ch = in_channels;
+        m->out_ch = out_channels;
+        m->feat = init_features;
+        m->depth = 4;
+        try {
+            m->build();
+        } catch (...) {
+            m->ctx = nullptr;
+            delete m;
+            throw;
+        }
+        *out = m;
+    });
+}
 int rfi_model_destroy(rfi_model* m) {
     return guarded([&] {
         if (!m) return;
@@ -344,7 +364,7 @@ void from_lib_convt(const float* lib, int cin, int cout, float* iohw) {
 // where a float entry lives inside a flat buffer (params / grads / adam m / adam v)
 size_t flat_offset(const rfi_model* m, const Entry& e) {
     switch (e.kind) {
-        case 0: return m->convs[e.layer].w_off;
+        case 0: case 7: return m->convs[e.layer].w_off;
         case 1: return m->ups[e.layer].w_off;
         case 6: return m->head_w_off;
         case 2:
@@ -401,7 +421,7 @@ int rfi_model_init(rfi_model* m, uint64_t seed) {
         };
         float last_bound = 0;
         for (const Entry& e : m->entries) {
-            if (e.kind == 0 || e.kind == 1 || e.kind == 6) {
+            if (e.kind == 0 || e.kind == 1 || e.kind == 6 || e.kind == 7) {
                 // kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)), fan_in = dims[1]*kh*kw
                 const double fan_in = (double)e.dims[1] * e.dims[2] * e.dims[3];
                 last_bound = (float)(1.0 / std::sqrt(fan_in));
@@ -442,7 +462,7 @@ int rfi_model_entry_info(rfi_model* m, int index, const char** name, int* ndim, 
         if (dims)
             for (int i = 0; i < 4; ++i) dims[i] = i < e.ndim ? e.dims[i] : 1;
         if (is_int64) *is_int64 = e.kind == 5;
-        if (is_parameter) *is_parameter = (e.kind == 0 || e.kind == 1 || e.kind == 2 || e.kind == 6);
+        if (is_parameter) *is_parameter = (e.kind == 0 || e.kind == 1 || e.kind == 2 || e.kind == 6 || e.kind == 7);
     });
 }
 int rfi_model_param_count(rfi_model* m, int64_t* n) {
@@ -791,8 +811,9 @@ int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t h
         const float* src = nullptr;
         size_t n = 0;
         const int D = m->depth;
-        RFI_REQUIRE(m->arch == 0 || base == "logits" || base == "dlogits" || base == "chan",
-                    "debug_tensor: this model exposes only logits / dlogits / chan");
+        RFI_REQUIRE(m->arch == 0 || base == "logits" || base == "dlogits" || base == "chan" ||
+                        (m->arch == 2 && base != "encY1" && base != "encY2" && base != "pool" && base != "dpool"),
+                    "debug_tensor: this model exposes only logits / dlogits / chan (and the decoder tensors of the ResNet-encoder U-Net)");
         auto level = [&](const std::vector<int>& v, size_t chmul) {
             RFI_REQUIRE(idx >= 1 && idx <= D, "debug_tensor: level out of range");
             const size_t M = (size_t)m->pN * (m->pH >> (idx - 1)) * (m->pW >> (idx - 1));
@@ -846,12 +867,9 @@ int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, 
             return;
         }
         for (size_t ci = 0; ci < m->convs.size(); ++ci) {
-            int lvl;
-            if ((int)ci < 2 * D) lvl = (int)ci / 2 + 1;
-            else if ((int)ci < 2 * D + 2) lvl = D + 1;
-            else lvl = D - ((int)ci - (2 * D + 2)) / 2;
+            const int lvl = m->convs[ci].level, R = m->convs[ci].R;       // M = OUTPUT pixels (stride-2 convs included)
             const double M = (double)n * (h >> (lvl - 1)) * (w >> (lvl - 1));
-            const double fl = 2.0 * M * 9.0 * m->convs[ci].cin * m->convs[ci].cout;
+            const double fl = 2.0 * M * R * R * m->convs[ci].cin * m->convs[ci].cout;
             f += fl;
             if (ci == 0) stem = fl;
         }
@@ -1340,6 +1358,103 @@ int rfi_op_conv3x3_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         from_lib_conv(lib.data(), cout, cin, 3, ref.data());
         RFI_CHECK_HIP(hipMemcpyAsync(dw_oihw, ref.data(), numel * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+// ---- stride-2 convolutions of the ResNet-style encoder (model_resnet.cpp): 3x3 / pad 1 as a 2x2 convolution on the
+// space-to-depth input, 1x1 / pad 0 on a channel slice of it.  h, w: INPUT size (even); outputs are h/2 x w/2.
+int rfi_op_conv_s2(rfi_ctx* ctx, int impl, int ksize, const float* x, int n, int h, int w, int cin, const float* w_oihw,
+                   int cout, float* y) {
+    return guarded([&] {
+        RFI_REQUIRE(ksize == 3 || ksize == 1, "conv_s2: kernel size 3 or 1");
+        ctx->activate();
+        Scratch s(ctx);
+        float* xs = s.get((size_t)n * h * w * cin);
+        launch_s2d(ctx, x, n, h, w, cin, xs);
+        ConvArgs a;
+        a.N = n; a.H = h / 2; a.W = w / 2; a.Hin = h / 2; a.Win = w / 2; a.Cout = cout;
+        a.x = View{xs, 4 * cin};
+        a.y = MutView{y, cout};
+        a.Hout = h / 2; a.Wout = w / 2;
+        a.S = 1;
+        if (ksize == 3) {
+            float* w3 = upload_lib_weight(ctx, s, w_oihw, (size_t)9 * cin * cout, false, cout, cin, 3);
+            float* w2 = s.get((size_t)16 * cin * cout);
+            launch_w_s2d(ctx, w3, cout, cin, w2, true);
+            a.w = w2; a.Cin = 4 * cin; a.R = 2; a.pad = 1;
+        } else {
+            a.w = w_oihw; a.Cin = cin; a.R = 1; a.pad = 0;          // [cout][cin][1][1] == [1 tap][cout][cin]
+        }
+        launch_conv(ctx, a, impl);
+    });
+}
+int rfi_op_conv_s2_dgrad(rfi_ctx* ctx, int impl, int ksize, const float* dy, int n, int h, int w, int cout,
+                         const float* w_oihw, int cin, float* dx) {
+    return guarded([&] {
+        RFI_REQUIRE(ksize == 3 || ksize == 1, "conv_s2_dgrad: kernel size 3 or 1");
+        ctx->activate();
+        Scratch s(ctx);
+        ConvArgs a;
+        a.N = n; a.H = h / 2; a.W = w / 2; a.Hin = h / 2; a.Win = w / 2; a.Cin = cout;
+        a.x = View{dy, cout};
+        a.Hout = h / 2; a.Wout = w / 2;
+        a.S = 1;
+        float* dxp = s.get((size_t)n * h * w * cin);
+        float* ds = nullptr;
+        if (ksize == 3) {
+            float* w3 = upload_lib_weight(ctx, s, w_oihw, (size_t)9 * cin * cout, false, cout, cin, 3);
+            float* w2 = s.get((size_t)16 * cin * cout);
+            float* wd = s.get((size_t)16 * cin * cout);
+            launch_w_s2d(ctx, w3, cout, cin, w2, true);
+            launch_weight_to_dgrad(ctx, w2, 4, cout, 4 * cin, 1, wd);
+            a.w = wd; a.Cout = 4 * cin; a.R = 2; a.pad = 0;
+            a.y = MutView{dxp, 4 * cin};
+        } else {
+            float* wd = s.get((size_t)cin * cout);
+            launch_weight_to_dgrad(ctx, w_oihw, 1, cout, cin, 0, wd);
+            RFI_CHECK_HIP(hipMemsetAsync(dxp, 0, (size_t)n * h * w * cin * sizeof(float), ctx->stream));
+            ds = s.get((size_t)n * (h / 2) * (w / 2) * cin);
+            a.w = wd; a.Cout = cin; a.R = 1; a.pad = 0;
+            a.y = MutView{ds, cin};
+        }
+        launch_conv(ctx, a, impl);
+        launch_d2s_add(ctx, dxp, ds, View{}, n, h, w, cin, dx);
+    });
+}
+int rfi_op_conv_s2_wgrad(rfi_ctx* ctx, int impl, int ksize, const float* x, const float* dy, int n, int h, int w, int cin,
+                         int cout, float* dw_oihw) {
+    return guarded([&] {
+        RFI_REQUIRE(ksize == 3 || ksize == 1, "conv_s2_wgrad: kernel size 3 or 1");
+        ctx->activate();
+        Scratch s(ctx);
+        float* xs = s.get((size_t)n * h * w * cin);
+        launch_s2d(ctx, x, n, h, w, cin, xs);
+        WgradArgs a;
+        a.xop = View{xs, 4 * cin};
+        a.yop = View{dy, cout};
+        a.N = n; a.H = h / 2; a.W = w / 2; a.Hx = h / 2; a.Wx = w / 2; a.Cy = cout;
+        a.S = 1; a.sx = 1;
+        if (ksize == 3) { a.Cx = 4 * cin; a.R = 2; a.pad = 1; }
+        else { a.Cx = cin; a.R = 1; a.pad = 0; }
+        a.tap_stride = (int64_t)a.Cx * cout;
+        a.sy = a.Cx;
+        const size_t numel = (size_t)a.R * a.R * a.Cx * cout;
+        a.dw = s.get(numel);
+        a.slab_floats = wgrad_slab_floats(a, impl);
+        a.slab = s.get(a.slab_floats);
+        launch_wgrad(ctx, a, impl);
+        if (ksize == 1) {
+            RFI_CHECK_HIP(hipMemcpyAsync(dw_oihw, a.dw, numel * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            return;
+        }
+        const size_t n3 = (size_t)9 * cin * cout;
+        float* w3 = s.get(n3);
+        launch_w_s2d(ctx, w3, cout, cin, a.dw, false);
+        std::vector<float> lib(n3), ref(n3);
+        RFI_CHECK_HIP(hipMemcpyAsync(lib.data(), w3, n3 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        from_lib_conv(lib.data(), cout, cin, 3, ref.data());
+        RFI_CHECK_HIP(hipMemcpyAsync(dw_oihw, ref.data(), n3 * 4, hipMemcpyHostToDevice, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     });
 }

@@ -712,8 +712,10 @@ bool conv_mfma_eligible(const ConvArgs& a) {
     if (a.xf.scale && ((reinterpret_cast<uintptr_t>(a.xf.scale) & 15) ||
                        (reinterpret_cast<uintptr_t>(a.xf.shift) & 15)))
         return false;
+    // R = 2, S = 1: the 2x2 form of a 3x3 / stride-2 conv on its space-to-depth input (pad 1: forward, top/left
+    // padding only; pad 0: its input gradient, which reads rows y, y + 1) -- resnet_kernels.hip
     const bool known = (a.R == 3 && a.S == 1 && a.pad == 1) || (a.R == 1 && a.S == 1 && a.pad == 0) ||
-                       (a.R == 2 && a.S == 2 && a.pad == 0);
+                       (a.R == 2 && a.S == 2 && a.pad == 0) || (a.R == 2 && a.S == 1 && (a.pad == 1 || a.pad == 0));
     return known;
 }
 
@@ -778,6 +780,7 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0, label);
     if (a.R == 3) dispatch_tiles<3, 1>(ctx, a);
     else if (a.R == 1) dispatch_tiles<1, 1>(ctx, a);
+    else if (a.S == 1) dispatch_tiles<2, 1>(ctx, a);
     else dispatch_tiles<2, 2>(ctx, a);
 }
 

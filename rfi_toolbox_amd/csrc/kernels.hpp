@@ -254,6 +254,16 @@ void launch_roi_align_bwd(rfi_ctx* ctx, const float* dout, int N, int H, int W, 
 void launch_fpn_merge_fwd(rfi_ctx* ctx, const float* lateral, const float* top, int N, int H, int W, int C, float* out);
 void launch_fpn_merge_bwd_top(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, float* dtop);
 
+// ---------------------------------------------------------------- ResNet-style encoder pieces (resnet_kernels.hip)
+void launch_s2d(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, float* out);          // [N,H,W,C] -> [N,H/2,W/2,4C]
+void launch_d2s_add(rfi_ctx* ctx, const float* dxp, const float* ds, View extra, int N, int H, int W, int C, float* out);
+void launch_bn_add_relu(rfi_ctx* ctx, const float* y, const float* scale, const float* shift, const float* s,
+                        const float* s_scale, const float* s_shift, int64_t M, int C, MutView out, MutView out2);
+void launch_relu_mask(rfi_ctx* ctx, View da, View da2, View a, View base, int64_t M, int C, float* dz);   // (da + da2) * (a > 0) + base
+void launch_add_inplace(rfi_ctx* ctx, float* x, const float* y, int64_t n);
+// 3x3 stride-2 filters [9][Cout][Cin] <-> their 2x2 form on the space-to-depth input [4][Cout][4 Cin]
+void launch_w_s2d(rfi_ctx* ctx, float* w3, int Cout, int Cin, float* w2, bool to_s2d);
+
 // generic: out[i] = sum_s slabs[s*n + i]
 void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n, float* out);
 

@@ -48,7 +48,7 @@ rfi_model::~rfi_model() {
     for (auto& b : pl) b.free();
     if (wb_pool) ctx->release(wb_pool);
     if (wb_descs) ctx->release(wb_descs);
-    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool})
+    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool})
         if (p) ctx->release(p);
     if (relayout_descs) ctx->release(relayout_descs);
     if (x3_descs) ctx->release(x3_descs);
@@ -64,14 +64,17 @@ void rfi_model::build() {
         planesP = std::string(e) == "bf16" ? 1 : (std::string(e) == "f32planes" ? 3 : 0);
     }
     if (const char* e = getenv("RFI_BN_FUSE")) fuse_bn_bwd = e[0] == '1';
+    if (arch != 0) planesP = 0;                       // the plane data flow exists for the plain U-Net only
     if (arch == 1) return build_cnn3();
+    if (arch == 2) return build_resnet();
     RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
     RFI_REQUIRE(depth >= 1 && depth <= 6, "UNet: depth must be in [1,6]");
     const int D = depth;
     convs.clear();
     ups.clear();
     size_t off = 0, chan_floats = 0, wd_floats = 0;
-    auto add_conv = [&](const std::string& prefix, int conv_idx, int bn_idx, int cin, int cout, int ema) {
+    i_bott = 2 * D;
+    auto add_conv = [&](const std::string& prefix, int conv_idx, int bn_idx, int cin, int cout, int ema, int lvl) {
         ConvBN c;
         c.conv_name = prefix + "." + std::to_string(conv_idx);
         c.bn_name = prefix + "." + std::to_string(bn_idx);
@@ -81,6 +84,7 @@ void rfi_model::build() {
         c.cin_p = convs.empty() ? (int)align4((size_t)cin) : cin;
         c.cout = cout;
         c.ema_repeats = ema;
+        c.level = lvl;
         c.w_off = off; off = align4(off + (size_t)9 * c.cin_p * cout);
         c.b_off = off; off = align4(off + cout);
         c.g_off = off; off = align4(off + cout);
@@ -93,12 +97,12 @@ void rfi_model::build() {
     for (int l = 1; l <= D; ++l) {
         const int cout = feat << (l - 1);
         const std::string p = "encoder" + std::to_string(l) + ".conv.conv";
-        add_conv(p, 0, 1, cin, cout, 2);
-        add_conv(p, 3, 4, cout, cout, 2);
+        add_conv(p, 0, 1, cin, cout, 2, l);
+        add_conv(p, 3, 4, cout, cout, 2, l);
         cin = cout;
     }
-    add_conv("bottleneck.conv", 0, 1, cin, cin * 2, 1);
-    add_conv("bottleneck.conv", 3, 4, cin * 2, cin * 2, 1);
+    add_conv("bottleneck.conv", 0, 1, cin, cin * 2, 1, D + 1);
+    add_conv("bottleneck.conv", 3, 4, cin * 2, cin * 2, 1, D + 1);
     cin *= 2;
     // decoder parameters come in forward order: up, conv1, conv2 per level; to keep `convs`
     // contiguous the up-convs get their offsets here and the convs right after
@@ -113,8 +117,8 @@ void rfi_model::build() {
         wd_floats += align4((size_t)4 * cin * cout);
         ups.push_back(u);
         const std::string p = "decoder" + std::to_string(l) + ".conv.conv";
-        add_conv(p, 0, 1, cin, cout, 1);
-        add_conv(p, 3, 4, cout, cout, 1);
+        add_conv(p, 0, 1, cin, cout, 1, l);
+        add_conv(p, 3, 4, cout, cout, 1, l);
         cin = cout;
     }
     head_w_off = off; off = align4(off + (size_t)out_ch * feat);
@@ -260,11 +264,14 @@ void rfi_model::prepare(int n, int h, int w) {
     for (int l = 1; l <= D; ++l) {
         const size_t M = (size_t)n * (h >> (l - 1)) * (w >> (l - 1));
         const size_t C = (size_t)feat << (l - 1);
-        for (int i : {encY1[l], encY2[l], decY1[l], decY2[l], gA[l], gB[l]}) bufs[i].ensure(ctx, M * C);
+        for (int i : {decY1[l], decY2[l], gA[l], gB[l]}) bufs[i].ensure(ctx, M * C);
+        if (arch != 2) for (int i : {encY1[l], encY2[l]}) bufs[i].ensure(ctx, M * C);     // (arch 2: its own tensors, prepare_resnet)
         bufs[concat[l]].ensure(ctx, M * 2 * C);
         bufs[dconcat[l]].ensure(ctx, M * 2 * C);
-        bufs[pool[l]].ensure(ctx, M / 4 * C);
-        bufs[dpool[l]].ensure(ctx, M / 4 * C);
+        if (arch != 2 || l == D) {
+            bufs[pool[l]].ensure(ctx, M / 4 * C);
+            bufs[dpool[l]].ensure(ctx, M / 4 * C);
+        }
     }
     {
         const size_t M = (size_t)n * (h >> D) * (w >> D);
@@ -290,14 +297,9 @@ void rfi_model::prepare(int n, int h, int w) {
     upd_red(sumsq_ws_doubles(n_flat) * 2);
     bufs[ws_red].ensure(ctx, red_need + 16);
     // wgrad slabs: the largest need over all layers
-    auto conv_geom = [&](int ci, int& H, int& W) {
-        // spatial size of conv ci's output
-        int lvl;
-        if (ci < 2 * D) lvl = ci / 2 + 1;
-        else if (ci < 2 * D + 2) lvl = D + 1;
-        else lvl = D - (ci - (2 * D + 2)) / 2;
-        H = h >> (lvl - 1);
-        W = w >> (lvl - 1);
+    auto conv_geom = [&](int ci, int& H, int& W) {         // spatial size of conv ci's output
+        H = h >> (convs[ci].level - 1);
+        W = w >> (convs[ci].level - 1);
     };
     for (size_t ci = 0; ci < convs.size(); ++ci) {
         int H, W;
@@ -305,9 +307,12 @@ void rfi_model::prepare(int n, int h, int w) {
         WgradArgs a;
         a.N = n; a.H = H; a.W = W; a.Hx = H; a.Wx = W;
         a.Cx = convs[ci].cin_p; a.Cy = convs[ci].cout;
-        a.xop.pstride = a.Cx; a.yop.pstride = a.Cy;
         a.R = 3; a.S = 1; a.pad = 1;
+        if (convs[ci].stride == 2) { a.Cx *= 4; a.R = 2; }            // its 2x2 form on the space-to-depth input
+        if (convs[ci].R == 1) { a.R = 1; a.pad = 0; }
+        a.xop.pstride = a.Cx; a.yop.pstride = a.Cy;
         a.tap_stride = (int64_t)a.Cx * a.Cy;
+        a.bf16x3 = true;              // (the split-at-staging plan is the largest)
         slab_need = std::max(slab_need, wgrad_slab_floats(a, IMPL_AUTO));
     }
     for (int k = 0; k < D; ++k) {
@@ -321,6 +326,7 @@ void rfi_model::prepare(int n, int h, int w) {
         slab_need = std::max(slab_need, wgrad_slab_floats(a, IMPL_AUTO));
     }
     bufs[ws_slab].ensure(ctx, slab_need + 16);
+    if (arch == 2) prepare_resnet(n, h, w);
     pN = n; pH = h; pW = w;
 }
 
@@ -330,8 +336,8 @@ void rfi_model::refresh_dgrad_weights() {
         std::vector<RelayoutDesc> h;
         relayout_bytes = 0;
         for (auto& c : convs) {
-            h.push_back({(int64_t)c.w_off, (int64_t)(c.wd - wd_pool), 9, c.cout, c.cin_p, 1});
-            relayout_bytes += 8.0 * 9 * c.cout * c.cin_p;
+            h.push_back({(int64_t)c.w_off, (int64_t)(c.wd - wd_pool), c.R * c.R, c.cout, c.cin_p, 1});
+            relayout_bytes += 8.0 * c.R * c.R * c.cout * c.cin_p;
         }
         for (auto& u : ups) {
             h.push_back({(int64_t)u.w_off, (int64_t)(u.wd - wd_pool), 4, u.cout, u.cin, 0});
@@ -348,13 +354,13 @@ void rfi_model::refresh_dgrad_weights() {
     if (compute_x3) {     // pre-split records of both layouts of every conv-like layer (the kernels read them as is)
         if (!w3_pool) {
             size_t need = 0;
-            for (auto& c : convs) need += weights_x3_floats(9, c.cout, c.cin_p) + weights_x3_floats(9, c.cin_p, c.cout);
+            for (auto& c : convs) need += weights_x3_floats(c.R * c.R, c.cout, c.cin_p) + weights_x3_floats(c.R * c.R, c.cin_p, c.cout);
             for (auto& u : ups) need += 2 * weights_x3_floats(4, u.cout, u.cin) + weights_x3_floats(4, u.cin, u.cout);
             w3_pool = static_cast<float*>(ctx->alloc((need + 64) * sizeof(float)));
             size_t o = 0;
             for (auto& c : convs) {
-                c.w3 = w3_pool + o; o += weights_x3_floats(9, c.cout, c.cin_p);
-                c.wd3 = w3_pool + o; o += weights_x3_floats(9, c.cin_p, c.cout);
+                c.w3 = w3_pool + o; o += weights_x3_floats(c.R * c.R, c.cout, c.cin_p);
+                c.wd3 = w3_pool + o; o += weights_x3_floats(c.R * c.R, c.cin_p, c.cout);
             }
             for (auto& u : ups) {
                 u.w3 = w3_pool + o; o += weights_x3_floats(4, u.cout, u.cin);
@@ -368,8 +374,8 @@ void rfi_model::refresh_dgrad_weights() {
                 x3_bytes += (double)taps * cout * cin * 4 + (double)weights_x3_floats(taps, cout, cin) * 4;
             };
             for (auto& c : convs) {
-                add(params + c.w_off, c.w3, 9, c.cout, c.cin_p);
-                add(c.wd, c.wd3, 9, c.cin_p, c.cout);
+                add(params + c.w_off, c.w3, c.R * c.R, c.cout, c.cin_p);
+                add(c.wd, c.wd3, c.R * c.R, c.cin_p, c.cout);
             }
             for (auto& u : ups) {
                 add(params + u.w_off, u.w3, 4, u.cout, u.cin);
@@ -383,6 +389,7 @@ void rfi_model::refresh_dgrad_weights() {
         launch_weights_to_x3_batched(ctx, static_cast<const X3Desc*>(x3_descs), x3_n, x3_bytes);
         x3_fresh = true;
     }
+    if (arch == 2) refresh_resnet_weights();               // 2x2 forms of the stride-2 filters
     if (planesP && arch == 0) refresh_plane_weights();     // B-operand-order filters of the plane kernels
     wd_dirty = false;
 }
@@ -444,9 +451,10 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
     refresh_dgrad_weights();          // derived filter copies (dgrad layout, 3 x bf16 records) follow the parameters
     if (arch == 1) return forward_cnn3(x_dev, n, h, w);
     if (planesP) return forward_planes(x_dev, n, h, w, train_mode);
-    const int D = depth;
+    const int D = depth, IB = i_bott;
     View cur = network_input(x_dev, n, h, w);
-    for (int l = 1; l <= D; ++l) {
+    if (arch == 2) cur = forward_resnet_encoder(cur, n, h, w, train_mode);
+    else for (int l = 1; l <= D; ++l) {
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
@@ -458,13 +466,13 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
     }
     {
         Shape s{n, h >> D, w >> D};
-        ConvBN& c1 = convs[2 * D];
-        ConvBN& c2 = convs[2 * D + 1];
+        ConvBN& c1 = convs[IB];
+        ConvBN& c2 = convs[IB + 1];
         run_conv_bn(this, c1, cur, InXform{}, s, buf(bottY1), train_mode);
         run_conv_bn(this, c2, View{buf(bottY1), c1.cout}, bn_xf(c1), s, buf(bottY2), train_mode);
     }
     const float* prevY = buf(bottY2);
-    ConvBN* prevBN = &convs[2 * D + 1];
+    ConvBN* prevBN = &convs[IB + 1];
     for (int l = D; l >= 1; --l) {
         const int k = D - l;
         UpConv& u = ups[k];
@@ -486,8 +494,8 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         a.bf16 = compute_bf16;
         a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
-        ConvBN& c1 = convs[2 * D + 2 + 2 * k];
-        ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
+        ConvBN& c1 = convs[IB + 2 + 2 * k];
+        ConvBN& c2 = convs[IB + 2 + 2 * k + 1];
         run_conv_bn(this, c1, View{buf(concat[l]), 2 * u.cout}, InXform{}, s, buf(decY1[l]), train_mode);
         run_conv_bn(this, c2, View{buf(decY1[l]), c1.cout}, bn_xf(c1), s, buf(decY2[l]), train_mode);
         prevY = buf(decY2[l]);
@@ -656,7 +664,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         bucket_ready(0, n_flat);                  // three layers: one bucket
         return;
     }
-    const int D = depth;
+    const int D = depth, IB = i_bott;
     const int64_t M1 = (int64_t)n * h * w;
     refresh_dgrad_weights();
     if (planesP) return backward_planes(x_dev, labels_dev, n, h, w);
@@ -667,7 +675,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         launch_loss_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, d_sums, buf(dlogits));
     if (head_sigmoid) launch_sigmoid_bwd(ctx, buf(probs), M1 * out_ch, buf(dlogits));
     {
-        ConvBN& last = convs[2 * D + 2 + 2 * (D - 1) + 1];
+        ConvBN& last = convs[IB + 2 + 2 * (D - 1) + 1];
         launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off,
                         out_ch, buf(dlogits), buf(gA[1]), buf(ws_red), grads + head_w_off,
                         grads + head_b_off, act_slope);
@@ -678,8 +686,8 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         const int k = D - l;
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         Shape sin{n, h >> l, w >> l};
-        ConvBN& c1 = convs[2 * D + 2 + 2 * k];
-        ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
+        ConvBN& c1 = convs[IB + 2 + 2 * k];
+        ConvBN& c2 = convs[IB + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         // conv2: input = act(decY1) ; conv1: input = concat (materialised)
         int rec = backward_conv_bn(this, c2, buf(gA[l]), buf(decY2[l]), View{buf(decY1[l]), c1.cout}, bn_xf(c1), s,
@@ -689,7 +697,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         pending_records = 0;
         // up-conv: dUp = dconcat[..., 0:C]
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
-        ConvBN& prevBN = (l == D) ? convs[2 * D + 1] : convs[2 * D + 2 + 2 * (k - 1) + 1];
+        ConvBN& prevBN = (l == D) ? convs[IB + 1] : convs[IB + 2 + 2 * (k - 1) + 1];
         View dUp{buf(dconcat[l]), 2 * u.cout};
         launch_channel_sum(ctx, dUp, (int64_t)s.N * s.H * s.W, u.cout, buf(ws_red), grads + u.b_off);
         WgradArgs wa;
@@ -740,13 +748,18 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     // bottleneck
     {
         Shape s{n, h >> D, w >> D};
-        ConvBN& c1 = convs[2 * D];
-        ConvBN& c2 = convs[2 * D + 1];
+        ConvBN& c1 = convs[IB];
+        ConvBN& c2 = convs[IB + 1];
         int rec = backward_conv_bn(this, c2, buf(gBottA), buf(bottY2), View{buf(bottY1), c1.cout}, bn_xf(c1), s,
                                    buf(gBottB), pending_records, &c1, buf(bottY1));
         backward_conv_bn(this, c1, buf(gBottB), buf(bottY1), View{buf(pool[D]), c1.cin}, InXform{}, s,
                          buf(dpool[D]), rec, nullptr, nullptr);
         bucket_ready(c1.w_off, ups[0].w_off);
+    }
+    if (arch == 2) {                  // ResNet-style encoder (model_resnet.cpp)
+        backward_resnet_encoder(x_dev, n, h, w);
+        side_join();
+        return;
     }
     // encoders, deep to shallow
     for (int l = D; l >= 1; --l) {
@@ -761,7 +774,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
                            : View{buf(pool[l - 1]), c1.cin};
         backward_conv_bn(this, c1, buf(gB[l]), buf(encY1[l]), in, InXform{}, s,
                          (l == 1) ? nullptr : buf(dpool[l - 1]), rec, nullptr, nullptr);
-        bucket_ready(c1.w_off, convs[2 * l].w_off);       // convs[2 l] = first conv of the next level / the bottleneck
+        bucket_ready(c1.w_off, convs[l == D ? IB : 2 * l].w_off);       // convs[2 l] = first conv of the next level / the bottleneck
     }
     side_join();
 }

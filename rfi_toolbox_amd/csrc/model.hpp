@@ -30,6 +30,11 @@ struct ConvBN {
     int cin_p = 0;                      // cin rounded up to a multiple of 4 (library layout; zero padded)
     size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;   // offsets into the flat param/grad buffers
     int ema_repeats = 1;
+    int level = 1;                      // resolution level of the OUTPUT: H >> (level - 1)
+    int R = 3, stride = 1;              // ResNet-style encoder: 3x3 stride 1 / 2, or the 1x1 stride-2 projection (R = 1)
+    bool has_bias = true;               // false: Conv2d(bias=False) in front of a BatchNorm (the bias slot stays 0, no state_dict entry)
+    float* ws2d = nullptr;              // stride 2: filters of the 2x2 form on the space-to-depth input [4][cout][4 cin]
+    float* wds2d = nullptr;             // ... and their dgrad layout [4'][4 cin][cout]
     bool has_bn = true;                 // false: Conv+bias -> ReLU (SimpleCNN); scale=1, shift=0 stay fixed
     int64_t nbt = 0;                    // num_batches_tracked (host side)
     // device per-channel state: [running_mean | running_var | mean | invstd | scale | shift | c1 | c2]
@@ -64,7 +69,8 @@ struct Entry {
     int ndim = 0;
     int64_t dims[4] = {0, 0, 0, 0};
     int kind = 0;        // 0 conv weight (OIHW), 1 convT weight (IOHW), 2 vector param, 3 running_mean,
-                         // 4 running_var, 5 num_batches_tracked, 6 final weight
+                         // 4 running_var, 5 num_batches_tracked, 6 final weight, 7 1x1 conv weight of convs[layer]
+                         // ([cout][cin][1][1] is the library's [1 tap][cout][cin] as is)
     int layer = -1;      // index into convs / ups; -1 for the head
     int which = 0;       // vector param: 0 conv bias, 1 bn gamma, 2 bn beta, 3 up bias, 4 head bias
     int64_t numel() const {
@@ -79,7 +85,9 @@ struct Entry {
 struct rfi_model {
     rfi_ctx* ctx = nullptr;
     int in_ch = 0, out_ch = 0, feat = 0, depth = 0;
-    int arch = 0;                     // 0: U-Net (models/unet.py), 1: 3-layer CNN (depth == 0)
+    int arch = 0;                     // 0: U-Net (models/unet.py), 1: 3-layer CNN (depth == 0),
+                                      // 2: U-Net with a ResNet-18-style encoder (model_resnet.cpp)
+    int i_bott = 0;                   // index of the bottleneck's first conv in `convs` (decoder convs follow it)
     bool training = true;
     float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
     bool compute_bf16 = false;        // conv / wgrad MFMAs on bf16-rounded operands (fp32 storage + accumulate)
@@ -135,6 +143,24 @@ struct rfi_model {
     void reset_channel_state();       // running stats 0/1, BN-less layers: scale 1, shift 0
     float* buf(int i) { return bufs[i].p; }
     int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
+
+    // ---- ResNet-18-style encoder (model_resnet.cpp): stem + 4 stages of 2 BasicBlocks
+    struct ResBlock {
+        int c1 = -1, c2 = -1, cd = -1;            // convs indices: conv1, conv2, projection (-1: identity shortcut)
+        int stride = 1, cin = 0, cout = 0, level = 1;
+        int Y1 = -1, Y2 = -1, Yd = -1, xs = -1, A = -1;      // bufs indices: raw conv outputs, space-to-depth input, block output
+    };
+    std::vector<ResBlock> blocks;
+    int rs_stemY = -1, rs_a0 = -1, rs_g0 = -1, rs_g1 = -1, rs_dX = -1, rs_dS = -1, rs_dW = -1, rs_dzd = -1;
+    int rs_dz[2] = {-1, -1}, rs_dA1[2] = {-1, -1};    // by block parity: the side stream's weight gradients still read the last block's
+    float* rs_ones = nullptr;         // [max C] ones / zeros: identity scale / shift for the pooling kernels
+    float* rs_zeros = nullptr;
+    float* rs_wpool = nullptr;        // derived filters of the stride-2 and 1x1 convs
+    void build_resnet();
+    void prepare_resnet(int n, int h, int w);
+    void refresh_resnet_weights();
+    rfi::View forward_resnet_encoder(rfi::View x, int n, int h, int w, bool train_mode);
+    void backward_resnet_encoder(const float* x_dev, int n, int h, int w);
 
     // ---- plane data flow (model_planes.cpp): planesP = 0 off (round-1 kernels on float32 tensors), 1 bf16
     // activations (the bfloat16 compute mode), 3 float32 as three bf16 pieces

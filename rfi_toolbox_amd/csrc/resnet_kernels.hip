@@ -1,0 +1,175 @@
+// Elementwise pieces of the ResNet-style encoder (model_resnet.cpp; SURVEY 8a row A10 -- not in the reference,
+// builder-defined, oracle/resnet_unet_ref.py).  All HBM-bound, NHWC float32, 16-byte accesses.
+//
+// Stride-2 3x3 convolutions run on the stride-1 kernels through space-to-depth: with
+//   X'[n, y, x, (a, b, c)] = X[n, 2y + a, 2x + b, c]          (a, b in {0, 1}; 4C channels, half the resolution)
+// a 3x3 / stride 2 / pad 1 conv of X is a 2x2 / stride 1 conv of X' with taps (dy, dx) in {-1, 0} (top/left pad 1):
+// input row 2y + r - 1 is (dy, a) = (-1, 1), (0, 0), (0, 1) for r = 0, 1, 2, so 9 of the 16 (tap, a, b) filter
+// blocks are the original taps and 7 are zero.  The 1x1 / stride 2 projection is a 1x1 conv on the (a, b) = (0, 0)
+// channel slice of X' (a view, no copy).
+#include "kernels.hpp"
+
+namespace rfi {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int grid_of(int64_t total) {
+    int64_t b = cdiv(total, 256);
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+// X [N][H][W][C] -> X' [N][H/2][W/2][4C]   (one float4 of channels per thread)
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, int N, int H, int W, int C, float* __restrict__ out) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t t = i / C4;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const int64_t o = ((((int64_t)n * (H / 2) + (yy >> 1)) * (W / 2) + (xx >> 1)) * 4 + ((yy & 1) * 2 + (xx & 1))) * C + c;
+        *reinterpret_cast<f32x4*>(out + o) = v;
+    }
+}
+// inverse, with the shortcut gradient added on the (0, 0) slice:  dX[n, 2y+a, 2x+b, c] = dX'[n,y,x,(a,b,c)] (+ dS[n,y,x,c])
+// and an optional full-resolution addend (the skip-connection gradient)
+__global__ __launch_bounds__(256) void d2s_add_kernel(const float* __restrict__ dxp, const float* __restrict__ ds,
+                                                     const float* __restrict__ extra, int extra_ps, int N, int H, int W, int C,
+                                                     float* __restrict__ out) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t t = i / C4;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        const int64_t pix = ((int64_t)n * (H / 2) + (yy >> 1)) * (W / 2) + (xx >> 1);
+        f32x4 v = *reinterpret_cast<const f32x4*>(dxp + (pix * 4 + ((yy & 1) * 2 + (xx & 1))) * C + c);
+        if (ds && !(yy & 1) && !(xx & 1)) v += *reinterpret_cast<const f32x4*>(ds + pix * C + c);
+        if (extra) v += *reinterpret_cast<const f32x4*>(extra + (((int64_t)n * H + yy) * W + xx) * extra_ps + c);
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
+// BasicBlock tail:  a = relu(Y * scale + shift + shortcut),  shortcut = S (identity) or S * s_scale + s_shift
+// (projection: the raw 1x1 conv output with its own BatchNorm).  out may be a channel slice of a wider buffer.
+__global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ s,
+                                                         const float* __restrict__ s_scale, const float* __restrict__ s_shift,
+                                                         int64_t M, int C, float* __restrict__ out, int out_ps,
+                                                         float* __restrict__ out2, int out2_ps) {
+    const int C4 = C / 4;
+    const int64_t total = M * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const int64_t m = i / C4;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 sv = {0.0f, 0.0f, 0.0f, 0.0f};                     // s == null: plain BatchNorm + ReLU (the stem)
+        if (s) sv = *reinterpret_cast<const f32x4*>(s + i * 4);
+        if (s_scale) sv = sv * *reinterpret_cast<const f32x4*>(s_scale + c) + *reinterpret_cast<const f32x4*>(s_shift + c);
+        f32x4 a = (yv * sc + sh) + sv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.0f ? a[e] : 0.0f;
+        *reinterpret_cast<f32x4*>(out + m * out_ps + c) = a;
+        if (out2) *reinterpret_cast<f32x4*>(out2 + m * out2_ps + c) = a;
+    }
+}
+// dz = (dA (+ dA2)) * (a > 0) (+ base): the gradient entering the block tail (both BatchNorm branches see dz as is);
+// with `base` = the main branch's input gradient this is the whole input gradient of an identity-shortcut block
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ da, int da_ps, const float* __restrict__ da2,
+                                                       int da2_ps, const float* __restrict__ a, int a_ps,
+                                                       const float* __restrict__ base, int base_ps, int64_t M, int C,
+                                                       float* __restrict__ dz) {
+    const int C4 = C / 4;
+    const int64_t total = M * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const int64_t m = i / C4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(da + m * da_ps + c);
+        if (da2) g += *reinterpret_cast<const f32x4*>(da2 + m * da2_ps + c);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + m * a_ps + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = av[e] > 0.0f ? g[e] : 0.0f;
+        if (base) g += *reinterpret_cast<const f32x4*>(base + m * base_ps + c);
+        *reinterpret_cast<f32x4*>(dz + i * 4) = g;
+    }
+}
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ x, const float* __restrict__ y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        v += *reinterpret_cast<const f32x4*>(y + i * 4);
+        *reinterpret_cast<f32x4*>(x + i * 4) = v;
+    }
+}
+
+// filters [9][Cout][Cin] (3x3, stride 2, pad 1) <-> [4][Cout][4 Cin] (2x2 on the space-to-depth input).
+// tap (r, s) -> 2x2 tap t = (r == 0 ? 0 : 1) * 2 + (s == 0 ? 0 : 1), slice (a, b) = (r == 1 ? 0 : 1, s == 1 ? 0 : 1)
+__global__ __launch_bounds__(256) void w_s2d_kernel(const float* __restrict__ w3, int Cout, int Cin, float* __restrict__ w2, int to_s2d) {
+    const int64_t total = (int64_t)4 * Cout * 4 * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cin);
+        int64_t t = i / Cin;
+        const int ab = (int)(t % 4); t /= 4;
+        const int co = (int)(t % Cout);
+        const int tap2 = (int)(t / Cout);
+        const int dy = tap2 >> 1, dx = tap2 & 1, a = ab >> 1, b = ab & 1;
+        // (dy, a): (0, 1) -> r = 0; (1, 0) -> r = 1; (1, 1) -> r = 2; (0, 0) -> no tap
+        const int r = dy == 0 ? (a == 1 ? 0 : -1) : (a == 0 ? 1 : 2);
+        const int s = dx == 0 ? (b == 1 ? 0 : -1) : (b == 0 ? 1 : 2);
+        if (to_s2d) {
+            w2[i] = (r >= 0 && s >= 0) ? w3[((int64_t)(r * 3 + s) * Cout + co) * Cin + c] : 0.0f;
+        } else if (r >= 0 && s >= 0) {
+            const_cast<float*>(w3)[((int64_t)(r * 3 + s) * Cout + co) * Cin + c] = w2[i];      // gradient back to the 3x3 layout
+        }
+    }
+}
+
+}  // namespace
+
+void launch_s2d(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, float* out) {
+    RFI_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "space-to-depth: C % 4 == 0, even H and W");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 8);
+    hipLaunchKernelGGL(s2d_kernel, dim3(grid_of((int64_t)N * H * W * C / 4)), dim3(256), 0, ctx->stream, x, N, H, W, C, out);
+    check_launch("s2d");
+}
+void launch_d2s_add(rfi_ctx* ctx, const float* dxp, const float* ds, View extra, int N, int H, int W, int C, float* out) {
+    RFI_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "depth-to-space: C % 4 == 0, even H and W");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 12);
+    hipLaunchKernelGGL(d2s_add_kernel, dim3(grid_of((int64_t)N * H * W * C / 4)), dim3(256), 0, ctx->stream, dxp, ds, extra.p,
+                       extra.pstride, N, H, W, C, out);
+    check_launch("d2s_add");
+}
+void launch_bn_add_relu(rfi_ctx* ctx, const float* y, const float* scale, const float* shift, const float* s,
+                        const float* s_scale, const float* s_shift, int64_t M, int C, MutView out, MutView out2) {
+    RFI_REQUIRE(C % 4 == 0, "bn_add_relu: C % 4 == 0");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * (out2.p ? 16 : 12));
+    hipLaunchKernelGGL(bn_add_relu_kernel, dim3(grid_of(M * C / 4)), dim3(256), 0, ctx->stream, y, scale, shift, s, s_scale,
+                       s_shift, M, C, out.p, out.pstride, out2.p, out2.pstride);
+    check_launch("bn_add_relu");
+}
+void launch_relu_mask(rfi_ctx* ctx, View da, View da2, View a, View base, int64_t M, int C, float* dz) {
+    RFI_REQUIRE(C % 4 == 0, "relu_mask: C % 4 == 0");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * (12 + (da2.p ? 4 : 0) + (base.p ? 4 : 0)));
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_of(M * C / 4)), dim3(256), 0, ctx->stream, da.p, da.pstride, da2.p, da2.pstride,
+                       a.p, a.pstride, base.p, base.pstride, M, C, dz);
+    check_launch("relu_mask");
+}
+void launch_add_inplace(rfi_ctx* ctx, float* x, const float* y, int64_t n) {
+    RFI_REQUIRE(n % 4 == 0, "add_inplace: n % 4 == 0");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * 12);
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_of(n / 4)), dim3(256), 0, ctx->stream, x, y, n / 4);
+    check_launch("add_inplace");
+}
+void launch_w_s2d(rfi_ctx* ctx, float* w3, int Cout, int Cin, float* w2, bool to_s2d) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)25 * Cout * Cin * 4);
+    hipLaunchKernelGGL(w_s2d_kernel, dim3(grid_of((int64_t)16 * Cout * Cin)), dim3(256), 0, ctx->stream, w3, Cout, Cin, w2,
+                       to_s2d ? 1 : 0);
+    check_launch("w_s2d");
+}
+
+}  // namespace rfi

@@ -471,14 +471,18 @@ void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
     RFI_REQUIRE((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride < (int64_t)1 << 31 &&
                     (int64_t)a.N * a.H * a.W * a.yop.pstride < (int64_t)1 << 31,
                 "wgrad: tensor too large for 32-bit element offsets");
-    const bool ok = wgrad_mfma_eligible(a);
+    const bool ok = wgrad_mfma_eligible(a) || ((a.bf16 || a.bf16x3) && wgrad_split_eligible(a));
     if (impl == IMPL_MFMA) RFI_REQUIRE(ok, "wgrad: shape/alignment not eligible for the MFMA kernel");
     if (impl == IMPL_DIRECT || !ok) {
         launch_wgrad_direct(ctx, a);
         return;
     }
     static const bool old_x3 = getenv("RFI_OLD_WGRAD") != nullptr;       // round 1's split-per-fragment kernel (A/B runs)
-    if (a.bf16x3 && !old_x3 && wgrad_split_eligible(a)) {
+    // R = 2 / S = 1 and R = 1 (ResNet-style encoder) exist only in the split-at-staging kernel (P = 1: bf16 mode)
+    const bool only_split = (a.R == 2 && a.S == 1) || a.R == 1;
+    if (only_split) RFI_REQUIRE((a.bf16 || a.bf16x3) && wgrad_split_eligible(a),
+                                "wgrad: 2x2 stride-1 and 1x1 weight gradients need the bf16 or 3 x bf16 arithmetic and 4-channel alignment");
+    if (((a.bf16x3 && !old_x3) || only_split) && wgrad_split_eligible(a)) {
         launch_wgrad_split(ctx, a);
         return;
     }

@@ -45,9 +45,9 @@ struct SWgradDev {
     int64_t slab_stride;
 };
 
-template <int R, int S, int BYB, int BXB, int TH, int TW>
+template <int R, int S, int BYB, int BXB, int TH, int TW, int P_>
 struct SWCfg {
-    static constexpr int P = 3;
+    static constexpr int P = P_;
     static constexpr int NT = 256;
     static constexpr int NTAP = R * R;
     static constexpr int BM = TH * TW;
@@ -89,10 +89,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
 }
 
 
-template <int R, int S, int BYB, int BXB, int TH, int TW>
+template <int R, int S, int BYB, int BXB, int TH, int TW, int P>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(SWgradDev d) {
-    using C = SWCfg<R, S, BYB, BXB, TH, TW>;
-    constexpr int P = 3;
+    using C = SWCfg<R, S, BYB, BXB, TH, TW, P>;
     const WgradArgs& a = d.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const sY = smem;
@@ -154,12 +153,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(SWgradDev d) {
     };
     // transform, split ONCE into (h, m, l) and write the three planes of the thread's 4 channels (8 bytes each)
     auto put = [&](f32x4 v, unsigned char* dst) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        split_pair(v.x, v.y, h0, m0, l0);
-        split_pair(v.z, v.w, h1, m1, l1);
-        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(dst + 64) = u32x2{m0, m1};
-        *reinterpret_cast<u32x2*>(dst + 128) = u32x2{l0, l1};
+        if constexpr (P == 3) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_pair(v.x, v.y, h0, m0, l0);
+            split_pair(v.z, v.w, h1, m1, l1);
+            *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(dst + 64) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(dst + 128) = u32x2{l0, l1};
+        } else {                                  // bf16 compute mode: one rounding (RNE) per element at staging
+            *reinterpret_cast<u32x2*>(dst) = u32x2{cvt_pair(v.x, v.y), cvt_pair(v.z, v.w)};
+        }
     };
     auto store_tile = [&]() {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -296,18 +299,18 @@ struct Plan { int nsplit; int64_t slab_stride; };
 
 template <int R, int S, int BYB, int BXB, int TH, int TW>
 Plan plan_cfg(const WgradArgs& a) {
+    static const int wgs = getenv("RFI_WGRAD_WGS") ? atoi(getenv("RFI_WGRAD_WGS")) : 512;    // tuning experiments
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
     const int chunks = (int)cdiv(a.Cy, 32 * BYB) * (int)cdiv(a.Cx, 32 * BXB);
-    static const int wgs = getenv("RFI_WGRAD_WGS") ? atoi(getenv("RFI_WGRAD_WGS")) : 512;    // tuning experiments
     int nsplit = (int)cdiv(wgs, chunks);             // two workgroups per CU in total
     if (nsplit > ntiles) nsplit = ntiles;
     if (nsplit < 1) nsplit = 1;
     return Plan{nsplit, (int64_t)R * R * a.tap_stride};
 }
 
-template <int R, int S, int BYB, int BXB, int TH, int TW>
+template <int R, int S, int BYB, int BXB, int TH, int TW, int P>
 void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
-    using C = SWCfg<R, S, BYB, BXB, TH, TW>;
+    using C = SWCfg<R, S, BYB, BXB, TH, TW, P>;
     const Plan p = plan_cfg<R, S, BYB, BXB, TH, TW>(a);
     RFI_REQUIRE(a.slab && a.slab_floats >= (size_t)p.nsplit * p.slab_stride, "wgrad: slab workspace too small");
     SWgradDev d{a, p.nsplit, p.slab_stride};
@@ -315,7 +318,7 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
     const size_t lds = C::LDS_BYTES;
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<R, S, BYB, BXB, TH, TW>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<R, S, BYB, BXB, TH, TW, P>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
     {
@@ -324,20 +327,25 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
         if (ctx->profiling)
             label = "wgrad R" + std::to_string(R) + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
                     std::to_string(a.W) + " cx" + std::to_string(a.Cx) + " cy" + std::to_string(a.Cy) + " split" +
-                    std::to_string(p.nsplit) + " 3xbf16 split-at-staging";
+                    std::to_string(p.nsplit) + (P == 3 ? " 3xbf16" : " bf16") + " split-at-staging";
         ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0, label);
-        hipLaunchKernelGGL((wgrad_split_kernel<R, S, BYB, BXB, TH, TW>), grid, dim3(256), lds, ctx->stream, d);
+        hipLaunchKernelGGL((wgrad_split_kernel<R, S, BYB, BXB, TH, TW, P>), grid, dim3(256), lds, ctx->stream, d);
         check_launch("wgrad_split");
     }
     launch_reduce_slabs(ctx, a.slab, p.nsplit, p.slab_stride, a.dw);
 }
 
+template <int R, int S>
 Plan select(rfi_ctx* ctx, const WgradArgs& a, bool launch) {
     const bool y2 = a.Cy > 32, x2 = a.Cx > 32;
-#define RFI_SW(BYB_, BXB_, TH_, TW_)                                        \
-    do {                                                                    \
-        if (launch) launch_cfg<3, 1, BYB_, BXB_, TH_, TW_>(ctx, a);         \
-        return plan_cfg<3, 1, BYB_, BXB_, TH_, TW_>(a);                     \
+    const bool p1 = a.bf16 && !a.bf16x3;
+#define RFI_SW(BYB_, BXB_, TH_, TW_)                                                  \
+    do {                                                                              \
+        if (launch) {                                                                 \
+            if (p1) launch_cfg<R, S, BYB_, BXB_, TH_, TW_, 1>(ctx, a);                \
+            else launch_cfg<R, S, BYB_, BXB_, TH_, TW_, 3>(ctx, a);                   \
+        }                                                                             \
+        return plan_cfg<R, S, BYB_, BXB_, TH_, TW_>(a);                               \
     } while (0)
     if (y2 && x2) RFI_SW(2, 2, 8, 8);
     if (y2) RFI_SW(2, 1, 8, 8);
@@ -346,18 +354,24 @@ Plan select(rfi_ctx* ctx, const WgradArgs& a, bool launch) {
     RFI_SW(1, 1, 16, 8);
 #undef RFI_SW
 }
+Plan select_r(rfi_ctx* ctx, const WgradArgs& a, bool launch) {
+    if (a.R == 3) return select<3, 1>(ctx, a, launch);
+    if (a.R == 2) return select<2, 1>(ctx, a, launch);
+    return select<1, 1>(ctx, a, launch);
+}
 
 }  // namespace
 
+// 3x3 (pad 1), the 2x2 (pad 1) form of a stride-2 3x3 conv on its space-to-depth input, and 1x1 convolutions
 bool wgrad_split_eligible(const WgradArgs& a) {
     if (a.Cx % 4 || a.Cy % 4 || a.xop.pstride % 4 || a.yop.pstride % 4) return false;
     if ((reinterpret_cast<uintptr_t>(a.xop.p) & 15) || (reinterpret_cast<uintptr_t>(a.yop.p) & 15)) return false;
-    return a.R == 3 && a.S == 1 && a.pad == 1;
+    return (a.R == 3 && a.S == 1 && a.pad == 1) || (a.R == 2 && a.S == 1 && a.pad == 1) || (a.R == 1 && a.S == 1 && a.pad == 0);
 }
 size_t wgrad_split_slab_floats(const WgradArgs& a) {
-    const Plan p = select(nullptr, a, false);
+    const Plan p = select_r(nullptr, a, false);
     return (size_t)p.nsplit * p.slab_stride;
 }
-void launch_wgrad_split(rfi_ctx* ctx, const WgradArgs& a) { select(ctx, a, true); }
+void launch_wgrad_split(rfi_ctx* ctx, const WgradArgs& a) { select_r(ctx, a, true); }
 
 }  // namespace rfi

@@ -340,3 +340,36 @@ def test_conv3x3_tiny_operands_underflow(impl):
     got = torch.from_numpy(out.numpy()).permute(0, 3, 1, 2).double()
     assert torch.isfinite(got).all()
     assert ((got - want).abs() <= 16 * 2.0 ** -24 * bound + 144 * 2.0 ** -126).all()
+
+
+# (n, h, w, cin, cout): the stride-2 convolutions of the ResNet-style encoder -- the 2x2 form on the
+# space-to-depth input and the 1x1 projection on a channel slice of it, every layer shape of UNetResNet18(f=64) at
+# 128 x 128 and of the small test models, plus ragged ones
+S2_SHAPES = [(2, 128, 128, 64, 128), (2, 64, 64, 128, 256), (2, 32, 32, 256, 512), (4, 64, 64, 16, 32), (3, 32, 32, 8, 16),
+             (1, 8, 8, 4, 8), (1, 12, 20, 20, 36), (3, 4, 4, 32, 64), (2, 16, 16, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", S2_SHAPES)
+@pytest.mark.parametrize("ksize", [3, 1])
+def test_stride2_convolutions(shape, ksize):
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(11 + hash(shape) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, ksize, ksize, generator=g) / (ksize * cin ** 0.5)).requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride=2, padding=ksize // 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    c = ctx()
+    dxd, dwd, ddy = c.to_device(nhwc(x.detach())), c.to_device(wt.detach().numpy()), c.to_device(nhwc(dy))
+    for impl in [IMPL_DIRECT, IMPL_MFMA, IMPL_X3]:
+        out = c.empty((n, h // 2, w // 2, cout))
+        check(lib.rfi_op_conv_s2(c.handle, impl, ksize, P(dxd), n, h, w, cin, P(dwd), cout, P(out)))
+        assert rel_err(out.numpy(), nhwc(y.detach())) <= TOL, f"fwd impl={impl}"
+        gx = c.empty((n, h, w, cin))
+        check(lib.rfi_op_conv_s2_dgrad(c.handle, impl, ksize, P(ddy), n, h, w, cout, P(dwd), cin, P(gx)))
+        assert rel_err(gx.numpy(), nhwc(x.grad)) <= TOL, f"dgrad impl={impl}"
+        if impl == IMPL_MFMA:
+            continue            # these weight gradients exist in the 3 x bf16 / bf16 arithmetic (and the direct kernel) only
+        gw = c.empty((cout, cin, ksize, ksize))
+        check(lib.rfi_op_conv_s2_wgrad(c.handle, impl, ksize, P(dxd), P(ddy), n, h, w, cin, cout, P(gw)))
+        assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, f"wgrad impl={impl}"
