@@ -50,16 +50,18 @@ def usable_cpus():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(workload, features, size, seconds_cap=25.0):
+def cpu_baseline(workload, features, size, gpu_batch=64, seconds_cap=25.0):
     """The oracle (torch-CPU fp32 restatement of the reference step) timed on this host.  A BOUNDED sample:
     batch 4 (BASELINE configs[0]; batch 1 for the 1024x1024 workload) -- not the GPU's batch 64 -- first on all
     usable host threads, then on ONE thread (SURVEY 8d asks for both).  A reported baseline, not the target."""
     import torch
 
-    from oracle import cnn_ref, unet_ref
+    from oracle import cnn_ref, resnet_unet_ref, unet_ref
     threads = usable_cpus()
     if workload == "cnn3":
         mk, step, what = cnn_ref.init_state, cnn_ref.train_step, f"cnn_ref SimpleCNN(3,1,{features})"
+    elif workload.startswith("resnet"):
+        mk, step, what = resnet_unet_ref.init_state, resnet_unet_ref.train_step, f"resnet_unet_ref ResNetUNet(3,1,{features})"
     else:
         mk, step, what = unet_ref.init_state, unet_ref.train_step, f"unet_ref UNet(3,1,{features})"
     batch = 1 if size >= 512 else 4
@@ -87,7 +89,7 @@ def cpu_baseline(workload, features, size, seconds_cap=25.0):
     med1, n1 = timed(1, 1, 3, seconds_cap * 0.4) if size < 512 else (None, 0)
     unit = "patches/s" if size < 512 else "samples/s"
     out = {"value": round(batch / med, 3), "unit": unit, "cores": threads, "kind": "port",
-           "sample": f"oracle/{what}.train_step, batch {batch} (the GPU line is batch 64) x {size}x{size}x3 fp32, "
+           "sample": f"oracle/{what}.train_step, batch {batch} (the GPU line is batch {gpu_batch}) x {size}x{size}x3 fp32, "
                      f"{n} timed steps after {warm} warm-up, median {med * 1e3:.1f} ms/step, "
                      f"torch.set_num_threads({threads})"}
     if med1:
@@ -134,7 +136,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=("unet", "cnn3", "unet1024"), default="unet",
+    ap.add_argument("--workload", choices=("unet", "cnn3", "unet1024", "resnet", "resnet1024"), default="unet",
                     help="unet: UNet(3,1,32) batch 64 x 128^2 (headline, BASELINE configs[1]/[4] shape); "
                          "cnn3: the builder-defined 3-layer CNN of configs[1] (SURVEY 8a A9), batch 64 x 128^2; "
                          "unet1024: UNet(3,1,32) on 1 x 1024^2 (configs[2] shape, fp32)")
@@ -158,11 +160,15 @@ def main():
         return self_launch(args.gpus)
 
     if args.batch is None:
-        args.batch = 1 if args.workload == "unet1024" else 64
+        args.batch = 1 if args.workload.endswith("1024") else 64
     if args.size is None:
-        args.size = 1024 if args.workload == "unet1024" else 128
+        args.size = 1024 if args.workload.endswith("1024") else 128
     if args.features is None:
-        args.features = 64 if args.workload == "cnn3" else 32
+        args.features = 64 if args.workload in ("cnn3", "resnet", "resnet1024") else 32
+
+    if args.workload.startswith("resnet") and args.dtype in ("bf16", "f32planes"):
+        # the plane data flow exists for the plain U-Net only: this model's bf16 mode rounds operands in registers
+        args.dtype = {"bf16": "bf16regs", "f32planes": "f32"}[args.dtype]
 
     from rfi_toolbox_amd import distributed as D
     rank, local_rank, world = D.init_control_plane("gloo")
@@ -182,7 +188,7 @@ def main():
 
     from rfi_toolbox_amd._lib import Hyper
     from rfi_toolbox_amd.data_generation import make_training_patches_device
-    from rfi_toolbox_amd.models import SimpleCNN, UNet
+    from rfi_toolbox_amd.models import SimpleCNN, UNet, UNetResNet18
     from rfi_toolbox_amd.runtime import Context
 
     log("imports done")
@@ -192,6 +198,8 @@ def main():
     torch.manual_seed(1234)                       # identical replicas on every rank
     if args.workload == "cnn3":
         model = SimpleCNN(3, 1, args.features, device=local_rank)
+    elif args.workload.startswith("resnet"):
+        model = UNetResNet18(3, 1, args.features, device=local_rank)
     else:
         model = UNet(3, 1, args.features, device=local_rank)
     model.train()
@@ -272,7 +280,7 @@ def main():
     # profiler and time itself at once) -- a constant read from the committed rocprofv3 --pmc passes of this
     # same command, and labelled as such
     import glob
-    tag = {"unet": "", "cnn3": "_cnn3", "unet1024": "_unet1024"}[args.workload] + \
+    tag = {"unet": "", "cnn3": "_cnn3", "unet1024": "_unet1024", "resnet": "_resnet", "resnet1024": "_resnet1024"}[args.workload] + \
           ("" if args.dtype == "f32" else "_" + args.dtype)
     traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic{tag}.json")))
     if traffic_files:
@@ -311,7 +319,11 @@ def main():
             "cnn3": f"SimpleCNN(3,1,{args.features}) = Conv3x3+ReLU, Conv3x3+ReLU, Conv1x1 (BASELINE configs[1]; "
                     f"builder-defined, SURVEY 8a A9) train step, batch {B}/GPU x {S}x{S}x3 NHWC fp32",
             "unet1024": f"UNet(3,1,{args.features}) train step on {B} x {S}x{S}x3 per GPU, fp32 "
-                        "(BASELINE configs[2] shape on the reference's U-Net)"}[args.workload],
+                        "(BASELINE configs[2] shape on the reference's U-Net)",
+            "resnet": f"UNetResNet18(3,1,{args.features}) (U-Net with a ResNet-18-style encoder; builder-defined, SURVEY 8a A10) "
+                      f"train step, batch {B}/GPU x {S}x{S}x3 NHWC",
+            "resnet1024": f"UNetResNet18(3,1,{args.features}) train step on {B} x {S}x{S}x3 per GPU (BASELINE configs[2]; "
+                          "builder-defined model, SURVEY 8a A10)"}[args.workload],
                    "arithmetic": {"f32": "float32 (contractions by 3 x bf16 splitting, float32-level accuracy; "
                                          "--dtype f32mfma selects the native float32 MFMA)",
                                   "f32planes": "float32 (3 x bf16 pieces, pre-split plane tensors, LDS-DMA staging)",
@@ -331,7 +343,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline ...")
-        out["cpu_baseline"] = cpu_baseline(args.workload, args.features, S)
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.features, S, B)
     print(json.dumps(out))
 
 
