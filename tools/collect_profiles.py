@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Fold gpurun_out/<TAG>/ (written on the GPU box by tools/profile_round.sh) into the tracked profiles/<TAG>_* files.
+
+    python tools/collect_profiles.py r2
+"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+for f in sorted(glob.glob(os.path.join(src, "bench*.json"))):
+    if os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
+for d, name in (("stats_serial", "kernel_stats"), ("stats_overlap", "kernel_stats_overlap"),
+                ("stats_serial_bf16", "kernel_stats_bf16")):
+    hits = glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True)
+    if hits:
+        shutil.copy(hits[0], os.path.join(dst, f"{tag}_{name}.csv"))
+here = os.path.join(ROOT, "tools")
+for dt, suffix in (("f32", ""), ("bf16", "_bf16")):
+    fd, wd, md = (os.path.join(src, f"pmc_{k}_{dt}") for k in ("fetch", "write", "mfma"))
+    if os.path.isdir(fd) and os.path.isdir(wd):
+        subprocess.check_call([sys.executable, os.path.join(here, "summarize_pmc.py"), fd, wd,
+                               os.path.join(dst, f"{tag}_traffic{suffix}.json")], stdout=subprocess.DEVNULL)
+    if os.path.isdir(md):
+        subprocess.check_call([sys.executable, os.path.join(here, "summarize_mfma.py"), md,
+                               os.path.join(dst, f"{tag}_mfma_util{suffix}.json")], stdout=subprocess.DEVNULL)
+print("\n".join(sorted(os.listdir(dst))))

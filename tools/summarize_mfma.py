@@ -8,7 +8,7 @@ effective shader clock of the two persistent MFMA kernel families.
 Both kernels are persistent (every wave lives for the whole launch), so per dispatch
 kernel_cycles = 4 x SQ_WAVE_CYCLES / n_waves (SQ_WAVE_CYCLES counts quad-cycles summed over waves),
 eff_clock = kernel_cycles / duration, and mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
-kernel_cycles).  fp32 MFMA 32x32x2 keeps a SIMD's pipe busy 64 cycles per instruction.
+kernel_cycles).  (v_mfma_f32_32x32x2_f32 keeps a SIMD's pipe busy 64 cycles per instruction, v_mfma_f32_32x32x16_bf16 32.)
 (GRBM_GUI_ACTIVE is not used: it runs ~8 us longer than the dispatch and not at the shader clock.)"""
 import collections
 import csv
@@ -42,7 +42,6 @@ res = {}
 for fam, a in acc.items():
     res[fam] = {"launches_seen": int(a["n"]), "avg_launch_us": round(a["ns"] / a["n"] / 1e3, 2),
                 "eff_clock_GHz": round(a["cycles"] / a["ns"], 3),
-                "mfma_util": round(a["mfma"] / (1024.0 * a["cycles"]), 4),
-                "peak_at_eff_clock_TFLOPs": round(157.3 * (a["cycles"] / a["ns"]) / 2.4, 1)}
+                "mfma_util": round(a["mfma"] / (1024.0 * a["cycles"]), 4)}
 json.dump({"families": res, "note": " ".join(__doc__.split("\n\n")[-1].split())}, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
