@@ -7,9 +7,11 @@
 
 A step = forward + BCE/dice loss + backward + (RCCL gradient all-reduce when N > 1) + global-norm
 clip + Adam on one batch of 64 synthetic patches per GPU that is already resident in HBM.
-Prints ONE JSON line on rank 0.  float32 results (the reference's CPU path is fp32); --dtype picks how the
-contractions are computed: f32 = float32 by 3 x bf16 splitting (default), f32mfma = native float32 MFMA,
-bf16 = bfloat16 operands.
+Prints ONE JSON line on rank 0.  --dtype picks the arithmetic of the contractions: bf16 (default for the U-Net
+workloads) = bfloat16 activations in HBM and bf16 MFMA operands with float32 accumulation, BatchNorm, loss and
+optimiser -- the mixed precision the reference itself trains in on a GPU (torch.autocast, train_model.py:131,144);
+f32 = float32 by 3 x bf16 splitting (float32-level accuracy; the reference's CPU arithmetic); f32mfma = native
+float32 MFMA.  At N = 1 the default line also carries the float32 measurement of the same step ("float32").
 """
 import argparse
 import json
@@ -131,6 +133,148 @@ def self_launch(n):
         raise SystemExit(f"bench ranks failed (rank, exit code): {bad}")
 
 
+def roofline_of(launches, fam_serial, profile_steps, dtype, workload, peak_tf):
+    """Roofline of the dominant MFMA kernel family from the per-launch HIP-event records of the SERIAL profile
+    steps (each kernel alone on the chip).  Per launch the attainable time is max(flops / MFMA peak, bytes / HBM
+    peak) with the ALGORITHMIC flops and bytes of that launch; `bound` is the roof that accounts for most of the
+    family's attainable time and `achieved` / `peak` / `frac` are quoted against that roof; `model_frac` is the
+    roofline-model fraction sum(attainable) / sum(measured) over the family's launches."""
+    roof = {"bound": "mfma", "achieved": None, "peak": round(peak_tf, 1), "unit": "TFLOP/s", "frac": None,
+            "traffic": None, "instruction": INSTR_BY_DTYPE[dtype]}
+    mfma_fams = [k for k in ("conv_igemm_mfma", "wgrad_igemm_mfma") if k in fam_serial and fam_serial[k]["ms"]]
+    if not mfma_fams:
+        return roof, None
+    dom = max(mfma_fams, key=lambda k: fam_serial[k]["ms"])
+    rows = [r for r in launches if r["family"] == dom and r["ms"] > 0]
+    t_meas = sum(r["ms"] for r in rows) * 1e-3
+    fl = sum(r["gflop"] for r in rows) * 1e9
+    by = sum(r["mbytes"] for r in rows) * 1e6
+    t_f = [r["gflop"] * 1e9 / (peak_tf * 1e12) for r in rows]
+    t_b = [r["mbytes"] * 1e6 / (PEAK_HBM_GBS * 1e9) for r in rows]
+    att_f = sum(a for a, b in zip(t_f, t_b) if a >= b)
+    att_b = sum(b for a, b in zip(t_f, t_b) if b > a)
+    n_f = sum(1 for a, b in zip(t_f, t_b) if a >= b)
+    hbm_bound = att_b > att_f
+    if hbm_bound:
+        ach = by / t_meas / 1e9
+        roof.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+    else:
+        ach = fl / t_meas / 1e12
+        roof.update(achieved=round(ach, 3), frac=round(ach / peak_tf, 4))
+    roof.update(kernel=dom,
+                mode="serial profile steps (side-stream overlap off, each kernel alone); the timed region runs with "
+                     "the weight-gradient kernels overlapped on a side stream",
+                avg_launch_ms=round(t_meas * 1e3 / len(rows), 5), launches_per_step=len(rows) / profile_steps,
+                algorithmic_flops_per_launch=fl / len(rows), algorithmic_bytes_per_launch=by / len(rows),
+                tflops=round(fl / t_meas / 1e12, 3), frac_of_mfma_peak=round(fl / t_meas / 1e12 / peak_tf, 4),
+                gbs=round(by / t_meas / 1e9, 1), frac_of_hbm_peak=round(by / t_meas / 1e9 / PEAK_HBM_GBS, 4),
+                model_frac=round((att_f + att_b) / t_meas, 4),
+                launches_mfma_bound=n_f, launches_hbm_bound=len(rows) - n_f)
+    if dtype in ("f32", "f32planes"):    # secondary: the same float32 work against what the native float32 MFMA could do
+        roof["vs_native_f32_mfma_peak_157.3"] = round(fl / t_meas / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    if not roof["frac"] <= 1.0 or not roof["frac_of_mfma_peak"] <= 1.0:
+        raise SystemExit(f"roofline fraction {roof['frac']} > 1: wrong peak for the instruction stream")
+    # HBM bytes per launch of the dominant family: NOT measured by this run (bench.py cannot sit under the profiler
+    # and time itself at once) -- a constant read from the committed rocprofv3 --pmc passes of this same command
+    import glob
+    tag = {"unet": "", "cnn3": "_cnn3", "unet1024": "_unet1024", "resnet": "_resnet", "resnet1024": "_resnet1024"}[workload] + \
+          ("" if dtype == "f32" else "_" + dtype)
+    traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic{tag}.json")))
+    if traffic_files:
+        try:
+            tj = json.load(open(traffic_files[-1]))["families"].get(dom)
+            if tj:
+                roof["traffic"] = tj["hbm_bytes_per_launch"]
+                roof["traffic_source"] = ("static, from " + os.path.relpath(traffic_files[-1], ROOT) +
+                                          " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                          "not measured by this run)")
+        except Exception:
+            pass
+    return roof, dom
+
+
+def per_family(report, profile_steps):
+    out_ = {}
+    for name, f in report.items():
+        per = {"launches_per_step": f["launches"] / profile_steps, "ms_per_step": f["ms"] / profile_steps}
+        if f["flops"]:
+            per["tflops"] = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] else None
+        if f["bytes"]:
+            per["gbs"] = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else None
+        out_[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in per.items()}
+    return out_
+
+
+def read_launch_csv(path):
+    import csv
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append({"family": r["family"], "label": r["label"], "ms": float(r["ms"]), "gflop": float(r["gflop"]),
+                     "mbytes": float(r["mbytes"])})
+    return rows
+
+
+def measure(model, ctx, D, d_x, d_y, hp, args, dtype, rank, launch_csv=None):
+    """W untimed + K timed steps of `model` in arithmetic `dtype` (barrier + synchronize on both sides, max over
+    ranks), then the per-family HIP-event profile on separate steps."""
+    import tempfile
+    B, S = args.batch, args.size
+    model.set_compute_dtype(MODE_BY_DTYPE[dtype])
+    for _ in range(args.warmup):
+        model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+    ctx.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+    ev_ms = ctx.timer_stop()                      # HIP events on the ctx stream; synchronises
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    D.barrier()
+    wall = D.max_over_ranks(wall)
+    log(f"[{dtype}] timed region done: {wall * 1e3 / args.steps:.2f} ms/step")
+    loss, _ = model.last_loss()
+    if not np.isfinite(loss):
+        raise SystemExit(f"non-finite loss {loss}")
+    # ---- per-kernel-family HIP-event profile (separate steps so events do not sit in the timed region).
+    # Two passes: OVERLAPPED (the mode the timed region ran in; durations of co-running kernels stretch) and SERIAL
+    # (side-stream overlap off: every kernel alone on the chip -> the per-kernel durations the roofline is computed
+    # from, comparable with `RFI_NO_OVERLAP=1 rocprofv3 --stats`)
+    fam, fam_ov, launches = {}, {}, []
+    if args.profile_steps > 0:
+        for serial in (False, True):
+            ctx.set_overlap(not serial and not os.environ.get("RFI_NO_OVERLAP") == "1")
+            ctx.profile_reset()
+            ctx.profile(True)
+            for _ in range(args.profile_steps):
+                model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+            ctx.synchronize()
+            ctx.profile(False)
+            if serial:
+                fam = ctx.profile_report()
+                if rank == 0:
+                    path = launch_csv or os.path.join(tempfile.gettempdir(), f"rfi_bench_launches_{os.getpid()}.csv")
+                    ctx.profile_dump(path)
+                    launches = read_launch_csv(path)
+                    if not launch_csv:
+                        os.unlink(path)
+            else:
+                fam_ov = ctx.profile_report()
+        ctx.set_overlap(not os.environ.get("RFI_NO_OVERLAP") == "1")
+    D.barrier()
+    return {"wall": wall, "ev_ms": ev_ms, "loss": float(loss), "fam": fam, "fam_ov": fam_ov, "launches": launches}
+
+
+ARITHMETIC = {"f32": "float32 (contractions by 3 x bf16 splitting, float32-level accuracy; --dtype f32mfma selects the "
+                     "native float32 MFMA)",
+              "f32planes": "float32 (3 x bf16 pieces, pre-split plane tensors, LDS-DMA staging)",
+              "f32mfma": "float32 (native v_mfma_f32_32x32x2_f32)",
+              "bf16": "bfloat16 activations in HBM and bf16 MFMA operands, float32 accumulate, float32 BatchNorm / loss / "
+                      "optimiser state (what torch.autocast gives the reference on a GPU, train_model.py:131,144)",
+              "bf16regs": "bfloat16 MFMA operands rounded in registers, float32 storage"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,18 +283,23 @@ def main():
     ap.add_argument("--workload", choices=("unet", "cnn3", "unet1024", "resnet", "resnet1024"), default="unet",
                     help="unet: UNet(3,1,32) batch 64 x 128^2 (headline, BASELINE configs[1]/[4] shape); "
                          "cnn3: the builder-defined 3-layer CNN of configs[1] (SURVEY 8a A9), batch 64 x 128^2; "
-                         "unet1024: UNet(3,1,32) on 1 x 1024^2 (configs[2] shape, fp32)")
+                         "unet1024: UNet(3,1,32) on 1 x 1024^2 (configs[2] shape on the reference's U-Net); "
+                         "resnet / resnet1024: the builder-defined U-Net with a ResNet-18-style encoder (configs[2], "
+                         "SURVEY 8a A10) at 64 x 128^2 / 1 x 1024^2")
     ap.add_argument("--batch", type=int, default=None, help="patches per GPU per step")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--features", type=int, default=None)
-    ap.add_argument("--dtype", choices=("f32", "f32mfma", "bf16", "f32planes", "bf16regs"), default="f32",
-                    help="f32 (default): float32 contractions by 3 x bf16 splitting (float32-level accuracy, six "
-                         "bf16 MFMAs per product block); f32mfma: native float32 MFMA; bf16: operands rounded to "
-                         "bfloat16 and activations stored as bf16, float32 accumulate / BatchNorm / optimiser (the "
-                         "reference's autocast mode on a GPU); f32planes: the default arithmetic on pre-split plane "
-                         "tensors; bf16regs: round 1's bf16 mode (float32 storage)")
+    ap.add_argument("--dtype", choices=("f32", "f32mfma", "bf16", "f32planes", "bf16regs"), default=None,
+                    help="bf16 (default for unet / unet1024 / resnet1024): bfloat16 activations in HBM and bf16 MFMA "
+                         "operands, float32 accumulate / BatchNorm / loss / optimiser (the reference's autocast mode on a "
+                         "GPU); f32 (default for cnn3 / resnet): float32 contractions by 3 x bf16 splitting "
+                         "(float32-level accuracy, six bf16 MFMAs per product block); f32mfma: native float32 MFMA; "
+                         "f32planes: the f32 arithmetic on pre-split plane tensors; bf16regs: bf16 operands rounded in "
+                         "registers, float32 storage (round 1's bf16 mode)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-float32-line", action="store_true",
+                    help="skip the float32 measurement the default N = 1 line carries next to the bf16 one")
     ap.add_argument("--launch-csv", default=None, help="write the per-launch HIP-event profile here")
     ap.add_argument("--dry-run", action="store_true",
                     help="control plane only (rendezvous, barrier, max-over-ranks, one JSON line); no GPU work")
@@ -165,7 +314,9 @@ def main():
         args.size = 1024 if args.workload.endswith("1024") else 128
     if args.features is None:
         args.features = 64 if args.workload in ("cnn3", "resnet", "resnet1024") else 32
-
+    default_dtype = args.dtype is None
+    if default_dtype:
+        args.dtype = "bf16" if args.workload in ("unet", "unet1024", "resnet1024") else "f32"
     if args.workload.startswith("resnet") and args.dtype in ("bf16", "f32planes"):
         # the plane data flow exists for the plain U-Net only: this model's bf16 mode rounds operands in registers
         args.dtype = {"bf16": "bf16regs", "f32planes": "f32"}[args.dtype]
@@ -195,15 +346,17 @@ def main():
     ctx = Context.get(local_rank)
     D.init_gradient_exchange(ctx, rank, world)
 
-    torch.manual_seed(1234)                       # identical replicas on every rank
-    if args.workload == "cnn3":
-        model = SimpleCNN(3, 1, args.features, device=local_rank)
-    elif args.workload.startswith("resnet"):
-        model = UNetResNet18(3, 1, args.features, device=local_rank)
-    else:
-        model = UNet(3, 1, args.features, device=local_rank)
-    model.train()
-    model.set_compute_dtype(MODE_BY_DTYPE[args.dtype])
+    def build_model():
+        torch.manual_seed(1234)                   # identical replicas on every rank
+        if args.workload == "cnn3":
+            m = SimpleCNN(3, 1, args.features, device=local_rank)
+        elif args.workload.startswith("resnet"):
+            m = UNetResNet18(3, 1, args.features, device=local_rank)
+        else:
+            m = UNet(3, 1, args.features, device=local_rank)
+        return m.train()
+
+    model = build_model()
     log("model built")
     B, S = args.batch, args.size
     # synthetic waterfalls -> views/tiling -> 3-channel patches + labels, generated and kept in HBM
@@ -211,136 +364,67 @@ def main():
     hp = Hyper(1e-4, 0.9, 0.999, 1e-8, 1e-5, 1.0)   # train_model.py:89,95,130,149 defaults
     log(f"inputs resident: {d_x.shape} {d_y.shape}, label fraction {d_y.numpy().mean():.3f}")
 
-    for _ in range(args.warmup):
-        model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
-    ctx.synchronize()
-    log("warm-up done")
-    D.barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
-    ev_ms = ctx.timer_stop()                      # HIP events on the ctx stream; synchronises
-    ctx.synchronize()
-    wall = time.perf_counter() - t0
-    D.barrier()
-    wall = D.max_over_ranks(wall)
-    log(f"timed region done: {wall * 1e3 / args.steps:.2f} ms/step")
-    loss, gnorm = model.last_loss()
-    if not np.isfinite(loss):
-        raise SystemExit(f"non-finite loss {loss}")
-
-    # ---- per-kernel-family HIP-event profile (separate steps so events do not sit in the timed region).
-    # Two passes: SERIAL (side-stream overlap off: every kernel alone on the chip -> the per-kernel
-    # durations the roofline is computed from, comparable with `RFI_NO_OVERLAP=1 rocprofv3 --stats`)
-    # and OVERLAPPED (the mode the timed region ran in; durations of co-running kernels stretch).
-    fam, fam_ov = {}, {}
-    if args.profile_steps > 0:
-        for serial in (False, True):
-            ctx.set_overlap(not serial and not os.environ.get("RFI_NO_OVERLAP") == "1")
-            ctx.profile_reset()
-            ctx.profile(True)
-            for _ in range(args.profile_steps):
-                model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
-            ctx.synchronize()
-            ctx.profile(False)
-            if serial:
-                fam = ctx.profile_report()
-                if args.launch_csv and rank == 0:
-                    ctx.profile_dump(args.launch_csv)
-            else:
-                fam_ov = ctx.profile_report()
-        ctx.set_overlap(not os.environ.get("RFI_NO_OVERLAP") == "1")
-    D.barrier()
+    res = measure(model, ctx, D, d_x, d_y, hp, args, args.dtype, rank, args.launch_csv)
+    second = None
+    if world == 1 and default_dtype and args.dtype == "bf16" and not args.no_float32_line:
+        del model
+        model2 = build_model()                    # the same step from the same initial weights in float32
+        second = measure(model2, ctx, D, d_x, d_y, hp, args, "f32", rank)
+        fwd_flops, step_flops = model2.algorithmic_flops(B, S, S)
+        n_params = model2.num_parameters()
+    else:
+        fwd_flops, step_flops = model.algorithmic_flops(B, S, S)
+        n_params = model.num_parameters()
 
     if rank != 0:
         return
-    ms_per_step = wall * 1e3 / args.steps
-    value = world * B * args.steps / wall
-    fwd_flops, step_flops = model.algorithmic_flops(B, S, S)
-    peak = PEAK_BY_DTYPE[args.dtype]
-    roof = {"bound": "mfma", "achieved": None, "peak": round(peak, 1), "unit": "TFLOP/s", "frac": None,
-            "traffic": None, "instruction": INSTR_BY_DTYPE[args.dtype]}
 
-    def per_family(report):
-        out_ = {}
-        for name, f in report.items():
-            per = {"launches_per_step": f["launches"] / args.profile_steps, "ms_per_step": f["ms"] / args.profile_steps}
-            if f["flops"]:
-                per["tflops"] = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] else None
-            if f["bytes"]:
-                per["gbs"] = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else None
-            out_[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in per.items()}
-        return out_
-    fam_out = per_family(fam)
-    # the kernel family the step spends most time in (conv_igemm_mfma for the U-Net)
-    mfma_fams = [k for k in ("conv_igemm_mfma", "wgrad_igemm_mfma") if k in fam and fam[k]["ms"]]
-    dom = max(mfma_fams, key=lambda k: fam[k]["ms"]) if mfma_fams else "conv_igemm_mfma"
-    # HBM bytes per launch of the dominant family: NOT measured by this run (bench.py cannot sit under the
-    # profiler and time itself at once) -- a constant read from the committed rocprofv3 --pmc passes of this
-    # same command, and labelled as such
-    import glob
-    tag = {"unet": "", "cnn3": "_cnn3", "unet1024": "_unet1024", "resnet": "_resnet", "resnet1024": "_resnet1024"}[args.workload] + \
-          ("" if args.dtype == "f32" else "_" + args.dtype)
-    traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic{tag}.json")))
-    if traffic_files:
-        try:
-            tj = json.load(open(traffic_files[-1]))["families"].get(dom)
-            if tj:
-                roof["traffic"] = tj["hbm_bytes_per_launch"]
-                roof["traffic_source"] = ("static, from " + os.path.relpath(traffic_files[-1], ROOT) +
-                                          " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
-                                          "not measured by this run)")
-        except Exception:
-            pass
-    if dom in fam and fam[dom]["ms"]:
-        ach = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3) / 1e12
-        roof.update(mode="serial profile steps (side-stream overlap off, each kernel alone); the timed region "
-                         "runs with the weight-gradient kernels overlapped on a side stream",
-                    achieved=round(ach, 3), frac=round(ach / peak, 4), kernel=dom,
-                    avg_launch_ms=round(fam[dom]["ms"] / fam[dom]["launches"], 5),
-                    launches_per_step=fam[dom]["launches"] / args.profile_steps,
-                    algorithmic_flops_per_launch=fam[dom]["flops"] / fam[dom]["launches"])
-        if args.dtype in ("f32", "f32planes"):    # secondary: the same float32 work against what the native float32 MFMA could do
-            roof["vs_native_f32_mfma_peak_157.3"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
-        if not roof["frac"] <= 1.0:
-            raise SystemExit(f"roofline fraction {roof['frac']} > 1: wrong peak for the instruction stream")
-    step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
+    def line_of(r, dtype):
+        ms_per_step = r["wall"] * 1e3 / args.steps
+        peak = PEAK_BY_DTYPE[dtype]
+        roof, _ = roofline_of(r["launches"], r["fam"], max(args.profile_steps, 1), dtype, args.workload, peak)
+        step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
+        return {"value": round(world * B * args.steps / r["wall"], 2), "ms_per_step": round(ms_per_step, 4),
+                "dtype": "bf16" if dtype.startswith("bf16") else "f32", "arithmetic": ARITHMETIC[dtype],
+                "roofline": roof,
+                "step": {"algorithmic_gflop_per_patch": round(step_flops / B / 1e9, 3),
+                         "tflops_whole_step": round(step_tflops, 3),
+                         "frac_of_instruction_peak": round(step_tflops / peak, 4),
+                         "hip_event_ms_per_step": round(r["ev_ms"] / args.steps, 4), "final_loss": round(r["loss"], 6)},
+                "families": per_family(r["fam"], max(args.profile_steps, 1)),
+                "families_overlapped": per_family(r["fam_ov"], max(args.profile_steps, 1))}
+
+    main_line = line_of(res, args.dtype)
     out = {
         "metric": ("training patches/sec (128x128x3)" if S == 128 else f"training samples/sec ({S}x{S}x3)"),
-        "value": round(value, 2), "unit": "patches/s" if S < 512 else "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype.startswith("bf16") else "f32", "data": "synthetic",
+        "value": main_line["value"], "unit": "patches/s" if S < 512 else "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_line["dtype"], "data": "synthetic",
         "config": {"workload": {
             "unet": f"UNet(3,1,{args.features}) train step (fwd+BCE/dice+bwd+clip+Adam), "
-                    f"batch {B}/GPU x {S}x{S}x3 NHWC fp32, BASELINE configs[1] shape on the "
+                    f"batch {B}/GPU x {S}x{S}x3 NHWC, BASELINE configs[1] shape on the "
                     "reference's U-Net (the '3-layer CNN' of configs[1] is not in the reference; "
                     "its builder-defined form runs with --workload cnn3)",
             "cnn3": f"SimpleCNN(3,1,{args.features}) = Conv3x3+ReLU, Conv3x3+ReLU, Conv1x1 (BASELINE configs[1]; "
                     f"builder-defined, SURVEY 8a A9) train step, batch {B}/GPU x {S}x{S}x3 NHWC fp32",
-            "unet1024": f"UNet(3,1,{args.features}) train step on {B} x {S}x{S}x3 per GPU, fp32 "
+            "unet1024": f"UNet(3,1,{args.features}) train step on {B} x {S}x{S}x3 per GPU "
                         "(BASELINE configs[2] shape on the reference's U-Net)",
             "resnet": f"UNetResNet18(3,1,{args.features}) (U-Net with a ResNet-18-style encoder; builder-defined, SURVEY 8a A10) "
                       f"train step, batch {B}/GPU x {S}x{S}x3 NHWC",
             "resnet1024": f"UNetResNet18(3,1,{args.features}) train step on {B} x {S}x{S}x3 per GPU (BASELINE configs[2]; "
                           "builder-defined model, SURVEY 8a A10)"}[args.workload],
-                   "arithmetic": {"f32": "float32 (contractions by 3 x bf16 splitting, float32-level accuracy; "
-                                         "--dtype f32mfma selects the native float32 MFMA)",
-                                  "f32planes": "float32 (3 x bf16 pieces, pre-split plane tensors, LDS-DMA staging)",
-                                  "f32mfma": "float32 (native v_mfma_f32_32x32x2_f32)",
-                                  "bf16": "bfloat16 activations in HBM and bf16 MFMA operands, float32 accumulate, "
-                                          "float32 BatchNorm / loss / optimiser state",
-                                  "bf16regs": "bfloat16 MFMA operands rounded in registers, float32 storage"}[args.dtype],
+                   "arithmetic": main_line["arithmetic"],
                    "global_batch": B * world, "patch": [S, S, 3], "parallelism": f"dp{world}",
-                   "params": model.num_parameters()},
-        "roofline": roof,
-        "step": {"algorithmic_gflop_per_patch": round(step_flops / B / 1e9, 3),
-                 "tflops_whole_step": round(step_tflops, 3),
-                 "frac_of_instruction_peak": round(step_tflops / peak, 4),
-                 "hip_event_ms_per_step": round(ev_ms / args.steps, 4), "final_loss": round(float(loss), 6)},
-        "families": fam_out,
-        "families_overlapped": per_family(fam_ov),
+                   "params": n_params},
+        "roofline": main_line["roofline"],
+        "step": main_line["step"],
+        "families": main_line["families"],
+        "families_overlapped": main_line["families_overlapped"],
     }
+    if second is not None:
+        out["float32"] = line_of(second, "f32")
+        out["float32"]["note"] = ("the same step, same inputs and initial weights, with --dtype f32 (float32 contractions by "
+                                  "3 x bf16 splitting): the arithmetic of the reference's CPU path")
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline ...")
         out["cpu_baseline"] = cpu_baseline(args.workload, args.features, S, B)

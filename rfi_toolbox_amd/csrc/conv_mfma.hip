@@ -777,7 +777,10 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
                 std::to_string(a.H) + "x" + std::to_string(a.W) + " " + std::to_string(a.Cin) + "->" +
                 std::to_string(a.Cout) + (a.xf.scale ? " xf" : "") + (a.zgroups > 1 ? " z4" : "") +
                 (a.bf16 ? " bf16" : "") + (a.bf16x3 ? " 3xbf16" : "");
-    ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0, label);
+    // algorithmic HBM bytes: every input, output and filter element once (float32 tensors)
+    const double bytes = 4.0 * ((double)a.N * a.Hin * a.Win * a.Cin + (double)a.N * a.H * a.W * a.zgroups * a.Cout +
+                                (double)a.R * a.R * a.zgroups * a.Cin * a.Cout);
+    ProfScope ps(ctx, FAM_CONV_MFMA, flops, bytes, label);
     if (a.R == 3) dispatch_tiles<3, 1>(ctx, a);
     else if (a.R == 1) dispatch_tiles<1, 1>(ctx, a);
     else if (a.S == 1) dispatch_tiles<2, 1>(ctx, a);

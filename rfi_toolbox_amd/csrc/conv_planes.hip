@@ -504,7 +504,10 @@ void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
     if (ctx->profiling)
         label = "pconv N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" + std::to_string(a.W) + " k" +
                 std::to_string(d.nkc * 16) + "->" + std::to_string(a.Cout) + (a.P == 3 ? " 3xbf16" : " bf16");
-    ProfScope ps(ctx, FAM_CONV_MFMA, flops, 0, label);
+    // algorithmic HBM bytes: the plane input (2 P bytes per value), the float32 output, the filters
+    const double bytes = (double)a.N * a.Hin * a.Win * d.nkc * 16.0 * 2 * a.P + 4.0 * a.N * a.H * a.W * a.Cout +
+                         (double)wbytes;
+    ProfScope ps(ctx, FAM_CONV_MFMA, flops, bytes, label);
     if (a.P == 3) dispatch<3>(ctx, d);
     else dispatch<1>(ctx, d);
     a.stats = d.a.stats;

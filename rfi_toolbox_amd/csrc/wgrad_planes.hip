@@ -312,7 +312,9 @@ void launch_cfg(rfi_ctx* ctx, PWgradDev& d) {
             label = "pwgrad R" + std::to_string(R) + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
                     std::to_string(a.W) + " cx" + std::to_string(a.seg_c[0] + a.seg_c[1]) + " cy" + std::to_string(a.Cy) +
                     " split" + std::to_string(p.nsplit) + (P == 3 ? " 3xbf16" : " bf16");
-        ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0, label);
+        const double cx = a.seg_c[0] + a.seg_c[1];
+        const double bytes = 2.0 * P * ((double)a.N * a.Hx * a.Wx * cx + (double)a.N * a.H * a.W * a.Cy) + 4.0 * R * R * cx * a.Cy;
+        ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, bytes, label);
         hipLaunchKernelGGL((pwgrad_kernel<R, S, BYB, BXB, TH, TW, P>), grid, dim3(256), lds, ctx->stream, d);
         check_launch("pwgrad");
     }

@@ -328,7 +328,8 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
             label = "wgrad R" + std::to_string(R) + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
                     std::to_string(a.W) + " cx" + std::to_string(a.Cx) + " cy" + std::to_string(a.Cy) + " split" +
                     std::to_string(p.nsplit) + (P == 3 ? " 3xbf16" : " bf16") + " split-at-staging";
-        ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, 0, label);
+        const double bytes = 4.0 * ((double)a.N * a.Hx * a.Wx * a.Cx + (double)a.N * a.H * a.W * a.Cy + (double)R * R * a.Cx * a.Cy);
+        ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, bytes, label);
         hipLaunchKernelGGL((wgrad_split_kernel<R, S, BYB, BXB, TH, TW, P>), grid, dim3(256), lds, ctx->stream, d);
         check_launch("wgrad_split");
     }

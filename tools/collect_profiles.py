@@ -16,7 +16,7 @@ for f in sorted(glob.glob(os.path.join(src, "bench*.json"))):
     if os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
 for d, name in (("stats_serial", "kernel_stats"), ("stats_overlap", "kernel_stats_overlap"),
-                ("stats_serial_bf16", "kernel_stats_bf16")):
+                ("stats_serial_bf16", "kernel_stats_bf16"), ("stats_overlap_bf16", "kernel_stats_overlap_bf16")):
     hits = glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, f"{tag}_{name}.csv"))

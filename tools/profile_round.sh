@@ -14,19 +14,19 @@ export TMPDIR=/tmp
 cd /tmp
 B="python3 $R/bench.py"
 T="timeout -k 10"
-$T 400 $B > "$O/bench.json" 2> "$O/bench.err"
-$T 300 $B --dtype bf16 --no-cpu-baseline > "$O/bench_bf16.json" 2>> "$O/bench.err"
+$T 400 $B > "$O/bench.json" 2> "$O/bench.err"                      # the driver's command: bf16 line + its float32 companion
+$T 300 $B --dtype f32 --no-cpu-baseline > "$O/bench_f32.json" 2>> "$O/bench.err"
 $T 300 $B --dtype f32mfma --no-cpu-baseline > "$O/bench_f32mfma.json" 2>> "$O/bench.err"
 $T 300 $B --workload cnn3 > "$O/bench_cnn3.json" 2>> "$O/bench.err"
 $T 400 $B --workload unet1024 > "$O/bench_unet1024.json" 2>> "$O/bench.err"
-$T 300 $B --workload unet1024 --dtype bf16 --no-cpu-baseline > "$O/bench_unet1024_bf16.json" 2>> "$O/bench.err"
-$T 400 $B --workload resnet1024 --dtype bf16 > "$O/bench_resnet1024_bf16.json" 2>> "$O/bench.err"
+$T 400 $B --workload resnet1024 > "$O/bench_resnet1024.json" 2>> "$O/bench.err"
 $T 300 $B --workload resnet --no-cpu-baseline > "$O/bench_resnet.json" 2>> "$O/bench.err"
 echo "bench lines done"
 P="--no-cpu-baseline --profile-steps 0 --steps 10 --warmup 3"
-RFI_NO_OVERLAP=1 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_serial" -- $B $P > "$O/stats_serial.log" 2>&1
-$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_overlap" -- $B $P > "$O/stats_overlap.log" 2>&1
+RFI_NO_OVERLAP=1 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_serial" -- $B $P --dtype f32 > "$O/stats_serial.log" 2>&1
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_overlap" -- $B $P --dtype f32 > "$O/stats_overlap.log" 2>&1
 RFI_NO_OVERLAP=1 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_serial_bf16" -- $B $P --dtype bf16 > "$O/stats_serial_bf16.log" 2>&1
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_overlap_bf16" -- $B $P --dtype bf16 > "$O/stats_overlap_bf16.log" 2>&1
 echo "kernel statistics done"
 Q="--no-cpu-baseline --profile-steps 0 --steps 5 --warmup 2"
 for dt in f32 bf16; do
