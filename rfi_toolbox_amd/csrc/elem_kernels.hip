@@ -486,6 +486,31 @@ __global__ void head_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
     }
 }
 
+// C % 4 == 0: L lanes per pixel (L a power of two <= 16), each lane reads 16-byte groups of channels
+template <int L>
+__global__ __launch_bounds__(256) void head_fwd_vec_kernel(const float* __restrict__ y, int64_t M, int C,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ w, const float* __restrict__ b, int Cout,
+                                                           float* __restrict__ logits, float slope) {
+    const int lane = threadIdx.x & (L - 1);
+    const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / L;
+    if (m >= M) return;   // whole L-lane group leaves together
+    const int C4 = C >> 2;
+    for (int o = 0; o < Cout; ++o) {
+        float acc = 0.0f;
+        for (int c4 = lane; c4 < C4; c4 += L) {
+            float yv[4], sc[4], sh[4], wv[4];
+            ldv<4>(y + m * C + 4 * c4, yv); ldv<4>(scale + 4 * c4, sc); ldv<4>(shift + 4 * c4, sh);
+            ldv<4>(w + (int64_t)o * C + 4 * c4, wv);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc += act_f(yv[v] * sc[v] + sh[v], slope) * wv[v];
+        }
+#pragma unroll
+        for (int off = L / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, L);
+        if (lane == 0) logits[m * Cout + o] = acc + b[o];
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __global__ void loss_reduce_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
@@ -689,6 +714,63 @@ __global__ void head_bwd_kernel(const float* __restrict__ y, int64_t M, int C, i
     }
 }
 
+// the same with four channels per lane (C % 4 == 0): 16-byte loads of y and stores of da
+__global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restrict__ y, int64_t M, int C, int CL,
+                                                           int64_t rows_per_block, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ w, int Cout,
+                                                           const float* __restrict__ dl, float* __restrict__ da,
+                                                           double* __restrict__ partial, float slope) {
+    __shared__ double red[4 * kBlock];
+    const int RL = kBlock / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = (blockIdx.y * CL + cl) * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const int64_t pstride = (int64_t)Cout * C + Cout;
+    for (int o = 0; o < Cout; ++o) {
+        double sw[4] = {0, 0, 0, 0}, sb = 0;
+        if (c < C) {
+            float sc[4], sh[4], wv[4];
+            ldv<4>(scale + c, sc); ldv<4>(shift + c, sh); ldv<4>(w + (int64_t)o * C + c, wv);
+            for (int64_t r = r0 + rl; r < r1; r += RL) {
+                const float d = dl[r * Cout + o];
+                float yv[4], g[4];
+                ldv<4>(y + r * C + c, yv);
+                if (o != 0) ldv<4>(da + r * C + c, g);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float a = act_f(yv[v] * sc[v] + sh[v], slope);
+                    sw[v] += (double)d * (double)a;
+                    g[v] = o == 0 ? d * wv[v] : g[v] + d * wv[v];
+                }
+                sb += (double)d;
+                stv<4>(da + r * C + c, g);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[v * kBlock + threadIdx.x] = sw[v];
+        __syncthreads();
+        if (rl == 0 && c < C) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double t = sw[v];
+                for (int k = 1; k < RL; ++k) t += red[v * kBlock + k * CL + cl];
+                partial[(int64_t)blockIdx.x * pstride + (int64_t)o * C + c + v] = t;
+            }
+        }
+        __syncthreads();
+        if (blockIdx.y == 0 && cl == 0) red[rl] = sb;   // db: channel lane 0 of the first channel block
+        __syncthreads();
+        if (blockIdx.y == 0 && threadIdx.x == 0) {
+            double t = 0;
+            for (int k = 0; k < RL; ++k) t += red[k];
+            partial[(int64_t)blockIdx.x * pstride + (int64_t)Cout * C + o] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ layouts
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int N, int C, int H, int W,
                                     float* __restrict__ dst) {
@@ -731,21 +813,34 @@ __global__ void weight_to_dgrad_kernel(const float* __restrict__ wf, int taps, i
         wd[i] = wf[((int64_t)ts * Cout + co) * Cin + ci];
     }
 }
-// all layers in one launch: blockIdx.y selects the layer descriptor
-__global__ void weight_to_dgrad_batched_kernel(const RelayoutDesc* __restrict__ descs, const float* __restrict__ src,
-                                               float* __restrict__ dst) {
-    const RelayoutDesc d = descs[blockIdx.y];
+// all layers in one launch: one 32 x 32 tile of one tap's [cout][cin] matrix per block, transposed through LDS so
+// that both the reads (cin contiguous) and the writes (cout contiguous) are coalesced; the block finds its layer in
+// the tile prefix of the descriptor table
+__global__ __launch_bounds__(256) void weight_to_dgrad_batched_kernel(const RelayoutDesc* __restrict__ descs, int n,
+                                                                     const float* __restrict__ src, float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int64_t b = blockIdx.x;
+    int l = 0;
+    while (l + 1 < n && descs[l + 1].tile0 <= b) ++l;
+    const RelayoutDesc d = descs[l];
     const float* __restrict__ wf = src + d.src_off;
     float* __restrict__ wd = dst + d.dst_off;
-    const int64_t total = (int64_t)d.taps * d.cout * d.cin;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % d.cout);
-        int64_t t = i / d.cout;
-        const int ci = (int)(t % d.cin);
-        const int tp = (int)(t / d.cin);
-        const int ts = d.flip ? (d.taps - 1 - tp) : tp;
-        wd[i] = wf[((int64_t)ts * d.cout + co) * d.cin + ci];
+    const int tci = (d.cin + 31) / 32, tco = (d.cout + 31) / 32;
+    const int t = (int)(b - d.tile0);
+    const int tp = t / (tci * tco), r = t % (tci * tco);
+    const int bco = r / tci, bci = r % tci;
+    const int ts = d.flip ? (d.taps - 1 - tp) : tp;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = bco * 32 + ty + 8 * k, ci = bci * 32 + tx;
+        if (co < d.cout && ci < d.cin) tile[ty + 8 * k][tx] = wf[((int64_t)ts * d.cout + co) * d.cin + ci];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ci = bci * 32 + ty + 8 * k, co = bco * 32 + tx;
+        if (co < d.cout && ci < d.cin) wd[((int64_t)tp * d.cin + ci) * d.cout + co] = tile[tx][ty + 8 * k];
     }
 }
 __global__ void relu_bwd_kernel(float4* __restrict__ dA, const float4* __restrict__ Y, int64_t n4) {
@@ -1041,9 +1136,20 @@ void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, in
 void launch_head_fwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
                      const float* shift, const float* w, const float* b, int Cout, float* logits, float slope) {
     ProfScope ps(ctx, FAM_ELEMWISE, 2.0 * M * C * Cout, (double)M * C * 4 + (double)M * Cout * 4);
-    const int64_t threads = M * 16;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)cdiv(threads, kBlock)), dim3(kBlock), 0,
-                       ctx->stream, y, M, C, scale, shift, w, b, Cout, logits, slope);
+    const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scale) |
+                                      reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(w)) & 15);
+    if (vec) {
+        int L = 1;
+        while (L * 2 <= C / 4 && L < 16) L *= 2;
+        const unsigned blocks = (unsigned)cdiv(M * L, kBlock);
+#define RFI_HF(L_) hipLaunchKernelGGL(head_fwd_vec_kernel<L_>, dim3(blocks), dim3(kBlock), 0, ctx->stream, y, M, C, scale, shift, w, b, Cout, logits, slope)
+        if (L == 16) RFI_HF(16); else if (L == 8) RFI_HF(8); else if (L == 4) RFI_HF(4); else if (L == 2) RFI_HF(2); else RFI_HF(1);
+#undef RFI_HF
+    } else {
+        const int64_t threads = M * 16;
+        hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)cdiv(threads, kBlock)), dim3(kBlock), 0,
+                           ctx->stream, y, M, C, scale, shift, w, b, Cout, logits, slope);
+    }
     check_launch("head_fwd");
 }
 
@@ -1116,12 +1222,20 @@ size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
 void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
                      const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                      float* partial_ws, float* dw, float* db, float slope) {
-    ChanGeom g = geom_rows(M, C, false);   // the head kernel is one channel per lane
+    const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(da) |
+                                      reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+                                      reinterpret_cast<uintptr_t>(w)) & 15);
+    ChanGeom g = geom_rows(M, C, vec);     // scalar kernel: one channel per lane; vector kernel: four
     {
         ProfScope ps(ctx, FAM_ELEMWISE, 4.0 * M * C * Cout, (double)M * C * 8);
-        hipLaunchKernelGGL(head_bwd_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
-                           M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
-                           reinterpret_cast<double*>(partial_ws), slope);
+        if (vec)
+            hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
+                               M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
+                               reinterpret_cast<double*>(partial_ws), slope);
+        else
+            hipLaunchKernelGGL(head_bwd_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
+                               M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
+                               reinterpret_cast<double*>(partial_ws), slope);
         check_launch("head_bwd");
     }
     {
@@ -1166,11 +1280,20 @@ void launch_weight_to_dgrad(rfi_ctx* ctx, const float* wf, int taps, int Cout, i
                        taps, Cout, Cin, flip, wd);
     check_launch("weight_to_dgrad");
 }
+int64_t relayout_assign_tiles(RelayoutDesc* descs, int n) {
+    int64_t t = 0;
+    for (int i = 0; i < n; ++i) {
+        descs[i].tile0 = t;
+        t += (int64_t)descs[i].taps * ((descs[i].cout + 31) / 32) * ((descs[i].cin + 31) / 32);
+    }
+    return t;
+}
 void launch_weight_to_dgrad_batched(rfi_ctx* ctx, const RelayoutDesc* descs_dev, int n, const float* src,
-                                    float* dst, double total_bytes) {
+                                    float* dst, double total_bytes, int64_t total_tiles) {
+    RFI_REQUIRE(total_tiles > 0 && total_tiles < ((int64_t)1 << 31), "weight_to_dgrad_batched: bad tile count");
     ProfScope ps(ctx, FAM_ELEMWISE, 0, total_bytes);
-    hipLaunchKernelGGL(weight_to_dgrad_batched_kernel, dim3(64, n), dim3(kBlock), 0, ctx->stream, descs_dev, src,
-                       dst);
+    hipLaunchKernelGGL(weight_to_dgrad_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, ctx->stream, descs_dev, n,
+                       src, dst);
     check_launch("weight_to_dgrad_batched");
 }
 void launch_relu_bwd(rfi_ctx* ctx, float* dA, const float* Y, int64_t n) {

@@ -192,9 +192,12 @@ void launch_weight_to_dgrad(rfi_ctx* ctx, const float* wf, int taps, int Cout, i
 struct RelayoutDesc {          // one conv-like layer of launch_weight_to_dgrad_batched (float offsets)
     int64_t src_off, dst_off;
     int taps, cout, cin, flip;
+    int64_t tile0 = 0;         // first 32 x 32 transpose tile of this layer in the launch's grid (filled by relayout_assign_tiles)
 };
+// prefix of 32 x 32 tiles over the layers; returns the total (= gridDim.x of the batched launch)
+int64_t relayout_assign_tiles(RelayoutDesc* descs, int n);
 void launch_weight_to_dgrad_batched(rfi_ctx* ctx, const RelayoutDesc* descs_dev, int n, const float* src,
-                                    float* dst, double total_bytes);
+                                    float* dst, double total_bytes, int64_t total_tiles);
 void launch_u8_to_f32(rfi_ctx* ctx, const uint8_t* src, int64_t n, float* dst);
 // dst[m][0..cp) = src[m][0..c) followed by zeros (channel padding of the network input to a multiple of 4)
 // dA[i] = Y[i] > 0 ? dA[i] : 0  (backward of a BN-less Conv -> ReLU; n % 4 == 0)

@@ -344,13 +344,14 @@ void rfi_model::refresh_dgrad_weights() {
             relayout_bytes += 8.0 * 4 * u.cout * u.cin;
         }
         relayout_n = (int)h.size();
+        relayout_tiles = relayout_assign_tiles(h.data(), relayout_n);
         relayout_descs = ctx->alloc(h.size() * sizeof(RelayoutDesc));
         RFI_CHECK_HIP(hipMemcpyAsync(relayout_descs, h.data(), h.size() * sizeof(RelayoutDesc),
                                      hipMemcpyHostToDevice, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // h goes out of scope
     }
     launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
-                                   wd_pool, relayout_bytes);
+                                   wd_pool, relayout_bytes, relayout_tiles);
     if (compute_x3) {     // pre-split records of both layouts of every conv-like layer (the kernels read them as is)
         if (!w3_pool) {
             size_t need = 0;

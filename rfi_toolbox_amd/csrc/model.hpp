@@ -119,6 +119,7 @@ struct rfi_model {
     bool x3_fresh = false;            // the 3 x bf16 records match the current parameters
     void* relayout_descs = nullptr;   // device table for the batched dgrad-layout rebuild
     int relayout_n = 0;
+    int64_t relayout_tiles = 0;
     double relayout_bytes = 0;
 
     // activations / workspaces for the prepared shape

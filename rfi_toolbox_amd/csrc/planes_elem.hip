@@ -59,10 +59,23 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
             for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? src[e] : 0.0f;
         }
         if (scale) {
+            float sc[8], sh[8];
+            if (VEC && c0 + 8 <= C) {          // four 16-byte loads instead of sixteen dword gathers
+                const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c0), b = *reinterpret_cast<const f32x4*>(scale + c0 + 4);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(shift + c0), d = *reinterpret_cast<const f32x4*>(shift + c0 + 4);
+                sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+                sh[0] = c.x; sh[1] = c.y; sh[2] = c.z; sh[3] = c.w; sh[4] = d.x; sh[5] = d.y; sh[6] = d.z; sh[7] = d.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sc[e] = c0 + e < C ? scale[c0 + e] : 0.0f;
+                    sh[e] = c0 + e < C ? shift[c0 + e] : 0.0f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (c0 + e < C) {
-                    float t = v[e] * scale[c0 + e] + shift[c0 + e];        // product and sum rounded separately (-ffp-contract=off)
+                    float t = v[e] * sc[e] + sh[e];                          // product and sum rounded separately (-ffp-contract=off)
                     if (relu) t = fmaxf(t, t * slope);                       // slope 0: ReLU
                     v[e] = t;
                 }
@@ -94,12 +107,20 @@ __global__ __launch_bounds__(256) void bn_relu_pool_planes_kernel(const float* _
         const int n = (int)(t / Hp);
         const int c0 = g * 8;
         float sc[8], sh[8], best[8];
+        if (vec && c0 + 8 <= C) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c0), b = *reinterpret_cast<const f32x4*>(scale + c0 + 4);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(shift + c0), d = *reinterpret_cast<const f32x4*>(shift + c0 + 4);
+            sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+            sh[0] = c.x; sh[1] = c.y; sh[2] = c.z; sh[3] = c.w; sh[4] = d.x; sh[5] = d.y; sh[6] = d.z; sh[7] = d.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sc[e] = c0 + e < C ? scale[c0 + e] : 0.0f;
-            sh[e] = c0 + e < C ? shift[c0 + e] : 0.0f;
-            best[e] = 0.0f;
+            for (int e = 0; e < 8; ++e) {
+                sc[e] = c0 + e < C ? scale[c0 + e] : 0.0f;
+                sh[e] = c0 + e < C ? shift[c0 + e] : 0.0f;
+            }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t pix = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
@@ -232,7 +253,7 @@ void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, in
 
 void launch_weights_to_wb(rfi_ctx* ctx, const WBDesc* descs_dev, int n, double total_bytes) {
     ProfScope ps(ctx, FAM_ELEMWISE, 0, total_bytes);
-    hipLaunchKernelGGL(weights_to_wb_kernel, dim3(64, n), dim3(256), 0, ctx->stream, descs_dev);
+    hipLaunchKernelGGL(weights_to_wb_kernel, dim3(512, n), dim3(256), 0, ctx->stream, descs_dev);    // (grid-stride loops: small layers leave most of the row idle)
     check_launch("weights_to_wb");
 }
 void launch_weights_to_wb_one(rfi_ctx* ctx, const WBDesc& d) {
