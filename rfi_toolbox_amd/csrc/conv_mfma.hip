@@ -429,8 +429,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                             s_ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[mt][nt][r];
                         const int g4 = (lane & 7) * 4;                  // 4 channels of this lane
                         const int co = co0 + g4;
+                        // folded convT phases: channel co of the GEMM is channel cc of output phase zf (fold % 4 == 0,
+                        // so a lane's four channels share the phase)
+                        const int zf = a.fold ? co / a.fold : 0;
+                        const int cc = a.fold ? co - zf * a.fold : co;
+                        const int ooy_l = a.fold ? (zf >> 1) : ooy, oox_l = a.fold ? (zf & 1) : oox;
                         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-                        if (a.bias && co < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+                        if (a.bias && co < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + cc);
                         // BatchNorm-backward sums of the layer whose activated output this tensor is the gradient of
                         f32x4 bsc = b4, bsh = b4, bmu = b4, bis = b4;
                         if (st_out && a.bwd_y && co < a.Cout) {
@@ -445,9 +450,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                             const f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pp * 36 + g4) + b4;
                             const int oy = oyb + pp / TW, ox = ctile.ox0 + pp % TW;
                             if (co < a.Cout && oy < a.H && ox < a.W) {
-                                const unsigned off = (unsigned)(((ctile.n * a.Hout + oy * a.osy + ooy) * a.Wout + ox * a.osx + oox) *
-                                                                a.y.pstride + co);
-                                *reinterpret_cast<f32x4*>(a.y.p + off) = v;
+                                const unsigned off = (unsigned)(((ctile.n * a.Hout + oy * a.osy + ooy_l) * a.Wout + ox * a.osx + oox_l) *
+                                                                a.y.pstride + cc);
+                                if (a.y16) {                            // bf16 output (RNE), 8 bytes per lane
+                                    const __bf16 q0 = (__bf16)v[0], q1 = (__bf16)v[1], q2 = (__bf16)v[2], q3 = (__bf16)v[3];
+                                    u32x2 pk;
+                                    pk[0] = (unsigned)__builtin_bit_cast(unsigned short, q0) | ((unsigned)__builtin_bit_cast(unsigned short, q1) << 16);
+                                    pk[1] = (unsigned)__builtin_bit_cast(unsigned short, q2) | ((unsigned)__builtin_bit_cast(unsigned short, q3) << 16);
+                                    *reinterpret_cast<u32x2*>(a.y16 + off) = pk;
+                                } else {
+                                    *reinterpret_cast<f32x4*>(a.y.p + off) = v;
+                                }
                                 if (st_out) {
                                     if (a.bwd_y) {
                                         const f32x4 yv = *reinterpret_cast<const f32x4*>(a.bwd_y + off);
@@ -618,6 +631,15 @@ void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
 // 128x32): twice the MFMAs between barriers and half the filter staging per output.
 template <int R, int S>
 void dispatch_tiles(rfi_ctx* ctx, ConvArgs& a) {
+    if constexpr (R == 1) {
+        // transposed conv with its four phases folded into the channels (a GEMM: K = Cin, N = 4 Cout): one staged
+        // input chunk feeds a 128-channel tile, i.e. 2-4x the MFMAs per barrier of the per-phase launches
+        if (a.fold && a.Cout >= 128) {
+            if (a.W >= 32) return launch_cfg<R, S, 4, 32, 128, 2, 2>(ctx, a);
+            if (a.W >= 16) return launch_cfg<R, S, 8, 16, 128, 2, 2>(ctx, a);
+            return launch_cfg<R, S, 8, 8, 128, 1, 4>(ctx, a);
+        }
+    }
     const int ychunks64 = (int)cdiv(a.Cout, 64) * a.zgroups;
     auto big_ok = [&](int th, int tw, int ych) {
         return (int64_t)a.N * cdiv(a.H, th) * cdiv(a.W, tw) * ych >= 512;
@@ -747,6 +769,7 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     const bool ok = conv_mfma_eligible(a);
     if (impl == IMPL_MFMA) RFI_REQUIRE(ok, "conv: shape/alignment not eligible for the MFMA kernel");
     if (impl == IMPL_DIRECT || !ok) {
+        RFI_REQUIRE(!a.y16, "conv: bfloat16 output needs the MFMA kernel");
         launch_conv_direct(ctx, a);
         return;
     }
@@ -778,9 +801,21 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
                 std::to_string(a.Cout) + (a.xf.scale ? " xf" : "") + (a.zgroups > 1 ? " z4" : "") +
                 (a.bf16 ? " bf16" : "") + (a.bf16x3 ? " 3xbf16" : "");
     // algorithmic HBM bytes: every input, output and filter element once (float32 tensors)
-    const double bytes = 4.0 * ((double)a.N * a.Hin * a.Win * a.Cin + (double)a.N * a.H * a.W * a.zgroups * a.Cout +
-                                (double)a.R * a.R * a.zgroups * a.Cin * a.Cout);
+    const double bytes = 4.0 * ((double)a.N * a.Hin * a.Win * a.Cin + (double)a.R * a.R * a.zgroups * a.Cin * a.Cout) +
+                         (a.y16 ? 2.0 : 4.0) * a.N * a.H * a.W * a.zgroups * a.Cout;
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, bytes, label);
+    static const bool no_fold = getenv("RFI_NO_CONVT_FOLD") != nullptr;          // A/B runs
+    const bool y_ok = a.y16 ? (reinterpret_cast<uintptr_t>(a.y16) & 7) == 0 : (reinterpret_cast<uintptr_t>(a.y.p) & 15) == 0;
+    RFI_REQUIRE(!a.y16 || (a.R == 1 && a.zgroups == 4 && (a.Cout & 3) == 0 && (a.y.pstride & 3) == 0 && y_ok && !a.stats),
+                "conv: bfloat16 output exists for the folded transposed convolution only (Cout % 4 == 0, aligned output)");
+    if (a.R == 1 && a.zgroups == 4 && (!no_fold || a.y16) && (a.Cout & 3) == 0 && (a.y.pstride & 3) == 0 && y_ok && !a.stats) {
+        ConvArgs f = a;                 // [4][Cout][Cin] filters (and their 3 x bf16 records) ARE [4 Cout][Cin]
+        f.fold = a.Cout;
+        f.Cout = 4 * a.Cout;
+        f.zgroups = 1;
+        dispatch_tiles<1, 1>(ctx, f);
+        return;
+    }
     if (a.R == 3) dispatch_tiles<3, 1>(ctx, a);
     else if (a.R == 1) dispatch_tiles<1, 1>(ctx, a);
     else if (a.S == 1) dispatch_tiles<2, 1>(ctx, a);

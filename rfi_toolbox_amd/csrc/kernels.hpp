@@ -51,6 +51,10 @@ struct ConvArgs {
     int ooy = 0, oox = 0;
     int R = 3, S = 1, pad = 1;
     int zgroups = 1;                  // convT fwd: 4 (a,b) groups: w += z*Cout*Cin, (ooy,oox) = (z/2, z%2)
+    unsigned short* y16 = nullptr;    // convT forward only: write the output as bfloat16 NHWC (a P = 1 plane tensor, planes.hpp)
+                                      // instead of float32; y.pstride then counts bf16 elements of that tensor, y.p is unused
+    int fold = 0;                     // > 0 (set by launch_conv): the four convT phases folded into the channel dimension --
+                                      // Cout = 4 * fold, output channel co belongs to phase z = co / fold, channel co % fold
     InXform xf;
     double algo_flops = -1;           // algorithmic FLOPs for the profile (default: from the shape)
     bool bf16 = false;                // MFMA kernels: operands rounded to bf16 in registers, fp32 accumulate

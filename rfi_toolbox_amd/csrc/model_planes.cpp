@@ -206,7 +206,6 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
         a.w = params + u.w_off;
         a.w3 = compute_x3 ? u.w3 : nullptr;
         a.bias = params + u.b_off;
-        a.y = MutView{buf(upf[l]), u.cout};
         a.Hout = s.H; a.Wout = s.W;
         a.osy = 2; a.osx = 2;
         a.R = 1; a.S = 1; a.pad = 0;
@@ -214,9 +213,19 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
         a.xf = bn_xf(*prevBN);
         a.bf16 = compute_bf16;
         a.bf16x3 = compute_x3;
+        // bf16 data flow with whole 16-channel chunks: the kernel writes the up-conv output as the bf16 operand of the
+        // decoder's first conv directly; otherwise float32 + one conversion pass (which also zero-fills chunk padding)
+        const bool direct = P == 1 && u.cout % 16 == 0 && conv_mfma_eligible(a) && pl[pUp[l]].pstride % 4 == 0;
+        if (direct) {
+            a.y16 = pl[pUp[l]].p;
+            a.y = MutView{nullptr, (int)pl[pUp[l]].pstride};
+        } else {
+            a.y = MutView{buf(upf[l]), u.cout};
+        }
         launch_conv(ctx, a);
         const int64_t M = (int64_t)s.N * s.H * s.W;
-        launch_act_split(ctx, View{buf(upf[l]), u.cout}, M, u.cout, InXform{}, P, pl[pUp[l]].p, pl[pUp[l]].pstride);
+        if (!direct)
+            launch_act_split(ctx, View{buf(upf[l]), u.cout}, M, u.cout, InXform{}, P, pl[pUp[l]].p, pl[pUp[l]].pstride);
         ConvBN& c1 = convs[2 * D + 2 + 2 * k];
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};      // cat([up, skip], dim=1) as two K-segments
