@@ -449,6 +449,71 @@ __global__ void pool_bwd_merge_kernel(const float* __restrict__ y, int N, int H,
             da[pixk[k] * C + c] = dskip[pixk[k] * dskip_ps + c] + (k == arg ? g : 0.0f);
     }
 }
+// the same pass, also leaving the BatchNorm-backward sums of the layer whose activated output da is the gradient of
+// (sum dz, sum dz * xhat per channel; what bn_bwd_reduce would re-read da and y for): the grid is chosen so that a
+// thread keeps ONE channel over its grid-stride iterations; fp64 per thread, fixed-order LDS fold per block, one
+// record per block (C <= 256) or per group of C / 256 blocks
+__global__ __launch_bounds__(256) void pool_bwd_merge_sums_kernel(
+    const float* __restrict__ y, int N, int H, int W, int C, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dskip, int dskip_ps,
+    const float* __restrict__ dpool, float* __restrict__ da, float slope, double* __restrict__ records) {
+    __shared__ double red[2][kBlock];
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int64_t total = (int64_t)N * Hp * Wp * C;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(first % C);                 // (gridDim.x * 256) % C == 0: the same for every iteration
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i / C;
+        const int px = (int)(t % Wp);
+        t /= Wp;
+        const int py = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        float best = 0.0f, yv[4], zv[4];
+        int arg = 0;
+        int64_t pixk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pixk[k] = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
+            yv[k] = y[pixk[k] * C + c];
+            zv[k] = yv[k] * sc + sh;
+            const float a = act_f(zv[k], slope);
+            if (k == 0 || a > best) {
+                best = a;
+                arg = k;
+            }
+        }
+        const float g = dpool[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = dskip[pixk[k] * dskip_ps + c] + (k == arg ? g : 0.0f);
+            da[pixk[k] * C + c] = d;
+            const float dz = dact_f(zv[k], d, slope);
+            const float xh = (yv[k] - mu) * is;
+            s1 += (double)dz;
+            s2 += (double)dz * (double)xh;
+        }
+    }
+    if (C <= kBlock) {                              // 256 % C == 0: threads c, c + C, ... hold channel c
+        red[0][threadIdx.x] = s1;
+        red[1][threadIdx.x] = s2;
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int k = threadIdx.x; k < kBlock; k += C) {
+                t1 += red[0][k];
+                t2 += red[1][k];
+            }
+            records[((int64_t)blockIdx.x * C + c) * 2 + 0] = t1;
+            records[((int64_t)blockIdx.x * C + c) * 2 + 1] = t2;
+        }
+    } else {                                        // C % 256 == 0: C / 256 consecutive blocks make one record
+        const int per = C / kBlock;
+        records[((int64_t)(blockIdx.x / per) * C + c) * 2 + 0] = s1;
+        records[((int64_t)(blockIdx.x / per) * C + c) * 2 + 1] = s2;
+    }
+}
 
 __global__ void copy_edge_kernel(int N, int H, int W, int C, const float* __restrict__ dskip,
                                  int dskip_ps, float* __restrict__ da) {
@@ -719,7 +784,11 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
                                                            int64_t rows_per_block, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ w, int Cout,
                                                            const float* __restrict__ dl, float* __restrict__ da,
-                                                           double* __restrict__ partial, float slope) {
+                                                           double* __restrict__ partial, float slope,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           double* __restrict__ bn_records) {
+    // bn_records != null (Cout == 1): also the BatchNorm-backward sums of the layer below (sum dz, sum dz * xhat with
+    // dz = da * act'), one fp64 record per row block -- bn_bwd_reduce's pass over da and y disappears
     __shared__ double red[4 * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -728,11 +797,13 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     const int64_t pstride = (int64_t)Cout * C + Cout;
+    double q1[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0};
     for (int o = 0; o < Cout; ++o) {
         double sw[4] = {0, 0, 0, 0}, sb = 0;
         if (c < C) {
-            float sc[4], sh[4], wv[4];
+            float sc[4], sh[4], wv[4], mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
             ldv<4>(scale + c, sc); ldv<4>(shift + c, sh); ldv<4>(w + (int64_t)o * C + c, wv);
+            if (bn_records) { ldv<4>(mean + c, mu); ldv<4>(invstd + c, is); }
             for (int64_t r = r0 + rl; r < r1; r += RL) {
                 const float d = dl[r * Cout + o];
                 float yv[4], g[4];
@@ -740,9 +811,16 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
                 if (o != 0) ldv<4>(da + r * C + c, g);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const float a = act_f(yv[v] * sc[v] + sh[v], slope);
+                    const float z = yv[v] * sc[v] + sh[v];
+                    const float a = act_f(z, slope);
                     sw[v] += (double)d * (double)a;
                     g[v] = o == 0 ? d * wv[v] : g[v] + d * wv[v];
+                    if (bn_records) {
+                        const float dz = dact_f(z, g[v], slope);
+                        const float xh = (yv[v] - mu[v]) * is[v];
+                        q1[v] += (double)dz;
+                        q2[v] += (double)dz * (double)xh;
+                    }
                 }
                 sb += (double)d;
                 stv<4>(da + r * C + c, g);
@@ -768,6 +846,23 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
             partial[(int64_t)blockIdx.x * pstride + (int64_t)Cout * C + o] = t;
         }
         __syncthreads();
+    }
+    if (bn_records) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[v * kBlock + threadIdx.x] = q == 0 ? q1[v] : q2[v];
+            __syncthreads();
+            if (rl == 0 && c < C) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    double t = q == 0 ? q1[v] : q2[v];
+                    for (int k = 1; k < RL; ++k) t += red[v * kBlock + k * CL + cl];
+                    bn_records[((int64_t)blockIdx.x * C + c + v) * 2 + q] = t;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1115,6 +1210,29 @@ void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int 
     }
 }
 
+int launch_pool_bwd_merge_sums(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, View dskip, const float* dpool,
+                               float* da, float slope, float* partial_ws) {
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    const bool small = C <= kBlock && kBlock % C == 0, wide = C > kBlock && C % kBlock == 0;
+    if ((H & 1) || (W & 1) || !(small || wide) || total < (int64_t)kBlock * 64) return 0;      // caller: separate reduction
+    int grid = grid_for(total, kMaxRowBlocks);
+    int records = grid;
+    if (wide) {
+        const int per = C / kBlock;
+        grid = std::max(per, grid / per * per);
+        if ((int64_t)grid * kBlock > total) return 0;
+        records = grid / per;
+    } else if ((int64_t)grid * kBlock > total) {
+        return 0;                                   // (every thread must own at least one element)
+    }
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 12 + (double)total * 4);
+    hipLaunchKernelGGL(pool_bwd_merge_sums_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, y, N, H, W, C, scale, shift, mean,
+                       invstd, dskip.p, dskip.pstride, dpool, da, slope, reinterpret_cast<double*>(partial_ws));
+    check_launch("pool_bwd_merge_sums");
+    return records;
+}
+
 void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
                            const float* scale, const float* shift, View dskip, const float* dpool,
                            float* da, float slope) {
@@ -1219,19 +1337,26 @@ size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
     (void)M;
     return (size_t)kMaxRowBlocks * ((size_t)Cout * C + Cout) * 2;
 }
-void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
-                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
-                     float* partial_ws, float* dw, float* db, float slope) {
+int launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
+                    const float* shift, const float* w, int Cout, const float* dlogits, float* da,
+                    float* partial_ws, float* dw, float* db, float slope, const float* bn_mean, const float* bn_invstd,
+                    float* bn_records_ws) {
+    int bn_records = 0;
     const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(da) |
                                       reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
                                       reinterpret_cast<uintptr_t>(w)) & 15);
     ChanGeom g = geom_rows(M, C, vec);     // scalar kernel: one channel per lane; vector kernel: four
     {
         ProfScope ps(ctx, FAM_ELEMWISE, 4.0 * M * C * Cout, (double)M * C * 8);
-        if (vec)
+        if (vec) {
+            const bool sums = bn_records_ws && bn_mean && bn_invstd && Cout == 1 &&
+                              !((reinterpret_cast<uintptr_t>(bn_mean) | reinterpret_cast<uintptr_t>(bn_invstd)) & 15);
             hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
                                M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
-                               reinterpret_cast<double*>(partial_ws), slope);
+                               reinterpret_cast<double*>(partial_ws), slope, bn_mean, bn_invstd,
+                               sums ? reinterpret_cast<double*>(bn_records_ws) : nullptr);
+            if (sums) bn_records = g.rblocks;
+        }
         else
             hipLaunchKernelGGL(head_bwd_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
                                M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
@@ -1256,6 +1381,7 @@ void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float
                            g.rblocks, (int64_t)n, Cout, db);
         check_launch("head_bwd_finish_db");
     }
+    return bn_records;
 }
 
 void launch_nchw_to_nhwc(rfi_ctx* ctx, const float* src, int N, int C, int H, int W, float* dst) {

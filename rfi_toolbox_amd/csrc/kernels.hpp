@@ -158,6 +158,12 @@ void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int 
 void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
                            const float* scale, const float* shift, View dskip, const float* dpool,
                            float* da, float slope = 0.0f);
+// the same pass, also writing the BatchNorm-backward sums of that layer (sum dz, sum dz * xhat) as fp64 records into
+// partial_ws (bn_bwd_ws_floats) for launch_bn_bwd_finalize_records; returns the record count, or 0 when the shape does
+// not fit the scheme (nothing launched: call launch_pool_bwd_merge and the separate reduction instead)
+int launch_pool_bwd_merge_sums(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, View dskip, const float* dpool,
+                               float* da, float slope, float* partial_ws);
 // logits[m,o] = b[o] + sum_c relu(y*scale+shift)[m,c] * w[o][c]
 void launch_head_fwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
                      const float* shift, const float* w, const float* b, int Cout, float* logits,
@@ -179,9 +185,13 @@ void launch_focal_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, 
                       float gamma, float* dlogits);
 // head backward: da[m,c] = sum_o dlogits[m,o]*w[o][c] (NOT yet relu-masked: bn_bwd does that);
 // dw[o][c] = sum_m dlogits[m,o]*act[m,c]; db[o] = sum_m dlogits[m,o]
-void launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
-                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
-                     float* partial_ws, float* dw, float* db, float slope = 0.0f);
+// bn_records_ws != null (+ the layer's batch mean / invstd): where the shape allows (Cout == 1, C % 4 == 0) the same pass
+// leaves the BatchNorm-backward sums of the layer as fp64 records there (bn_bwd_ws_floats; a region DISJOINT from
+// partial_ws) and returns their count for launch_bn_bwd_finalize_records; 0: not produced
+int launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
+                    const float* shift, const float* w, int Cout, const float* dlogits, float* da,
+                    float* partial_ws, float* dw, float* db, float slope = 0.0f, const float* bn_mean = nullptr,
+                    const float* bn_invstd = nullptr, float* bn_records_ws = nullptr);
 size_t head_bwd_ws_floats(int64_t M, int C, int Cout);
 // per-channel sum over pixels of a view (convT bias grad)
 void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out);

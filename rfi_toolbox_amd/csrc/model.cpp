@@ -291,7 +291,7 @@ void rfi_model::prepare(int n, int h, int w) {
     size_t cmax = (size_t)feat << depth;
     upd_red(bn_stats_ws_floats((int)cmax));
     upd_red(bn_bwd_ws_floats(M1, (int)cmax));
-    upd_red(head_bwd_ws_floats(M1, feat, out_ch));
+    upd_red(head_bwd_ws_floats(M1, feat, out_ch) + bn_bwd_ws_floats(M1, feat));   // (+ the BN-backward records head_bwd leaves)
     upd_red(channel_sum_ws_floats(M1, (int)cmax));
     upd_red(loss_ws_doubles(M1) * 2);
     upd_red(sumsq_ws_doubles(n_flat) * 2);
@@ -675,14 +675,17 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     else
         launch_loss_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, d_sums, buf(dlogits));
     if (head_sigmoid) launch_sigmoid_bwd(ctx, buf(probs), M1 * out_ch, buf(dlogits));
+    int head_records = 0;
     {
         ConvBN& last = convs[IB + 2 + 2 * (D - 1) + 1];
-        launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off,
-                        out_ch, buf(dlogits), buf(gA[1]), buf(ws_red), grads + head_w_off,
-                        grads + head_b_off, act_slope);
+        // (head partials behind the region where the next layer expects its BatchNorm-backward records)
+        head_records = launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off,
+                                       out_ch, buf(dlogits), buf(gA[1]), buf(ws_red) + bn_bwd_ws_floats(M1, feat),
+                                       grads + head_w_off, grads + head_b_off, act_slope, last.mean(), last.invstd(),
+                                       buf(ws_red));
     }
     // decoders, shallow to deep
-    int pending_records = 0;          // BatchNorm-backward records a producing kernel left for the next layer
+    int pending_records = head_records;   // BatchNorm-backward records a producing kernel left for the next layer
     for (int l = 1; l <= D; ++l) {
         const int k = D - l;
         Shape s{n, h >> (l - 1), w >> (l - 1)};
@@ -767,10 +770,16 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
-        launch_pool_bwd_merge(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
-                              View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
+        // max-pool routing + skip gradient, with the BatchNorm-backward sums of c2 from the same pass where the
+        // shape allows (else the separate reduction inside backward_conv_bn)
+        int have = launch_pool_bwd_merge_sums(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), c2.mean(),
+                                              c2.invstd(), View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]),
+                                              buf(gA[l]), act_slope, buf(ws_red));
+        if (!have)
+            launch_pool_bwd_merge(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
+                                  View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
         int rec = backward_conv_bn(this, c2, buf(gA[l]), buf(encY2[l]), View{buf(encY1[l]), c1.cout}, bn_xf(c1), s,
-                                   buf(gB[l]), 0, &c1, buf(encY1[l]));
+                                   buf(gB[l]), have, &c1, buf(encY1[l]));
         View in = (l == 1) ? (c1.cin_p == in_ch ? View{x_dev, in_ch} : View{buf(x_pad), c1.cin_p})
                            : View{buf(pool[l - 1]), c1.cin};
         backward_conv_bn(this, c1, buf(gB[l]), buf(encY1[l]), in, InXform{}, s,

@@ -252,12 +252,15 @@ struct SideScopeP {
 // dA: gradient w.r.t. the ACTIVATED output of conv c (float32, left untouched).  Writes dW / db / dgamma / dbeta
 // and, if dx != null, the gradient w.r.t. the conv's input (float32 raw, `cin` channels per pixel).
 void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, const float* Y, const PlaneSeg* in, int nseg, Shape s,
-                       float* dx, PlaneBuf& dYp) {
+                       float* dx, PlaneBuf& dYp, int have_records = 0) {
     rfi_ctx* ctx = m->ctx;
     const int64_t M = (int64_t)s.N * s.H * s.W;
     float* ws = m->buf(m->ws_red);
-    launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(), c.c2(),
-                         m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
+    if (have_records > 0)           // the kernel that produced dA left the BatchNorm-backward sums in the workspace
+        launch_bn_bwd_finalize_records(ctx, ws, have_records, M, c.cout, c.c1(), c.c2(), m->grads + c.g_off, m->grads + c.be_off);
+    else
+        launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(), c.c2(),
+                             m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
     launch_bn_bwd_apply(ctx, const_cast<float*>(dA), Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
                         m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope, dYp.p, dYp.pstride,
                         m->planesP);
@@ -308,10 +311,12 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     else
         launch_loss_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, d_sums, buf(dlogits));
     if (head_sigmoid) launch_sigmoid_bwd(ctx, buf(probs), M1 * out_ch, buf(dlogits));
+    int head_records = 0;
     {
         ConvBN& last = convs[2 * D + 2 + 2 * (D - 1) + 1];
-        launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off, out_ch,
-                        buf(dlogits), buf(gA[1]), buf(ws_red), grads + head_w_off, grads + head_b_off, act_slope);
+        head_records = launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off, out_ch,
+                                       buf(dlogits), buf(gA[1]), buf(ws_red) + bn_bwd_ws_floats(M1, feat), grads + head_w_off,
+                                       grads + head_b_off, act_slope, last.mean(), last.invstd(), buf(ws_red));
     }
     for (int l = 1; l <= D; ++l) {                // decoders, shallow to deep
         const int k = D - l;
@@ -321,7 +326,7 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         const PlaneSeg a1 = seg_of(pl[pA1d[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), buf(decY2[l]), &a1, 1, s, buf(gB[l]), pl[pdYa[l]]);
+        backward_pconv_bn(this, c2, buf(gA[l]), buf(decY2[l]), &a1, 1, s, buf(gB[l]), pl[pdYa[l]], l == 1 ? head_records : 0);
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};
         backward_pconv_bn(this, c1, buf(gB[l]), buf(decY1[l]), in2, 2, s, buf(dconcat[l]), pl[pdYb[l]]);
         // ConvTranspose: dUp = dconcat[..., 0:C]; the round-1 kernels on float32 tensors
@@ -374,10 +379,14 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
-        launch_pool_bwd_merge(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
-                              View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
+        const int have = launch_pool_bwd_merge_sums(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), c2.mean(),
+                                                    c2.invstd(), View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]),
+                                                    buf(gA[l]), act_slope, buf(ws_red));
+        if (!have)
+            launch_pool_bwd_merge(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
+                                  View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
         const PlaneSeg a1 = seg_of(pl[pA1e[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), buf(encY2[l]), &a1, 1, s, buf(gB[l]), pl[pdYa[l]]);
+        backward_pconv_bn(this, c2, buf(gA[l]), buf(encY2[l]), &a1, 1, s, buf(gB[l]), pl[pdYa[l]], have);
         const PlaneSeg in = seg_of(l == 1 ? pl[pXin] : pl[pPool[l - 1]]);
         backward_pconv_bn(this, c1, buf(gB[l]), buf(encY1[l]), &in, 1, s, (l == 1) ? nullptr : buf(dpool[l - 1]), pl[pdYb[l]]);
         bucket_ready(c1.w_off, convs[2 * l].w_off);
