@@ -206,7 +206,8 @@ class _ConvBF16(torch.autograd.Function):
     def forward(ctx, x, w, b, padding):
         ctx.save_for_backward(x, w)
         ctx.padding = padding
-        return F.conv2d(_bf(x), _bf(w), b, padding=padding)
+        y = F.conv2d(_bf(x), _bf(w), b, padding=padding)
+        return _bf(y) if _BF16_ROUND_OUTPUTS else y       # (straight-through: the gradient passes unchanged)
 
     @staticmethod
     def backward(ctx, dy):
@@ -233,18 +234,26 @@ class _ConvT2x2BF16(torch.autograd.Function):
 
 
 _BF16_OPERANDS = False
+_BF16_ROUND_OUTPUTS = False
 
 
 class bf16_operands:
-    """``with unet_ref.bf16_operands(): ...`` -- forward/backward of the oracle in the bf16-operand arithmetic."""
+    """``with unet_ref.bf16_operands(): ...`` -- forward/backward of the oracle in the bf16-operand arithmetic.
+    ``round_outputs=True``: every 3x3 conv output (conv + bias, before BatchNorm) is additionally rounded to bfloat16,
+    as torch.autocast does (its conv outputs ARE bf16 tensors) and as the HIP library's bf16 data flow does, which
+    stores them as bf16; BatchNorm statistics are then those of the rounded values."""
+
+    def __init__(self, round_outputs=False):
+        self.round_outputs = bool(round_outputs)
 
     def __enter__(self):
-        global _BF16_OPERANDS
-        self.prev, _BF16_OPERANDS = _BF16_OPERANDS, True
+        global _BF16_OPERANDS, _BF16_ROUND_OUTPUTS
+        self.prev = (_BF16_OPERANDS, _BF16_ROUND_OUTPUTS)
+        _BF16_OPERANDS, _BF16_ROUND_OUTPUTS = True, self.round_outputs
 
     def __exit__(self, *exc):
-        global _BF16_OPERANDS
-        _BF16_OPERANDS = self.prev
+        global _BF16_OPERANDS, _BF16_ROUND_OUTPUTS
+        _BF16_OPERANDS, _BF16_ROUND_OUTPUTS = self.prev
 
 
 def _conv3x3(x, w, b):

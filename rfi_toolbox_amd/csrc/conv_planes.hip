@@ -31,6 +31,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][mt][nt][r] = 0.0f;
 
-    const bool vec_out = (a.Cout & 3) == 0 && (a.y_pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+    const bool vec_out = (a.Cout & 3) == 0 && (a.y_pstride & 3) == 0 &&
+                         (a.y16 ? (reinterpret_cast<uintptr_t>(a.y16) & 7) == 0 : (reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
     // the bias of this lane's output channels, loaded ONCE: an ordinary global load inside the loop would make
     // the compiler drain the whole vector-memory queue (DMA prefetch and output stores included) at its use
     f32x4 bias4[NTL];
@@ -250,12 +252,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                         for (int ps = 0; ps < 2; ++ps) {
                             const int pl = ps * 8 + (lane >> 3);
                             const int pp = half * 16 + pl;
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pl * 36 + g4) + b4;
+                            f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pl * 36 + g4) + b4;
                             const int oy = oyb + pp / TW, ox = oxb + pp % TW;
                             if (co < a.Cout && oy < a.H && ox < a.W) {
-                                *reinterpret_cast<f32x4*>(
-                                    a.y + (unsigned)(((ct.n * a.Hout + oy * a.osy + a.ooy) * a.Wout + ox * a.osx + a.oox) *
-                                                         a.y_pstride + co)) = v;
+                                const unsigned off = (unsigned)(((ct.n * a.Hout + oy * a.osy + a.ooy) * a.Wout + ox * a.osx + a.oox) *
+                                                                a.y_pstride + co);
+                                if (a.y16 || a.round_y) {               // the tensor holds bf16 values (RNE; NaN stays NaN)
+                                    unsigned short q[4];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const __bf16 h = (__bf16)v[e];
+                                        q[e] = __builtin_bit_cast(unsigned short, h);
+                                        v[e] = (float)h;
+                                    }
+                                    if (a.y16) {
+                                        u32x2 pk;
+                                        pk[0] = (unsigned)q[0] | ((unsigned)q[1] << 16);
+                                        pk[1] = (unsigned)q[2] | ((unsigned)q[3] << 16);
+                                        *reinterpret_cast<u32x2*>(a.y16 + off) = pk;
+                                    }
+                                }
+                                if (!a.y16) *reinterpret_cast<f32x4*>(a.y + off) = v;
                                 if (st_out) {
                                     p1 += v;
                                     p2 += v * v;
@@ -429,7 +446,9 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
     const int per = (int)cdiv(tx, std::max(1, gmax / 8));
     int GX = 8 * (int)cdiv(tx, per);
     if (ntiles < 8) GX = ntiles;
-    const bool vec_out = (a.Cout & 3) == 0 && (a.y_pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+    const bool vec_out = (a.Cout & 3) == 0 && (a.y_pstride & 3) == 0 &&
+                         (a.y16 ? (reinterpret_cast<uintptr_t>(a.y16) & 7) == 0 : (reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+    RFI_REQUIRE(vec_out || !(a.y16 || a.round_y), "pconv: bf16 output needs Cout % 4 == 0 and an aligned tensor");
     if (a.stats && vec_out && GX <= a.stats_max_records) a.stats_records = GX;
     else { a.stats = nullptr; a.stats_records = 0; }
     static PerDeviceOnce attr_once;
@@ -505,7 +524,7 @@ void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
         label = "pconv N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" + std::to_string(a.W) + " k" +
                 std::to_string(d.nkc * 16) + "->" + std::to_string(a.Cout) + (a.P == 3 ? " 3xbf16" : " bf16");
     // algorithmic HBM bytes: the plane input (2 P bytes per value), the float32 output, the filters
-    const double bytes = (double)a.N * a.Hin * a.Win * d.nkc * 16.0 * 2 * a.P + 4.0 * a.N * a.H * a.W * a.Cout +
+    const double bytes = (double)a.N * a.Hin * a.Win * d.nkc * 16.0 * 2 * a.P + (a.y16 ? 2.0 : 4.0) * a.N * a.H * a.W * a.Cout +
                          (double)wbytes;
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, bytes, label);
     if (a.P == 3) dispatch<3>(ctx, d);

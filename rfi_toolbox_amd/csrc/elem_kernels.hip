@@ -79,6 +79,27 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[V]) {
     if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     else p[0] = v[0];
 }
+// V channels of the raw conv output Y at element index idx: float32 or (y16) bfloat16 (kernels.hpp, YRef)
+template <int V>
+__device__ __forceinline__ void ldy(const void* y, int y16, int64_t idx, float (&v)[V]) {
+    if (y16) {
+        const unsigned short* q = static_cast<const unsigned short*>(y) + idx;
+        if constexpr (V == 4) {
+            const uint2 t = *reinterpret_cast<const uint2*>(q);
+            v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+            v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+        } else {
+            v[0] = __builtin_bit_cast(float, (unsigned)q[0] << 16);
+        }
+    } else {
+        ldv<V>(static_cast<const float*>(y) + idx, v);
+    }
+}
+__device__ __forceinline__ float ldy1(const void* y, int y16, int64_t idx) {
+    float v[1];
+    ldy<1>(y, y16, idx, v);
+    return v[0];
+}
 // block-level sum over the RL row lanes of NQ per-lane quantities of V channels each;
 // lane rl == 0 ends up with the totals in acc.  red: NQ * V * 256 doubles of LDS.
 template <int V, int NQ>
@@ -202,7 +223,7 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
 // ------------------------------------------------------------------ batch-norm backward
 // partial[(rb*C+c)*2 + {0,1}] = sum dz, sum dz*xhat;  dz = da * (y*scale+shift > 0)
 template <int V>
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ y,
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const void* __restrict__ y, int y16, int64_t yps,
                                      int64_t M, int C, int CL, int64_t rows_per_block,
                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -222,7 +243,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* 
         ldv<V>(scale + c, sc); ldv<V>(shift + c, sh); ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             float yv[V], dv[V];
-            ldv<V>(y + r * C + c, yv);
+            ldy<V>(y, y16, r * yps + c, yv);
             ldv<V>(da + r * C + c, dv);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
@@ -268,7 +289,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int r
 
 // in place: da <- dy;  partial[rb*C+c] = sum dy (double)
 template <int V>
-__global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restrict__ y, int64_t M,
+__global__ void bn_bwd_apply_kernel(float* __restrict__ da, const void* __restrict__ y, int y16, int64_t yps, int64_t M,
                                     int C, int CL, int64_t rows_per_block,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -293,7 +314,7 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const float* __restr
         for (int v = 0; v < V; ++v) g[v] = g[v] * is[v];
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             float yv[V], dv[V], o[V];
-            ldv<V>(y + r * C + c, yv);
+            ldy<V>(y, y16, r * yps + c, yv);
             ldv<V>(da + r * C + c, dv);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
@@ -415,7 +436,7 @@ __global__ void bn_relu_edge_kernel(const float* __restrict__ y, int N, int H, i
     }
 }
 
-__global__ void pool_bwd_merge_kernel(const float* __restrict__ y, int N, int H, int W, int C,
+__global__ void pool_bwd_merge_kernel(const void* __restrict__ y, int y16, int64_t yps, int N, int H, int W, int C,
                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                       const float* __restrict__ dskip, int dskip_ps,
                                       const float* __restrict__ dpool, float* __restrict__ da, float slope) {
@@ -436,7 +457,7 @@ __global__ void pool_bwd_merge_kernel(const float* __restrict__ y, int N, int H,
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             pixk[k] = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
-            float a = y[pixk[k] * C + c] * sc + sh;
+            float a = ldy1(y, y16, pixk[k] * yps + c) * sc + sh;
             a = act_f(a, slope);
             if (k == 0 || a > best) {
                 best = a;
@@ -449,69 +470,96 @@ __global__ void pool_bwd_merge_kernel(const float* __restrict__ y, int N, int H,
             da[pixk[k] * C + c] = dskip[pixk[k] * dskip_ps + c] + (k == arg ? g : 0.0f);
     }
 }
-// the same pass, also leaving the BatchNorm-backward sums of the layer whose activated output da is the gradient of
-// (sum dz, sum dz * xhat per channel; what bn_bwd_reduce would re-read da and y for): the grid is chosen so that a
-// thread keeps ONE channel over its grid-stride iterations; fp64 per thread, fixed-order LDS fold per block, one
-// record per block (C <= 256) or per group of C / 256 blocks
-__global__ __launch_bounds__(256) void pool_bwd_merge_sums_kernel(
-    const float* __restrict__ y, int N, int H, int W, int C, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dskip, int dskip_ps,
-    const float* __restrict__ dpool, float* __restrict__ da, float slope, double* __restrict__ records) {
-    __shared__ double red[2][kBlock];
-    const int Hp = H >> 1, Wp = W >> 1;
-    const int64_t total = (int64_t)N * Hp * Wp * C;
+// Four channels per thread (16-byte accesses), optionally (SUMS) also leaving the BatchNorm-backward sums of the layer
+// whose activated output da is the gradient of (sum dz, sum dz * xhat per channel; what bn_bwd_reduce would re-read da
+// and y for): the grid is then chosen so that a thread keeps ONE channel group over its grid-stride iterations; fp64 per
+// thread, fixed-order LDS fold per block, one record per block (C / 4 <= 256) or per group of C / 1024 blocks
+template <bool SUMS>
+__global__ __launch_bounds__(256) void pool_bwd_merge_vec_kernel(
+    const void* __restrict__ y, int y16, int64_t yps, int N, int H, int W, int C, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ dskip, int dskip_ps, const float* __restrict__ dpool, float* __restrict__ da, float slope,
+    double* __restrict__ records) {
+    __shared__ double red[SUMS ? 8 * kBlock : 1];
+    const int Hp = H >> 1, Wp = W >> 1, C4 = C >> 2;
+    const int64_t total = (int64_t)N * Hp * Wp * C4;
     const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = (int)(first % C);                 // (gridDim.x * 256) % C == 0: the same for every iteration
-    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-    double s1 = 0.0, s2 = 0.0;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t t = i / C;
+        const int c = (int)(i % C4) * 4;            // (SUMS: the same for every iteration of this thread)
+        int64_t t = i / C4;
         const int px = (int)(t % Wp);
         t /= Wp;
         const int py = (int)(t % Hp);
         const int n = (int)(t / Hp);
-        float best = 0.0f, yv[4], zv[4];
-        int arg = 0;
+        float sc[4], sh[4], mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+        ldv<4>(scale + c, sc); ldv<4>(shift + c, sh);
+        if (SUMS) { ldv<4>(mean + c, mu); ldv<4>(invstd + c, is); }
+        float best[4], yv[4][4], zv[4][4];
+        int arg[4] = {0, 0, 0, 0};
         int64_t pixk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             pixk[k] = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
-            yv[k] = y[pixk[k] * C + c];
-            zv[k] = yv[k] * sc + sh;
-            const float a = act_f(zv[k], slope);
-            if (k == 0 || a > best) {
-                best = a;
-                arg = k;
+            ldy<4>(y, y16, pixk[k] * yps + c, yv[k]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                zv[k][v] = yv[k][v] * sc[v] + sh[v];
+                const float a = act_f(zv[k][v], slope);
+                if (k == 0 || a > best[v]) {
+                    best[v] = a;
+                    arg[v] = k;
+                }
             }
         }
-        const float g = dpool[i];
+        float g[4];
+        ldv<4>(dpool + i * 4, g);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float d = dskip[pixk[k] * dskip_ps + c] + (k == arg ? g : 0.0f);
-            da[pixk[k] * C + c] = d;
-            const float dz = dact_f(zv[k], d, slope);
-            const float xh = (yv[k] - mu) * is;
-            s1 += (double)dz;
-            s2 += (double)dz * (double)xh;
+            float d[4];
+            ldv<4>(dskip + pixk[k] * dskip_ps + c, d);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                d[v] += (k == arg[v] ? g[v] : 0.0f);
+                if (SUMS) {
+                    const float dz = dact_f(zv[k][v], d[v], slope);
+                    const float xh = (yv[k][v] - mu[v]) * is[v];
+                    s1[v] += (double)dz;
+                    s2[v] += (double)dz * (double)xh;
+                }
+            }
+            stv<4>(da + pixk[k] * C + c, d);
         }
     }
-    if (C <= kBlock) {                              // 256 % C == 0: threads c, c + C, ... hold channel c
-        red[0][threadIdx.x] = s1;
-        red[1][threadIdx.x] = s2;
-        __syncthreads();
-        if ((int)threadIdx.x < C) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int k = threadIdx.x; k < kBlock; k += C) {
-                t1 += red[0][k];
-                t2 += red[1][k];
+    if constexpr (SUMS) {
+        const int c = (int)(first % C4) * 4;
+        if (C4 <= kBlock) {                         // 256 % C4 == 0: threads g, g + C4, ... hold channel group g
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                red[(2 * v) * kBlock + threadIdx.x] = s1[v];
+                red[(2 * v + 1) * kBlock + threadIdx.x] = s2[v];
             }
-            records[((int64_t)blockIdx.x * C + c) * 2 + 0] = t1;
-            records[((int64_t)blockIdx.x * C + c) * 2 + 1] = t2;
+            __syncthreads();
+            if ((int)threadIdx.x < C4) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    double t1 = 0.0, t2 = 0.0;
+                    for (int k = threadIdx.x; k < kBlock; k += C4) {
+                        t1 += red[(2 * v) * kBlock + k];
+                        t2 += red[(2 * v + 1) * kBlock + k];
+                    }
+                    records[((int64_t)blockIdx.x * C + c + v) * 2 + 0] = t1;
+                    records[((int64_t)blockIdx.x * C + c + v) * 2 + 1] = t2;
+                }
+            }
+        } else {                                    // C4 % 256 == 0: C4 / 256 consecutive blocks make one record
+            const int per = C4 / kBlock;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                records[((int64_t)(blockIdx.x / per) * C + c + v) * 2 + 0] = s1[v];
+                records[((int64_t)(blockIdx.x / per) * C + c + v) * 2 + 1] = s2[v];
+            }
         }
-    } else {                                        // C % 256 == 0: C / 256 consecutive blocks make one record
-        const int per = C / kBlock;
-        records[((int64_t)(blockIdx.x / per) * C + c) * 2 + 0] = s1;
-        records[((int64_t)(blockIdx.x / per) * C + c) * 2 + 1] = s2;
     }
 }
 
@@ -553,7 +601,7 @@ __global__ void head_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
 
 // C % 4 == 0: L lanes per pixel (L a power of two <= 16), each lane reads 16-byte groups of channels
 template <int L>
-__global__ __launch_bounds__(256) void head_fwd_vec_kernel(const float* __restrict__ y, int64_t M, int C,
+__global__ __launch_bounds__(256) void head_fwd_vec_kernel(const void* __restrict__ y, int y16, int64_t yps, int64_t M, int C,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ w, const float* __restrict__ b, int Cout,
                                                            float* __restrict__ logits, float slope) {
@@ -565,7 +613,7 @@ __global__ __launch_bounds__(256) void head_fwd_vec_kernel(const float* __restri
         float acc = 0.0f;
         for (int c4 = lane; c4 < C4; c4 += L) {
             float yv[4], sc[4], sh[4], wv[4];
-            ldv<4>(y + m * C + 4 * c4, yv); ldv<4>(scale + 4 * c4, sc); ldv<4>(shift + 4 * c4, sh);
+            ldy<4>(y, y16, m * yps + 4 * c4, yv); ldv<4>(scale + 4 * c4, sc); ldv<4>(shift + 4 * c4, sh);
             ldv<4>(w + (int64_t)o * C + 4 * c4, wv);
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc += act_f(yv[v] * sc[v] + sh[v], slope) * wv[v];
@@ -780,7 +828,7 @@ __global__ void head_bwd_kernel(const float* __restrict__ y, int64_t M, int C, i
 }
 
 // the same with four channels per lane (C % 4 == 0): 16-byte loads of y and stores of da
-__global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restrict__ y, int64_t M, int C, int CL,
+__global__ __launch_bounds__(256) void head_bwd_vec_kernel(const void* __restrict__ y, int y16, int64_t yps, int64_t M, int C, int CL,
                                                            int64_t rows_per_block, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ w, int Cout,
                                                            const float* __restrict__ dl, float* __restrict__ da,
@@ -807,7 +855,7 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
             for (int64_t r = r0 + rl; r < r1; r += RL) {
                 const float d = dl[r * Cout + o];
                 float yv[4], g[4];
-                ldv<4>(y + r * C + c, yv);
+                ldy<4>(y, y16, r * yps + c, yv);
                 if (o != 0) ldv<4>(da + r * C + c, g);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -1113,20 +1161,20 @@ void launch_bn_bwd_finalize_records(rfi_ctx* ctx, const float* partial_ws, int r
     check_launch("bn_bwd_finalize");
 }
 
-void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t M, int C,
+void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, YRef y, int64_t M, int C,
                           const float* scale, const float* shift, const float* mean,
                           const float* invstd, float* partial_ws, float* c1, float* c2,
                           float* dgamma, float* dbeta, float slope) {
     ChanGeom g = geom_rows(M, C);
     {
-        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 8);
+        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * (y.bf16 ? 6 : 8));
         if (g.V == 4)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
-                               ctx->stream, da, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
+                               ctx->stream, da, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
                                reinterpret_cast<double*>(partial_ws), slope);
         else
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
-                               ctx->stream, da, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
+                               ctx->stream, da, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
                                reinterpret_cast<double*>(partial_ws), slope);
         check_launch("bn_bwd_reduce");
     }
@@ -1139,21 +1187,21 @@ void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, const float* y, int64_t
     }
 }
 
-void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, const float* y, int64_t M, int C,
+void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, YRef y, int64_t M, int C,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
                          float* partial_ws, float* dbias, float slope, unsigned short* planes_out,
                          int64_t planes_pstride, int planes_P) {
     ChanGeom g = geom_rows(M, C);
     {
-        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * (planes_out ? 8 + 2 * planes_P : 12));
+        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * ((planes_out ? 8 + 2 * planes_P : 12) - (y.bf16 ? 2 : 0)));
         if (g.V == 4)
             hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
-                               da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
+                               da_inout, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
                                c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
         else
             hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
-                               da_inout, y, M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
+                               da_inout, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
                                c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
         check_launch("bn_bwd_apply");
     }
@@ -1210,37 +1258,48 @@ void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int 
     }
 }
 
-int launch_pool_bwd_merge_sums(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale,
+static bool pool_vec_ok(YRef y, int C, const float* scale, const float* shift, View dskip, const float* dpool, const float* da) {
+    return C % 4 == 0 && dskip.pstride % 4 == 0 && y.stride(C) % 4 == 0 &&
+           !((reinterpret_cast<uintptr_t>(y.p) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+              reinterpret_cast<uintptr_t>(dskip.p) | reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(da)) & 15);
+}
+int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C, const float* scale,
                                const float* shift, const float* mean, const float* invstd, View dskip, const float* dpool,
                                float* da, float slope, float* partial_ws) {
-    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
-    const bool small = C <= kBlock && kBlock % C == 0, wide = C > kBlock && C % kBlock == 0;
-    if ((H & 1) || (W & 1) || !(small || wide) || total < (int64_t)kBlock * 64) return 0;      // caller: separate reduction
+    if (!pool_vec_ok(y, C, scale, shift, dskip, dpool, da) ||
+        ((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(invstd)) & 15))
+        return 0;
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C4;
+    const bool small = C4 <= kBlock && kBlock % C4 == 0, wide = C4 > kBlock && C4 % kBlock == 0;
+    if ((H & 1) || (W & 1) || !(small || wide) || total < (int64_t)kBlock * 16) return 0;      // caller: separate reduction
     int grid = grid_for(total, kMaxRowBlocks);
     int records = grid;
     if (wide) {
-        const int per = C / kBlock;
+        const int per = C4 / kBlock;
         grid = std::max(per, grid / per * per);
-        if ((int64_t)grid * kBlock > total) return 0;
         records = grid / per;
-    } else if ((int64_t)grid * kBlock > total) {
-        return 0;                                   // (every thread must own at least one element)
     }
-    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 12 + (double)total * 4);
-    hipLaunchKernelGGL(pool_bwd_merge_sums_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, y, N, H, W, C, scale, shift, mean,
-                       invstd, dskip.p, dskip.pstride, dpool, da, slope, reinterpret_cast<double*>(partial_ws));
+    if ((int64_t)grid * kBlock > total) return 0;   // (every thread must own at least one element)
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * 16);
+    hipLaunchKernelGGL(pool_bwd_merge_vec_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, y.p, y.bf16, y.stride(C), N, H, W,
+                       C, scale, shift, mean, invstd, dskip.p, dskip.pstride, dpool, da, slope, reinterpret_cast<double*>(partial_ws));
     check_launch("pool_bwd_merge_sums");
     return records;
 }
 
-void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
+void launch_pool_bwd_merge(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
                            const float* scale, const float* shift, View dskip, const float* dpool,
                            float* da, float slope) {
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
     {
-        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 12 + (double)total * 4);
-        hipLaunchKernelGGL(pool_bwd_merge_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
-                           N, H, W, C, scale, shift, dskip.p, dskip.pstride, dpool, da, slope);
+        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * 4);
+        if (pool_vec_ok(y, C, scale, shift, dskip, dpool, da))
+            hipLaunchKernelGGL(pool_bwd_merge_vec_kernel<false>, dim3(grid_for(total / 4)), dim3(kBlock), 0, ctx->stream, y.p, y.bf16,
+                               y.stride(C), N, H, W, C, scale, shift, nullptr, nullptr, dskip.p, dskip.pstride, dpool, da, slope, nullptr);
+        else
+            hipLaunchKernelGGL(pool_bwd_merge_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y.p, y.bf16, y.stride(C),
+                               N, H, W, C, scale, shift, dskip.p, dskip.pstride, dpool, da, slope);
         check_launch("pool_bwd_merge");
     }
     if ((H & 1) || (W & 1)) {
@@ -1251,16 +1310,18 @@ void launch_pool_bwd_merge(rfi_ctx* ctx, const float* y, int N, int H, int W, in
     }
 }
 
-void launch_head_fwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
+void launch_head_fwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
                      const float* shift, const float* w, const float* b, int Cout, float* logits, float slope) {
-    ProfScope ps(ctx, FAM_ELEMWISE, 2.0 * M * C * Cout, (double)M * C * 4 + (double)M * Cout * 4);
-    const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scale) |
-                                      reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(w)) & 15);
+    ProfScope ps(ctx, FAM_ELEMWISE, 2.0 * M * C * Cout, (double)M * C * (yr.bf16 ? 2 : 4) + (double)M * Cout * 4);
+    const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(yr.p) | reinterpret_cast<uintptr_t>(scale) |
+                                      reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(w)) & 15) && yr.stride(C) % 4 == 0;
+    RFI_REQUIRE(vec || !yr.bf16, "head_fwd: a bfloat16 input needs C % 4 == 0");
+    const float* y = static_cast<const float*>(yr.p);
     if (vec) {
         int L = 1;
         while (L * 2 <= C / 4 && L < 16) L *= 2;
         const unsigned blocks = (unsigned)cdiv(M * L, kBlock);
-#define RFI_HF(L_) hipLaunchKernelGGL(head_fwd_vec_kernel<L_>, dim3(blocks), dim3(kBlock), 0, ctx->stream, y, M, C, scale, shift, w, b, Cout, logits, slope)
+#define RFI_HF(L_) hipLaunchKernelGGL(head_fwd_vec_kernel<L_>, dim3(blocks), dim3(kBlock), 0, ctx->stream, yr.p, yr.bf16, yr.stride(C), M, C, scale, shift, w, b, Cout, logits, slope)
         if (L == 16) RFI_HF(16); else if (L == 8) RFI_HF(8); else if (L == 4) RFI_HF(4); else if (L == 2) RFI_HF(2); else RFI_HF(1);
 #undef RFI_HF
     } else {
@@ -1337,22 +1398,24 @@ size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
     (void)M;
     return (size_t)kMaxRowBlocks * ((size_t)Cout * C + Cout) * 2;
 }
-int launch_head_bwd(rfi_ctx* ctx, const float* y, int64_t M, int C, const float* scale,
+int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                     float* partial_ws, float* dw, float* db, float slope, const float* bn_mean, const float* bn_invstd,
                     float* bn_records_ws) {
     int bn_records = 0;
-    const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(da) |
+    const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(yr.p) | reinterpret_cast<uintptr_t>(da) |
                                       reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
-                                      reinterpret_cast<uintptr_t>(w)) & 15);
+                                      reinterpret_cast<uintptr_t>(w)) & 15) && yr.stride(C) % 4 == 0;
+    RFI_REQUIRE(vec || !yr.bf16, "head_bwd: a bfloat16 input needs C % 4 == 0");
+    const float* y = static_cast<const float*>(yr.p);
     ChanGeom g = geom_rows(M, C, vec);     // scalar kernel: one channel per lane; vector kernel: four
     {
-        ProfScope ps(ctx, FAM_ELEMWISE, 4.0 * M * C * Cout, (double)M * C * 8);
+        ProfScope ps(ctx, FAM_ELEMWISE, 4.0 * M * C * Cout, (double)M * C * (yr.bf16 ? 6 : 8));
         if (vec) {
             const bool sums = bn_records_ws && bn_mean && bn_invstd && Cout == 1 &&
                               !((reinterpret_cast<uintptr_t>(bn_mean) | reinterpret_cast<uintptr_t>(bn_invstd)) & 15);
-            hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,
-                               M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
+            hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, yr.p, yr.bf16,
+                               yr.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
                                reinterpret_cast<double*>(partial_ws), slope, bn_mean, bn_invstd,
                                sums ? reinterpret_cast<double*>(bn_records_ws) : nullptr);
             if (sums) bn_records = g.rblocks;

@@ -169,6 +169,13 @@ struct rfi_model {
     std::vector<rfi::PlaneBuf> pl;
     std::vector<int> pA1e, pSkip, pPool, pUp, pA1d, pdYa, pdYb, upf;
     int pXin = -1, pA1b = -1, pdYbottA = -1, pdYbottB = -1;
+    // bf16 data flow (P = 1, feat % 4 == 0): raw conv outputs that only elementwise kernels read are stored as bfloat16
+    // (indices into pl; -1: float32 in bufs): both convs of every encoder, the first of the bottleneck and of every
+    // decoder, the last decoder's second.  The four tensors a transposed conv reads stay float32 tensors holding
+    // bf16-rounded values, so the arithmetic is uniform: every conv output of this mode is a bfloat16 value
+    bool y16_flow = false;
+    std::vector<int> yE1, yE2, yD1;
+    int yB1 = -1, yD2top = -1;
     rfi::bf16_t* wb_pool = nullptr;
     void* wb_descs = nullptr;
     int wb_n = 0;

@@ -64,6 +64,22 @@ void rfi_model::prepare_planes(int n, int h, int w) {
     }
     const int64_t Mb = (int64_t)n * (h >> D) * (w >> D);
     for (int i : {pA1b, pdYbottA, pdYbottB}) pl[i].ensure(ctx, Mb, feat << D, P);
+    static const bool no_y16 = getenv("RFI_NO_Y16") != nullptr;                 // A/B runs: float32 conv outputs
+    y16_flow = P == 1 && feat % 4 == 0 && !no_y16;
+    if (y16_flow) {
+        if (yB1 < 0) {
+            auto mk1 = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) { pl.emplace_back(); v[l] = (int)pl.size() - 1; } };
+            mk1(yE1); mk1(yE2); mk1(yD1);
+            pl.emplace_back(); yB1 = (int)pl.size() - 1;
+            pl.emplace_back(); yD2top = (int)pl.size() - 1;
+        }
+        for (int l = 1; l <= D; ++l) {
+            const int64_t M = (int64_t)n * (h >> (l - 1)) * (w >> (l - 1));
+            for (int i : {yE1[l], yE2[l], yD1[l]}) pl[i].ensure(ctx, M, feat << (l - 1), 1);
+        }
+        pl[yB1].ensure(ctx, Mb, feat << D, 1);
+        pl[yD2top].ensure(ctx, M1, feat, 1);
+    }
     // weight-gradient slabs of the plane kernel
     size_t slab_need = 0;
     for (size_t ci = 0; ci < convs.size(); ++ci) {
@@ -131,7 +147,15 @@ struct Shape { int N, H, W; };
 
 PlaneSeg seg_of(const PlaneBuf& b) { return PlaneSeg{b.p, b.pstride, b.nchunks}; }
 
-void run_pconv_bn(rfi_model* m, ConvBN& c, const PlaneSeg* in, int nseg, Shape s, float* Y, bool train) {
+// where a raw conv output lives: a float32 tensor (values rounded to bf16 when the bf16 flow is on) or a bfloat16 one
+struct YT {
+    float* f = nullptr;
+    const PlaneBuf* h = nullptr;
+    YRef ref() const { return h ? YRef(h->p, h->pstride) : YRef(f); }
+};
+
+void run_pconv_bn(rfi_model* m, ConvBN& c, const PlaneSeg* in, int nseg, Shape s, YT Yt, bool train) {
+    float* Y = Yt.f;
     PConvArgs a;
     a.x[0] = in[0];
     if (nseg > 1) a.x[1] = in[1];
@@ -140,7 +164,8 @@ void run_pconv_bn(rfi_model* m, ConvBN& c, const PlaneSeg* in, int nseg, Shape s
     a.Cout = c.cout;
     a.wB = c.wBf;
     a.bias = m->params + c.b_off;
-    a.y = Y; a.y_pstride = c.cout;
+    if (Yt.h) { a.y16 = Yt.h->p; a.y_pstride = (int)Yt.h->pstride; }
+    else { a.y = Y; a.y_pstride = c.cout; a.round_y = m->y16_flow; }
     a.Hout = s.H; a.Wout = s.W;
     a.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
     float* ws = m->buf(m->ws_red);
@@ -151,6 +176,7 @@ void run_pconv_bn(rfi_model* m, ConvBN& c, const PlaneSeg* in, int nseg, Shape s
     launch_pconv(m->ctx, a);
     const int64_t M = (int64_t)s.N * s.H * s.W;
     if (train) {
+        RFI_REQUIRE(a.stats_records > 0 || !Yt.h, "plane conv: no statistics records for a bfloat16 output");
         if (a.stats_records == 0) launch_bn_stats(m->ctx, Y, M, c.cout, ws);
         launch_bn_finalize(m->ctx, ws, M, c.cout, m->params + c.g_off, m->params + c.be_off, c.running_mean(),
                            c.running_var(), c.ema_repeats, c.mean(), c.invstd(), c.scale(), c.shift(), nullptr,
@@ -163,11 +189,12 @@ void run_pconv_bn(rfi_model* m, ConvBN& c, const PlaneSeg* in, int nseg, Shape s
 }
 
 // Conv3x3+BN+act twice: Y1 = conv(in) ; A1 = planes(act(BN(Y1))) ; Y2 = conv(A1)
-void double_conv(rfi_model* m, ConvBN& c1, ConvBN& c2, const PlaneSeg* in, int nseg, Shape s, float* Y1, PlaneBuf& A1,
-                 float* Y2, bool train) {
+void double_conv(rfi_model* m, ConvBN& c1, ConvBN& c2, const PlaneSeg* in, int nseg, Shape s, YT Y1, PlaneBuf& A1,
+                 YT Y2, bool train) {
     run_pconv_bn(m, c1, in, nseg, s, Y1, train);
     const int64_t M = (int64_t)s.N * s.H * s.W;
-    launch_act_split(m->ctx, View{Y1, c1.cout}, M, c1.cout, m->bn_xf(c1), m->planesP, A1.p, A1.pstride);
+    launch_act_split(m->ctx, View{Y1.f, c1.cout}, M, c1.cout, m->bn_xf(c1), m->planesP, A1.p, A1.pstride,
+                     Y1.h ? Y1.h->p : nullptr, Y1.h ? Y1.h->pstride : 0);
     const PlaneSeg a1 = seg_of(A1);
     run_pconv_bn(m, c2, &a1, 1, s, Y2, train);
 }
@@ -179,18 +206,23 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
     prepare_planes(n, h, w);
     launch_act_split(ctx, View{x_dev, in_ch}, (int64_t)n * h * w, in_ch, InXform{}, P, pl[pXin].p, pl[pXin].pstride);
     PlaneSeg cur = seg_of(pl[pXin]);
+    // a raw conv output: the bfloat16 tensor pl[hi] when the bf16 flow is on (hi >= 0), else the float32 tensor bufs[fi]
+    auto yt = [&](int fi, int hi) { YT y; if (y16_flow && hi >= 0) y.h = &pl[hi]; else y.f = buf(fi); return y; };
     for (int l = 1; l <= D; ++l) {
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
-        double_conv(this, c1, c2, &cur, 1, s, buf(encY1[l]), pl[pA1e[l]], buf(encY2[l]), train_mode);
-        launch_bn_relu_pool_planes(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), act_slope, P,
-                                   pl[pSkip[l]].p, pl[pSkip[l]].pstride, pl[pPool[l]].p, pl[pPool[l]].pstride);
+        const YT y2 = yt(encY2[l], y16_flow ? yE2[l] : -1);
+        double_conv(this, c1, c2, &cur, 1, s, yt(encY1[l], y16_flow ? yE1[l] : -1), pl[pA1e[l]], y2, train_mode);
+        launch_bn_relu_pool_planes(ctx, y2.f, s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), act_slope, P,
+                                   pl[pSkip[l]].p, pl[pSkip[l]].pstride, pl[pPool[l]].p, pl[pPool[l]].pstride,
+                                   y2.h ? y2.h->p : nullptr, y2.h ? y2.h->pstride : 0);
         cur = seg_of(pl[pPool[l]]);
     }
     {
         Shape s{n, h >> D, w >> D};
-        double_conv(this, convs[2 * D], convs[2 * D + 1], &cur, 1, s, buf(bottY1), pl[pA1b], buf(bottY2), train_mode);
+        double_conv(this, convs[2 * D], convs[2 * D + 1], &cur, 1, s, yt(bottY1, y16_flow ? yB1 : -1), pl[pA1b],
+                    yt(bottY2, -1), train_mode);            // (read by the transposed conv: float32 tensor)
     }
     const float* prevY = buf(bottY2);
     ConvBN* prevBN = &convs[2 * D + 1];
@@ -229,13 +261,15 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
         ConvBN& c1 = convs[2 * D + 2 + 2 * k];
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};      // cat([up, skip], dim=1) as two K-segments
-        double_conv(this, c1, c2, in2, 2, s, buf(decY1[l]), pl[pA1d[l]], buf(decY2[l]), train_mode);
+        // (decoder l's second output feeds the next transposed conv -- float32 tensor -- except the last: the head)
+        double_conv(this, c1, c2, in2, 2, s, yt(decY1[l], y16_flow ? yD1[l] : -1), pl[pA1d[l]],
+                    yt(decY2[l], y16_flow && l == 1 ? yD2top : -1), train_mode);
         prevY = buf(decY2[l]);
         prevBN = &c2;
     }
     const int64_t M1 = (int64_t)n * h * w;
-    launch_head_fwd(ctx, prevY, M1, feat, prevBN->scale(), prevBN->shift(), params + head_w_off, params + head_b_off,
-                    out_ch, buf(logits), act_slope);
+    launch_head_fwd(ctx, yt(decY2[1], y16_flow ? yD2top : -1).ref(), M1, feat, prevBN->scale(), prevBN->shift(),
+                    params + head_w_off, params + head_b_off, out_ch, buf(logits), act_slope);
     if (head_sigmoid) launch_sigmoid_fwd(ctx, buf(logits), M1 * out_ch, buf(probs));
 }
 
@@ -251,7 +285,7 @@ struct SideScopeP {
 
 // dA: gradient w.r.t. the ACTIVATED output of conv c (float32, left untouched).  Writes dW / db / dgamma / dbeta
 // and, if dx != null, the gradient w.r.t. the conv's input (float32 raw, `cin` channels per pixel).
-void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, const float* Y, const PlaneSeg* in, int nseg, Shape s,
+void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, YRef Y, const PlaneSeg* in, int nseg, Shape s,
                        float* dx, PlaneBuf& dYp, int have_records = 0) {
     rfi_ctx* ctx = m->ctx;
     const int64_t M = (int64_t)s.N * s.H * s.W;
@@ -305,6 +339,8 @@ void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, const float* Y,
 void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
     (void)x_dev;
     const int D = depth;
+    // a raw conv output of the forward pass: bfloat16 tensor pl[hi] in the bf16 flow, else float32 bufs[fi]
+    auto yr = [&](int fi, int hi) { return (y16_flow && hi >= 0) ? YRef(pl[hi].p, pl[hi].pstride) : YRef(buf(fi)); };
     const int64_t M1 = (int64_t)n * h * w;
     if (loss_kind == 1)
         launch_focal_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, focal_alpha, focal_gamma, buf(dlogits));
@@ -314,7 +350,7 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     int head_records = 0;
     {
         ConvBN& last = convs[2 * D + 2 + 2 * (D - 1) + 1];
-        head_records = launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off, out_ch,
+        head_records = launch_head_bwd(ctx, yr(decY2[1], y16_flow ? yD2top : -1), M1, feat, last.scale(), last.shift(), params + head_w_off, out_ch,
                                        buf(dlogits), buf(gA[1]), buf(ws_red) + bn_bwd_ws_floats(M1, feat), grads + head_w_off,
                                        grads + head_b_off, act_slope, last.mean(), last.invstd(), buf(ws_red));
     }
@@ -326,9 +362,10 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         const PlaneSeg a1 = seg_of(pl[pA1d[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), buf(decY2[l]), &a1, 1, s, buf(gB[l]), pl[pdYa[l]], l == 1 ? head_records : 0);
+        backward_pconv_bn(this, c2, buf(gA[l]), yr(decY2[l], y16_flow && l == 1 ? yD2top : -1), &a1, 1, s, buf(gB[l]), pl[pdYa[l]],
+                          l == 1 ? head_records : 0);
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};
-        backward_pconv_bn(this, c1, buf(gB[l]), buf(decY1[l]), in2, 2, s, buf(dconcat[l]), pl[pdYb[l]]);
+        backward_pconv_bn(this, c1, buf(gB[l]), yr(decY1[l], y16_flow ? yD1[l] : -1), in2, 2, s, buf(dconcat[l]), pl[pdYb[l]]);
         // ConvTranspose: dUp = dconcat[..., 0:C]; the round-1 kernels on float32 tensors
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
         ConvBN& prevBN = (l == D) ? convs[2 * D + 1] : convs[2 * D + 2 + 2 * (k - 1) + 1];
@@ -372,23 +409,24 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         Shape s{n, h >> D, w >> D};
         const PlaneSeg a1 = seg_of(pl[pA1b]), p4 = seg_of(pl[pPool[D]]);
         backward_pconv_bn(this, convs[2 * D + 1], buf(gBottA), buf(bottY2), &a1, 1, s, buf(gBottB), pl[pdYbottA]);
-        backward_pconv_bn(this, convs[2 * D], buf(gBottB), buf(bottY1), &p4, 1, s, buf(dpool[D]), pl[pdYbottB]);
+        backward_pconv_bn(this, convs[2 * D], buf(gBottB), yr(bottY1, y16_flow ? yB1 : -1), &p4, 1, s, buf(dpool[D]), pl[pdYbottB]);
         bucket_ready(convs[2 * D].w_off, ups[0].w_off);
     }
     for (int l = D; l >= 1; --l) {                // encoders, deep to shallow
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
-        const int have = launch_pool_bwd_merge_sums(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), c2.mean(),
+        const int have = launch_pool_bwd_merge_sums(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), c2.mean(),
                                                     c2.invstd(), View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]),
                                                     buf(gA[l]), act_slope, buf(ws_red));
         if (!have)
-            launch_pool_bwd_merge(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
+            launch_pool_bwd_merge(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
                                   View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
         const PlaneSeg a1 = seg_of(pl[pA1e[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), buf(encY2[l]), &a1, 1, s, buf(gB[l]), pl[pdYa[l]], have);
+        backward_pconv_bn(this, c2, buf(gA[l]), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, buf(gB[l]), pl[pdYa[l]], have);
         const PlaneSeg in = seg_of(l == 1 ? pl[pXin] : pl[pPool[l - 1]]);
-        backward_pconv_bn(this, c1, buf(gB[l]), buf(encY1[l]), &in, 1, s, (l == 1) ? nullptr : buf(dpool[l - 1]), pl[pdYb[l]]);
+        backward_pconv_bn(this, c1, buf(gB[l]), yr(encY1[l], y16_flow ? yE1[l] : -1), &in, 1, s, (l == 1) ? nullptr : buf(dpool[l - 1]),
+                          pl[pdYb[l]]);
         bucket_ready(c1.w_off, convs[2 * l].w_off);
     }
     side_join();

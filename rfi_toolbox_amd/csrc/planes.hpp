@@ -29,11 +29,13 @@ static inline size_t plane_elems(int64_t pixels, int C, int P) { return (size_t)
 
 // ---------------------------------------------------------------- producers
 // fp32 [M][C] view (pstride floats per pixel) -> planes; optional BatchNorm-apply + (Leaky)ReLU in flight
-void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P, bf16_t* out, int64_t out_pstride);
+// x16 != null: the input is a bfloat16 NHWC tensor (a raw conv output of the bf16 data flow) instead of x
+void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P, bf16_t* out, int64_t out_pstride,
+                      const bf16_t* x16 = nullptr, int64_t x16_pstride = 0);
 // a = act(y*scale+shift) -> skip planes (full resolution) + 2x2 max-pooled planes (H, W even)
 void launch_bn_relu_pool_planes(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale,
                                 const float* shift, float slope, int P, bf16_t* skip, int64_t skip_pstride,
-                                bf16_t* pooled, int64_t pooled_pstride);
+                                bf16_t* pooled, int64_t pooled_pstride, const bf16_t* y16 = nullptr, int64_t y16_pstride = 0);
 // planes -> fp32 (tests / debugging): sum of the pieces
 void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, int64_t M, int C, int P, float* out,
                           int out_pstride);
@@ -71,6 +73,10 @@ struct PConvArgs {
     const float* bias = nullptr;
     float* y = nullptr;               // raw float32 NHWC output (pre-BatchNorm), y_pstride floats per pixel
     int y_pstride = 0;
+    bf16_t* y16 = nullptr;            // bf16 data flow: the raw output as bfloat16 NHWC instead (y unused; y_pstride counts bf16
+                                      // elements); the statistics are then those of the ROUNDED values
+    bool round_y = false;             // float32 output holding bf16-rounded values (same arithmetic as y16, for consumers that
+                                      // read float32 tensors)
     int Hout = 0, Wout = 0;
     int osy = 1, osx = 1, ooy = 0, oox = 0;
     int R = 3, S = 1, pad = 1;

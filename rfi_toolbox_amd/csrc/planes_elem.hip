@@ -40,7 +40,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[3]) {
 }
 
 template <int P, bool VEC>
-__global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ x, int xp, int64_t M, int C,
+__global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ x, const bf16_t* __restrict__ x16, int xp, int64_t M, int C,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         int relu, float slope, bf16_t* __restrict__ out, int64_t op) {
     const int groups = plane_chunks(C) * 2;                    // 8-channel groups per pixel (padded)
@@ -51,7 +51,16 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
         const int c0 = g * 8;
         float v[8];
         const float* src = x + m * xp + c0;
-        if (VEC && c0 + 8 <= C) {
+        if (x16) {                                  // the raw conv output stored as bfloat16 (bf16 data flow): one 16-byte load
+            const u32x4 t = *reinterpret_cast<const u32x4*>(x16 + m * xp + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = __builtin_bit_cast(float, t[e] << 16);
+                v[2 * e + 1] = __builtin_bit_cast(float, t[e] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? v[e] : 0.0f;
+        } else if (VEC && c0 + 8 <= C) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         } else {
@@ -92,7 +101,8 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
 // a = act(y * scale + shift) -> skip planes (full resolution) and 2x2 max-pooled planes, 8 channels of one pooled
 // pixel per thread (Encoder.forward, models/unet.py:21-28: `pool(conv(x)), conv(x)`)
 template <int P>
-__global__ __launch_bounds__(256) void bn_relu_pool_planes_kernel(const float* __restrict__ y, int N, int H, int W, int C,
+__global__ __launch_bounds__(256) void bn_relu_pool_planes_kernel(const float* __restrict__ y, const bf16_t* __restrict__ y16,
+                                                                 int64_t yps, int N, int H, int W, int C,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  float slope, bf16_t* __restrict__ skip, int64_t sp,
                                                                  bf16_t* __restrict__ pooled, int64_t pp) {
@@ -126,7 +136,14 @@ __global__ __launch_bounds__(256) void bn_relu_pool_planes_kernel(const float* _
             const int64_t pix = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
             const float* src = y + pix * C + c0;
             float v[8];
-            if (vec && c0 + 8 <= C) {
+            if (y16) {
+                const u32x4 t = *reinterpret_cast<const u32x4*>(y16 + pix * yps + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = __builtin_bit_cast(float, t[e] << 16);
+                    v[2 * e + 1] = __builtin_bit_cast(float, t[e] & 0xffff0000u);
+                }
+            } else if (vec && c0 + 8 <= C) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
                 v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
             } else {
@@ -204,19 +221,23 @@ __global__ __launch_bounds__(256) void weights_to_wb_kernel(const WBDesc* __rest
 
 }  // namespace
 
-void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P, bf16_t* out, int64_t out_pstride) {
+void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P, bf16_t* out, int64_t out_pstride,
+                      const bf16_t* x16, int64_t x16_pstride) {
     RFI_REQUIRE(P == 1 || P == 3, "act_split: planes must be 1 or 3");
     RFI_REQUIRE(M > 0 && C > 0, "act_split: empty tensor");
     RFI_REQUIRE(out_pstride % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "act_split: unaligned output");
     const bool vec = (x.pstride % 4 == 0) && (reinterpret_cast<uintptr_t>(x.p) & 15) == 0;
+    RFI_REQUIRE(!x16 || (x16_pstride % 8 == 0 && (reinterpret_cast<uintptr_t>(x16) & 15) == 0 && x16_pstride >= 16 * plane_chunks(C)),
+                "act_split: the bfloat16 input must be a chunk-padded, 16-byte aligned tensor");
     const int64_t total = M * plane_chunks(C) * 2;
-    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * 4 + (double)total * 16 * P);
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * (x16 ? 2 : 4) + (double)total * 16 * P);
+    const int xp = x16 ? (int)x16_pstride : x.pstride;
     int64_t blocks = cdiv(total, 256);
     if (blocks > 8192) blocks = 8192;
     const int relu = xf.scale ? xf.relu : 0;
 #define RFI_AS(P_, V_)                                                                                        \
     hipLaunchKernelGGL((act_split_kernel<P_, V_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x.p,  \
-                       x.pstride, M, C, xf.scale, xf.shift, relu, xf.slope, out, out_pstride)
+                       x16, xp, M, C, xf.scale, xf.shift, relu, xf.slope, out, out_pstride)
     if (P == 3) { if (vec) RFI_AS(3, true); else RFI_AS(3, false); }
     else { if (vec) RFI_AS(1, true); else RFI_AS(1, false); }
 #undef RFI_AS
@@ -225,18 +246,20 @@ void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P,
 
 void launch_bn_relu_pool_planes(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale,
                                 const float* shift, float slope, int P, bf16_t* skip, int64_t skip_pstride,
-                                bf16_t* pooled, int64_t pooled_pstride) {
+                                bf16_t* pooled, int64_t pooled_pstride, const bf16_t* y16, int64_t y16_pstride) {
     RFI_REQUIRE((H & 1) == 0 && (W & 1) == 0, "bn_relu_pool_planes: even H and W (the U-Net levels are)");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * plane_chunks(C) * 2;
-    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 4 + (double)total * 16 * P * 5);
+    RFI_REQUIRE(!y16 || (y16_pstride % 8 == 0 && (reinterpret_cast<uintptr_t>(y16) & 15) == 0 && y16_pstride >= 16 * plane_chunks(C)),
+                "bn_relu_pool_planes: the bfloat16 input must be a chunk-padded, 16-byte aligned tensor");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y16 ? 2 : 4) + (double)total * 16 * P * 5);
     int64_t blocks = cdiv(total, 256);
     if (blocks > 8192) blocks = 8192;
     if (P == 3)
-        hipLaunchKernelGGL(bn_relu_pool_planes_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, N, H, W, C,
-                           scale, shift, slope, skip, skip_pstride, pooled, pooled_pstride);
+        hipLaunchKernelGGL(bn_relu_pool_planes_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, y16, y16_pstride,
+                           N, H, W, C, scale, shift, slope, skip, skip_pstride, pooled, pooled_pstride);
     else
-        hipLaunchKernelGGL(bn_relu_pool_planes_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, N, H, W, C,
-                           scale, shift, slope, skip, skip_pstride, pooled, pooled_pstride);
+        hipLaunchKernelGGL(bn_relu_pool_planes_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, y16, y16_pstride,
+                           N, H, W, C, scale, shift, slope, skip, skip_pstride, pooled, pooled_pstride);
     check_launch("bn_relu_pool_planes");
 }
 

@@ -48,7 +48,7 @@ def _case_bf16():
     """The oracle in the bf16-operand arithmetic (`unet_ref.bf16_operands`) on the same inputs and state."""
     c = _case()
     xo, yo = unet_ref.nhwc_to_nchw(c["x"]), c["y"].float().unsqueeze(1)
-    with unet_ref.bf16_operands():
+    with unet_ref.bf16_operands(round_outputs=True):
         l, lg, g, bufs = unet_ref.loss_and_grads(c["st"], xo, yo)
     total, _ = unet_ref.clip_coefficient(g, 1.0)
     return dict(l=float(l), lg=lg, g=g, bufs=bufs, norm=float(total))
