@@ -483,6 +483,9 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
 // workgroup tiles, halo rows without the pad slot (-20..-38 % staged bytes per MFMA: +-3 %); a start delay for the
 // second workgroup of each CU (no effect); one 8-wave workgroup per CU with every buffer doubled and the prefetch
 // DMA issued between the MFMAs of the previous item (same time for float32 pieces, 15-30 % slower for bf16).  The
+// Also not kept: a transposed epilogue (operands swapped so that a lane holds 4 x 4 consecutive channels of ONE pixel
+// and stores them straight from the accumulators, no transpose through LDS): correct, but each wave store then
+// covers 16 bytes of 32 different pixel rows instead of 8 whole rows, and the step went from 4.48 to 5.01 ms.  The
 // kernel sits at 1.0-1.2 PFLOP/s of executed bf16 MFMA on the deep layers (the float32-by-3xbf16 arithmetic: x 1/6),
 // which is where the best known hand-scheduled GEMM of the CDNA4 guide ends on random data (1.32-1.34 PFLOP/s at a
 // sustained 1.9 GHz); the 32-channel layers are bound by HBM (6 B per activation element in, 4 B out).
