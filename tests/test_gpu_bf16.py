@@ -126,3 +126,40 @@ def test_bf16_inference_iou_at_1024_on_reference_weights(golden_dir):
     for k in ("iou", "precision", "recall", "f1", "dice"):
         assert abs(got_m[k] - ref_m[k]) <= 1e-3, (k, got_m[k], ref_m[k])
     assert ((logits > 0) != (want > 0)).mean() <= 1e-3
+
+
+@pytest.mark.parametrize("cls,f,n,h,w", [("UNetBigger", 8, 2, 64, 64), ("UNet", 12, 2, 48, 80), ("UNet", 6, 1, 32, 32),
+                                         ("UNet", 16, 3, 16, 16)])
+def test_bf16_data_flow_other_shapes(cls, f, n, h, w):
+    """The bf16 data flow away from the benched shape: depth 5 (1024 channels at the bottleneck), channel counts
+    that are not powers of two (partial 16-channel chunks, the scalar fallbacks of the fused reductions), a width
+    that is not a multiple of 4 (conv outputs stay float32 there: the oracle then rounds operands only), tiny maps."""
+    from rfi_toolbox_amd.models import UNetBigger
+    depth = 5 if cls == "UNetBigger" else 4
+    st = unet_ref.init_state(3, 1, f, depth=depth, seed=7)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n, h, w, 3, generator=g)
+    y = (torch.rand(n, h, w, generator=g) > 0.8).to(torch.uint8)
+    xo, yo = unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1)
+    with unet_ref.bf16_operands(round_outputs=(f % 4 == 0)):
+        lb, lgb, gb, _ = unet_ref.loss_and_grads(st, xo, yo)
+    l32, lg32, g32, _ = unet_ref.loss_and_grads(st, xo, yo)
+    m = (UNetBigger if cls == "UNetBigger" else UNet)(3, 1, f).load_state_dict(st).train().set_compute_dtype("bfloat16")
+    loss = m.forward_backward(x, y)
+    assert loss == pytest.approx(float(lb), rel=5e-3)
+    want = lgb.permute(0, 2, 3, 1).reshape(-1).numpy()
+    w32 = lg32.permute(0, 2, 3, 1).reshape(-1).numpy()
+    span = float(np.abs(want).max())
+    d_same, d_arith = np.abs(m.debug_tensor("logits") - want).max(), np.abs(w32 - want).max()
+    assert d_same <= max(0.6 * d_arith, 5e-3 * span), (d_same, d_arith, span)
+    rels = []
+    for k, gk in gb.items():
+        if k.endswith((".0.bias", ".3.bias")) and "conv" in k:
+            continue
+        gk = gk.numpy().ravel()
+        nrm = np.linalg.norm(gk) + 1e-30
+        rel_same = np.linalg.norm(m.grad(k).ravel() - gk) / nrm
+        rel_arith = np.linalg.norm(g32[k].numpy().ravel() - gk) / nrm
+        rels.append(rel_same / max(rel_arith, 1e-9))
+        assert rel_same <= max(1.5 * rel_arith, 3e-2), (k, rel_same, rel_arith)
+    assert np.median(rels) <= 1.0, np.median(rels)
