@@ -91,6 +91,16 @@ int rfi_cnn3_create(rfi_ctx* ctx, int in_channels, int out_channels, int width, 
  * 2 (float32 by 3 x bf16, default), 0 (native float32 MFMA), 4 (bf16 operands); 1 / 3 run as 4 / 2 (the plane
  * data flow exists for the plain U-Net only). */
 int rfi_unet_resnet_create(rfi_ctx* ctx, int in_channels, int out_channels, int init_features, rfi_model** out);
+/* The per-RoI mask branch of Mask R-CNN (BASELINE.json configs[3], north_star "per-pixel mask head"; SURVEY.md 8a row A11;
+ * not in the reference and no torchvision here: builder-defined as the published head, oracle/mask_head_ref.py):
+ * conv_layers x [Conv3x3(C->C, p1)+bias -> ReLU] -> ConvTranspose2d(C->C, k2, s2)+bias -> ReLU -> Conv1x1(C->K).  Input:
+ * RoIAlign-ed features [R, h, w, C] (rfi_op_roi_align), output logits [R, 2h, 2w, K]; labels of the training calls are
+ * [R, 2h, 2w] uint8 and the loss is the mean BCE-with-logits over them (K = 1; rfi_model_set_loss(m, 1, alpha, gamma)
+ * switches to a focal loss).  Entries: mask_fcn{1..L}.weight/bias, conv5_mask.weight/bias, mask_fcn_logits.weight/bias.
+ * Every rfi_model_* / rfi_train_* call applies with n = R; rfi_model_input_grad returns the gradient w.r.t. the input
+ * features of the last backward pass ([R, h, w, C]) for rfi_op_roi_align_backward. */
+int rfi_mask_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int out_channels, rfi_model** out);
+int rfi_model_input_grad(rfi_model* m, float* dx, int dx_mem);
 int rfi_model_destroy(rfi_model* m);
 /* variants of models/unet.py:120-268 on the same graph: UNetDifferentActivation's activation
  * (0 = ReLU, 0 < s < 1 = LeakyReLU(negative_slope=s), after every BatchNorm) and UNetOverfit's head

@@ -367,9 +367,10 @@ def clip_coefficient(grads, max_norm=1.0):
 
 
 def train_step(state, adam, x_nchw, y, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-               weight_decay=1e-5, clip=1.0, tape=None, forward_fn=None):
+               weight_decay=1e-5, clip=1.0, tape=None, forward_fn=None, loss_fn=None):
     """One optimisation step in place on ``state``/``adam``.  Returns dict of scalars+grads."""
-    loss, logits, grads, bufs = loss_and_grads(state, x_nchw, y, training=True, tape=tape, forward_fn=forward_fn)
+    loss, logits, grads, bufs = loss_and_grads(state, x_nchw, y, training=True, tape=tape, forward_fn=forward_fn,
+                                               loss_fn=loss_fn)
     total, coef = clip_coefficient(grads, clip)
     adam["step"] += 1
     t = adam["step"]

@@ -64,6 +64,8 @@ _PROTOS = {
     "rfi_unet_create": (_i, [_vp, _i, _i, _i, _i, _pvp]),
     "rfi_cnn3_create": (_i, [_vp, _i, _i, _i, _pvp]),
     "rfi_unet_resnet_create": (_i, [_vp, _i, _i, _i, _pvp]),
+    "rfi_mask_head_create": (_i, [_vp, _i, _i, _i, _pvp]),
+    "rfi_model_input_grad": (_i, [_vp, _vp, _i]),
     "rfi_model_set_activation": (_i, [_vp, _f]),
     "rfi_model_set_compute_dtype": (_i, [_vp, _i]),
     "rfi_model_set_head_sigmoid": (_i, [_vp, _i]),

@@ -318,6 +318,37 @@ int rfi_unet_resnet_create(rfi_ctx* ctx, int in_channels, int out_channels, int 
         *out = m;
     });
 }
+int rfi_mask_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int out_channels, rfi_model** out) {
+    return guarded([&] {
+        RFI_REQUIRE(ctx && out, "rfi_mask_head_create: null argument");
+        auto* m = new rfi_model();
+        m->ctx = ctx;
+        m->arch = 3;
+        m->in_ch = in_channels;
+        m->out_ch = out_channels;
+        m->feat = in_channels;
+        m->depth = conv_layers;
+        try {
+            m->build();
+        } catch (...) {
+            m->ctx = nullptr;
+            delete m;
+            throw;
+        }
+        *out = m;
+    });
+}
+int rfi_model_input_grad(rfi_model* m, float* dx, int dx_mem) {
+    return guarded([&] {
+        RFI_REQUIRE(m->arch == 3, "input_grad: only the mask head computes the gradient w.r.t. its input");
+        RFI_REQUIRE(m->pN > 0 && dx, "input_grad: no backward pass has run");
+        m->ctx->activate();
+        const size_t cnt = (size_t)m->pN * m->pH * m->pW * m->in_ch;
+        RFI_CHECK_HIP(hipMemcpyAsync(dx, m->buf(m->mkGx), cnt * sizeof(float),
+                                     dx_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    });
+}
 int rfi_model_destroy(rfi_model* m) {
     return guarded([&] {
         if (!m) return;
@@ -615,10 +646,11 @@ const float* stage_input(rfi_model* m, const float* x, int x_mem, int n, int h, 
 const uint8_t* stage_labels(rfi_model* m, const uint8_t* y, int y_mem, int n, int h, int w) {
     if (y_mem == RFI_DEVICE) return y;
     uint8_t* st = reinterpret_cast<uint8_t*>(m->buf(m->lab_stage));
-    RFI_CHECK_HIP(hipMemcpyAsync(st, y, (size_t)n * h * w, hipMemcpyHostToDevice, m->ctx->stream));
+    RFI_CHECK_HIP(hipMemcpyAsync(st, y, (size_t)n * h * w * m->out_scale * m->out_scale, hipMemcpyHostToDevice, m->ctx->stream));
     return st;
 }
 void emit_logits(rfi_model* m, float* out, int out_mem, int n, int h, int w, bool nchw) {
+    h *= m->out_scale; w *= m->out_scale;         // (the mask head's output map is twice its input map)
     const size_t cnt = (size_t)n * h * w * m->out_ch;
     const float* src = m->buf(m->head_sigmoid ? m->probs : m->logits);   // the model's OUTPUT
     if (nchw && m->out_ch > 1) {
@@ -770,7 +802,7 @@ int rfi_model_eval_batch(rfi_model* m, const float* x, int x_mem, const uint8_t*
         const float* xd = stage_input(m, x, x_mem, n, h, w, false);
         const uint8_t* yd = stage_labels(m, labels, labels_mem, n, h, w);
         m->forward(xd, n, h, w, m->training);
-        const int64_t cnt = (int64_t)n * h * w;
+        const int64_t cnt = (int64_t)n * h * w * m->out_scale * m->out_scale;
         uint8_t* mask = reinterpret_cast<uint8_t*>(m->buf(m->out_stage));      // cnt bytes fit (cnt floats)
         // evaluate_model.py:44-47 thresholds sigmoid(model output), whatever the model returns
         launch_threshold(m->ctx, m->buf(m->head_sigmoid ? m->probs : m->logits), cnt, threshold, mask);
@@ -824,7 +856,7 @@ int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t h
             n = M * ((size_t)m->feat << (idx - 1)) * chmul;
         };
         const size_t Mb = (size_t)m->pN * (m->pH >> D) * (m->pW >> D), Cb = (size_t)m->feat << D;
-        const size_t M1 = (size_t)m->pN * m->pH * m->pW;
+        const size_t M1 = (size_t)m->pN * m->pH * m->pW * m->out_scale * m->out_scale;     // pixels of the OUTPUT map
         if (base == "encY1") level(m->encY1, 1);
         else if (base == "encY2") level(m->encY2, 1);
         else if (base == "decY1") level(m->decY1, 1);
@@ -861,6 +893,13 @@ int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, 
         // 2*M*K*N over every conv / convT / head, each layer evaluated once
         double f = 0, stem = 0;
         const int D = m->depth;
+        if (m->arch == 3) {             // mask head: L 3x3 convs at the RoI resolution, the transposed conv, the 1x1 head at 2x
+            const double M = (double)n * h * w, C = m->in_ch;
+            f = m->depth * 2.0 * M * 9.0 * C * C + 2.0 * M * 4.0 * C * C + 2.0 * 4.0 * M * C * m->out_ch;
+            if (fwd) *fwd = f;
+            if (step) *step = 3.0 * f;  // the input gradient is computed too (it feeds the RoIAlign adjoint)
+            return;
+        }
         if (m->arch == 1) {             // 3-layer CNN: two 3x3 convs at full resolution + the 1x1 head
             const double M = (double)n * h * w;
             stem = 2.0 * M * 9.0 * m->convs[0].cin * m->convs[0].cout;

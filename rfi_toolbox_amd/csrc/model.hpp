@@ -86,7 +86,8 @@ struct rfi_model {
     rfi_ctx* ctx = nullptr;
     int in_ch = 0, out_ch = 0, feat = 0, depth = 0;
     int arch = 0;                     // 0: U-Net (models/unet.py), 1: 3-layer CNN (depth == 0),
-                                      // 2: U-Net with a ResNet-18-style encoder (model_resnet.cpp)
+                                      // 2: U-Net with a ResNet-18-style encoder (model_resnet.cpp),
+                                      // 3: Mask R-CNN's per-RoI mask head (model_mask.cpp; depth = conv layers)
     int i_bott = 0;                   // index of the bottleneck's first conv in `convs` (decoder convs follow it)
     bool training = true;
     float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
@@ -144,6 +145,16 @@ struct rfi_model {
     void reset_channel_state();       // running stats 0/1, BN-less layers: scale 1, shift 0
     float* buf(int i) { return bufs[i].p; }
     int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
+
+    // ---- per-RoI mask head (model_mask.cpp; arch 3): depth conv3x3+ReLU layers, a transposed conv + ReLU, a 1x1 head.
+    // The output map is out_scale (= 2) times the input map in each direction
+    int out_scale = 1;
+    std::vector<int> mkY, mkG;
+    int mkU = -1, mkGU = -1, mkGx = -1;
+    void build_mask();
+    void prepare_mask(int n, int h, int w);
+    void forward_mask(const float* x_dev, int n, int h, int w);
+    void backward_mask(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w);
 
     // ---- ResNet-18-style encoder (model_resnet.cpp): stem + 4 stages of 2 BasicBlocks
     struct ResBlock {

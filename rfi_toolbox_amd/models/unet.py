@@ -98,6 +98,7 @@ class HipSegmenter:
     ``_create(ctx)`` (the C-ABI constructor) and ``_first_key`` (to recognise wrapped checkpoints)."""
 
     _first_key = ""
+    _out_scale = 1                   # output map = _out_scale x input map (2 for the mask head)
 
     def _create(self, ctx):          # -> c_void_p model handle
         raise NotImplementedError
@@ -251,7 +252,8 @@ class HipSegmenter:
         if c != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {c}")
         ptr, mem, keep = as_pointer(x, np.float32, self.ctx)
-        out = np.empty((n, self.out_channels, h, w) if nchw else (n, h, w, self.out_channels), dtype=np.float32)
+        ho, wo = h * self._out_scale, w * self._out_scale
+        out = np.empty((n, self.out_channels, ho, wo) if nchw else (n, ho, wo, self.out_channels), dtype=np.float32)
         fn = lib.rfi_model_forward_nchw if nchw else lib.rfi_model_forward_nhwc
         check(fn(self._h, C.c_void_p(ptr), mem, n, h, w, out.ctypes.data_as(C.c_void_p), HOST))
         del keep
@@ -286,7 +288,8 @@ class HipSegmenter:
         if c != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {c}")
         mshape = tuple(mask.shape)
-        if mshape not in ((n, h, w), (n, 1, h, w), (n, h, w, 1)):
+        ho, wo = h * self._out_scale, w * self._out_scale
+        if mshape not in ((n, ho, wo), (n, 1, ho, wo), (n, ho, wo, 1)):
             raise ValueError(f"mask shape {mshape} does not match data {shape}")
         xp, xm, k1 = as_pointer(data, np.float32, self.ctx)
         yp, ym, k2 = as_pointer(mask, np.uint8, self.ctx)

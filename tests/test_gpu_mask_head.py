@@ -1,0 +1,134 @@
+"""-m gpu: the per-RoI mask branch of Mask R-CNN (BASELINE.json configs[3]) on MI355X against
+oracle/mask_head_ref.py (the same layers as plain torch.nn modules; parity unpinned by the reference, which has no
+detector), and the whole branch -- RoIAlign -> mask head -> BCE -> gradients back into the feature map -- against the
+NumPy RoIAlign oracle chained with the torch head."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detection_ref, mask_head_ref as mref, unet_ref
+from rfi_toolbox_amd.models import MaskHead
+from rfi_toolbox_amd.models import detection_ops as ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(c, r, s, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(r, s, s, c, generator=g)
+    y = (torch.rand(r, 2 * s, 2 * s, generator=g) > 0.6).to(torch.uint8)
+    return x, y, unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1)
+
+
+def test_state_dict_init_and_forward():
+    torch.manual_seed(5)
+    m = MaskHead(16, 1, 4)
+    want = mref.init_state(16, 1, 4, seed=5)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(want.keys())
+    for k in want:
+        assert torch.equal(sd[k], want[k]), k
+    x, _, xo, _ = _case(16, 5, 14, 6)
+    got = m.eval()(xo)
+    ref = mref.forward(want, xo)
+    assert got.shape == (5, 1, 28, 28)
+    np.testing.assert_allclose(got.numpy(), ref.detach().numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()) + 1e-6)
+    np.testing.assert_allclose(m.forward_nhwc(x.numpy())[..., 0], ref.detach().numpy()[:, 0], rtol=0,
+                               atol=2e-5 * float(ref.abs().max()) + 1e-6)
+    with pytest.raises(ValueError):
+        MaskHead(10, 1)
+    with pytest.raises(ValueError):
+        m.train_step(x, torch.zeros(5, 14, 14, dtype=torch.uint8))       # labels live on the 2x map
+
+
+@pytest.mark.parametrize("mode,c,r,s", [("float32", 16, 6, 14), ("float32_mfma", 16, 6, 14), ("float32", 64, 32, 14), ("float32", 256, 8, 14)])
+def test_gradients_vs_oracle(mode, c, r, s):
+    st = mref.init_state(c, 1, 4, seed=11)
+    x, y, xo, yo = _case(c, r, s, 12)
+    l32, lg32, g32, gx32 = mref.loss_and_grads(st, xo, yo)
+    st64 = OrderedDict((k, v.double()) for k, v in st.items())
+    _, _, g64, gx64 = mref.loss_and_grads(st64, xo.double(), yo.double())
+    m = MaskHead(c, 1, 4).load_state_dict(st).train().set_compute_dtype(mode)
+    loss = m.forward_backward(x, y)
+    assert loss == pytest.approx(float(l32), abs=5e-6)
+    want = lg32.permute(0, 2, 3, 1).reshape(-1).numpy()
+    assert np.abs(m.debug_tensor("logits") - want).max() <= 1e-5 * max(1.0, float(np.abs(want).max()))
+    got_all = {k: m.grad(k) for k in g64}
+    got_all["input"] = m.input_grad((r, s, s, c))
+    g64 = dict(g64, input=gx64.permute(0, 2, 3, 1))
+    g32 = dict(g32, input=gx32.permute(0, 2, 3, 1))
+    for k, w64 in g64.items():
+        w64 = w64.numpy().ravel()
+        nrm = np.linalg.norm(w64) + 1e-30
+        rel_ref = np.linalg.norm(g32[k].numpy().ravel() - w64) / nrm
+        rel_hip = np.linalg.norm(got_all[k].ravel() - w64) / nrm
+        # (plain ReLUs on conv outputs, no BatchNorm: threshold flips are rare; 1e-3 covers one)
+        assert rel_hip <= max(4 * rel_ref, 1e-3), (k, rel_hip, rel_ref)
+
+
+def test_three_training_steps_vs_oracle():
+    c, r, s = 16, 8, 14
+    st = mref.init_state(c, 1, 4, seed=21)
+    x, y, xo, yo = _case(c, r, s, 22)
+    m = MaskHead(c, 1, 4).load_state_dict(st).train()
+    ost = OrderedDict((k, v.clone()) for k, v in st.items())
+    adam = unet_ref.new_adam_state(ost)
+    for step in range(3):
+        ref = mref.train_step(ost, adam, xo, yo, lr=1e-3, weight_decay=1e-5, clip=1.0)
+        loss = m.train_step(x, y, lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+        assert loss == pytest.approx(ref["loss"], abs=2e-5 * (step + 1)), step
+    sd = m.state_dict()
+    for k, v in ost.items():
+        np.testing.assert_allclose(sd[k].numpy(), v.numpy(), rtol=0, atol=5e-4, err_msg=k)
+    tp, fp, fn = m.eval_batch(x, y)
+    pred = (mref.forward(ost, xo) > 0).numpy()[:, 0]
+    yt = y.numpy() > 0
+    assert abs(tp - int((pred & yt).sum())) <= 3 and abs(fp - int((pred & ~yt).sum())) <= 3 and abs(fn - int((~pred & yt).sum())) <= 3
+
+
+def test_bf16_operand_mode():
+    c, r, s = 32, 16, 14
+    st = mref.init_state(c, 1, 4, seed=31)
+    x, y, xo, yo = _case(c, r, s, 32)
+    l32, _, g32, _ = mref.loss_and_grads(st, xo, yo)
+    with unet_ref.bf16_operands():
+        lb, _, gb, gxb = mref.loss_and_grads(st, xo, yo)
+    m = MaskHead(c, 1, 4).load_state_dict(st).train().set_compute_dtype("bfloat16")
+    loss = m.forward_backward(x, y)
+    assert loss == pytest.approx(float(lb), rel=2e-3)
+    for k, g in gb.items():
+        g = g.numpy().ravel()
+        nrm = np.linalg.norm(g) + 1e-30
+        rel_same = np.linalg.norm(m.grad(k).ravel() - g) / nrm
+        rel_arith = np.linalg.norm(g32[k].numpy().ravel() - g) / nrm
+        assert rel_same <= max(1.1 * rel_arith, 1e-2), (k, rel_same, rel_arith)
+
+
+def test_mask_branch_end_to_end():
+    """features -> RoIAlign (14 x 14, sampling 2) -> mask head -> BCE against per-RoI targets -> gradient of the
+    feature map, every stage on the GPU, against the NumPy RoIAlign oracle chained with the torch head."""
+    rng = np.random.default_rng(3)
+    n, size, c, scale = 2, 32, 16, 0.25
+    feats = rng.standard_normal((n, size, size, c)).astype(np.float32)
+    rois = np.array([[0, 4, 4, 60, 70], [1, 20, 10, 90, 100], [0, 0, 0, 128, 128], [1, 50.5, 40.25, 75, 61], [0, 100, 90, 140, 131],
+                     [1, 8, 8, 24, 24]], dtype=np.float32)
+    r = len(rois)
+    target = (rng.random((r, 28, 28)) > 0.5).astype(np.uint8)
+    st = mref.init_state(c, 1, 4, seed=41)
+    # oracle chain
+    roi_feats = detection_ref.roi_align(feats, rois, scale, (14, 14), 2, False)
+    xo = torch.from_numpy(np.ascontiguousarray(roi_feats.transpose(0, 3, 1, 2))).float()
+    l_ref, _, g_ref, gx_ref = mref.loss_and_grads(st, xo, torch.from_numpy(target).float().unsqueeze(1))
+    dfeat_ref = detection_ref.roi_align_backward(gx_ref.permute(0, 2, 3, 1).numpy().astype(np.float64), feats.shape, rois, scale,
+                                                 (14, 14), 2, False)
+    # HIP chain
+    m = MaskHead(c, 1, 4).load_state_dict(st).train()
+    rf = ops.roi_align(feats, rois, scale, (14, 14), 2, False)
+    loss = m.forward_backward(rf, target)
+    dfeat = ops.roi_align_backward(m.input_grad(rf.shape), feats.shape, rois, scale, 2, False)
+    assert loss == pytest.approx(float(l_ref), abs=1e-5)
+    assert np.abs(dfeat - dfeat_ref).max() <= 2e-4 * np.abs(dfeat_ref).max()
+    k = "mask_fcn1.weight"
+    assert np.linalg.norm(m.grad(k) - g_ref[k].numpy()) <= 2e-4 * np.linalg.norm(g_ref[k].numpy())

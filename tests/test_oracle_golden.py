@@ -266,3 +266,29 @@ def test_unet_variants_oracle_matches_reference(golden_dir, name, kw):
         want = g[f"grad1/{k}"]
         got = (gr * r["clip_coef"]).numpy()
         assert np.linalg.norm(got - want) <= 1e-4 * np.linalg.norm(want) + 1e-9, k
+
+
+def test_builder_defined_oracles_match_their_torch_modules():
+    """The oracles of models the reference does not contain restate plain torch.nn modules:
+    functional forward == module forward, state_dict order == module order."""
+    import torch
+
+    from oracle import mask_head_ref, resnet_unet_ref
+    st = resnet_unet_ref.init_state(3, 1, 8, seed=1)
+    mod = resnet_unet_ref.ResNetUNet(3, 1, 8)
+    mod.load_state_dict(st)
+    x = torch.randn(2, 3, 32, 32)
+    assert float((mod.eval()(x) - resnet_unet_ref.forward(st, x)).abs().max()) == 0.0
+    bu = {}
+    out = resnet_unet_ref.forward(st, x, training=True, buffer_updates=bu)
+    assert float((mod.train()(x) - out).abs().max()) <= 5e-6
+    sd = mod.state_dict()
+    assert max(float((sd[k].float() - bu[k].float()).abs().max()) for k in bu) <= 1e-6
+    st = mask_head_ref.init_state(8, 1, 4, seed=2)
+    mh = mask_head_ref.MaskHeadModule(8, 1, 4)
+    mh.load_state_dict(st)
+    x = torch.randn(3, 8, 14, 14)
+    assert float((mh(x) - mask_head_ref.forward(st, x)).abs().max()) == 0.0
+    y = (torch.rand(3, 1, 28, 28) > 0.5).float()
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(mh(x), y)
+    assert float(loss) == pytest.approx(float(mask_head_ref.mask_loss(mask_head_ref.forward(st, x), y)), abs=1e-7)
