@@ -376,6 +376,10 @@ def main():
         fwd_flops, step_flops = model.algorithmic_flops(B, S, S)
         n_params = model.num_parameters()
 
+    if world > 1:                     # leave the RCCL communicator in an orderly way (every rank, before anyone exits)
+        ctx.synchronize()
+        D.barrier()
+        ctx.comm_destroy()
     if rank != 0:
         return
 

@@ -151,6 +151,8 @@ int rfi_ctx_synchronize(rfi_ctx* ctx) {
     return guarded([&] {
         ctx->activate();
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->side_stream) RFI_CHECK_HIP(hipStreamSynchronize(ctx->side_stream));
+        if (ctx->comm_stream) RFI_CHECK_HIP(hipStreamSynchronize(ctx->comm_stream));
     });
 }
 int rfi_ctx_stream(rfi_ctx* ctx, void** s) {
@@ -989,6 +991,7 @@ int rfi_comm_destroy(rfi_ctx* ctx) {
         if (ctx->nccl_comm) {
             ctx->activate();
             hipStreamSynchronize(ctx->stream);
+            if (ctx->comm_stream) hipStreamSynchronize(ctx->comm_stream);
             nccl_check(g_nccl.CommDestroy(ctx->nccl_comm), "ncclCommDestroy");
             ctx->nccl_comm = nullptr;
             ctx->world = 1;
