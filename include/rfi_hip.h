@@ -101,6 +101,16 @@ int rfi_unet_resnet_create(rfi_ctx* ctx, int in_channels, int out_channels, int 
  * features of the last backward pass ([R, h, w, C]) for rfi_op_roi_align_backward. */
 int rfi_mask_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int out_channels, rfi_model** out);
 int rfi_model_input_grad(rfi_model* m, float* dx, int dx_mem);
+/* The RPN head (Faster R-CNN; SURVEY 8a A11, not in the reference): conv_layers x [Conv3x3(C->C, p1)+bias -> ReLU] -> ONE
+ * Conv1x1(C -> 5 A): per pixel A objectness logits followed by A x 4 box deltas (anchor-major), i.e. cls_logits and
+ * bbox_pred of the usual implementation stacked.  Entries: conv.{i}.0.weight/bias, head.weight/bias.  forward gives
+ * [N, H, W, 5 A]; its loss needs per-anchor targets and lives outside the model: rfi_op_rpn_loss produces
+ * d(loss)/d(head output), rfi_model_backward_dlogits (after a forward pass on the same input) turns it into parameter
+ * gradients and the input gradient (rfi_model_input_grad), rfi_train_apply steps the optimiser.  Also valid for the
+ * mask head. */
+int rfi_rpn_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int anchors_per_pixel, rfi_model** out);
+int rfi_model_backward_dlogits(rfi_model* m, const float* x, int x_mem, const float* dlogits, int dlogits_mem, int n, int h,
+                               int w);
 int rfi_model_destroy(rfi_model* m);
 /* variants of models/unet.py:120-268 on the same graph: UNetDifferentActivation's activation
  * (0 = ReLU, 0 < s < 1 = LeakyReLU(negative_slope=s), after every BatchNorm) and UNetOverfit's head
@@ -330,6 +340,20 @@ int rfi_op_roi_align(rfi_ctx* ctx, const float* x, int n, int h, int w, int c, c
 int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, const float* rois,
                               int r, float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
                               float* dx);
+/* Region-proposal pieces (not in the reference: Faster R-CNN's box parameterisation and RPN loss, greedy IoU
+ * NMS, oracle/detection_ref.py).  All tensors device pointers unless named *_host.
+ * box_decode: boxes[n][4] = decode(anchors[n_anchors][4] repeating, deltas[n][4]) (weights 1, dw/dh <= log(1000/16)),
+ *   clipped to [0, clip_w] x [0, clip_h] when clip_w > 0.
+ * nms: boxes sorted by descending score -> indices kept by greedy suppression at IoU > iou_threshold (host array of n ints).
+ * rpn_loss: head output [pixels][5 A] (A objectness logits, then A x 4 deltas), labels int8 [pixels A] in {1, 0, -1 =
+ *   not sampled}, regression targets [pixels A][4]; objectness = sum BCE over sampled / num_sampled, box = sum smooth-L1
+ *   (beta) over positives / num_sampled; dhead = gradient of (objectness + box) w.r.t. the head output. */
+int rfi_op_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,
+                      float clip_w, float* boxes);
+int rfi_op_nms(rfi_ctx* ctx, const float* boxes_sorted, int n, float iou_threshold, int32_t* keep_host, int* n_keep);
+int rfi_op_rpn_loss(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
+                    const float* targets, int64_t num_sampled, float beta, float* dhead, float* loss_objectness,
+                    float* loss_box);
 int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out);
 int rfi_op_fpn_merge_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, float* dtop);
 int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean, float* var_biased);

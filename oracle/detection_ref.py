@@ -106,3 +106,70 @@ def fpn_merge_backward_top(dout):
     pad = np.zeros((N, 2 * Ht, 2 * Wt, C))
     pad[:, :H, :W] = dout
     return pad.reshape(N, Ht, 2, Wt, 2, C).sum(axis=(2, 4))
+
+
+# ---------------------------------------------------------------- region proposals (Faster R-CNN conventions)
+def decode_boxes(anchors, deltas, image_size=None):
+    """float64: boxes = decode(anchors (A, 4) repeating, deltas (k A, 4)), weights 1, dw / dh clamped at log(1000/16)."""
+    anchors = np.asarray(anchors, np.float64).reshape(-1, 4)
+    deltas = np.asarray(deltas, np.float64).reshape(-1, 4)
+    a = np.tile(anchors, (len(deltas) // len(anchors), 1))
+    w, h = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+    cx, cy = a[:, 0] + 0.5 * w, a[:, 1] + 0.5 * h
+    dw, dh = np.minimum(deltas[:, 2], np.log(1000.0 / 16)), np.minimum(deltas[:, 3], np.log(1000.0 / 16))
+    pcx, pcy, pw, ph = deltas[:, 0] * w + cx, deltas[:, 1] * h + cy, np.exp(dw) * w, np.exp(dh) * h
+    b = np.stack([pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph], 1)
+    if image_size is not None:
+        b[:, 0::2] = np.clip(b[:, 0::2], 0, image_size[1])
+        b[:, 1::2] = np.clip(b[:, 1::2], 0, image_size[0])
+    return b
+
+
+def box_iou(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    iw = np.clip(np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0]), 0, None)
+    ih = np.clip(np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1]), 0, None)
+    inter = iw * ih
+    return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+
+def nms(boxes, scores, thr):
+    """Greedy NMS: visit boxes in descending (stable) score order, keep a box unless a kept one overlaps it by IoU > thr."""
+    boxes = np.asarray(boxes, np.float32).astype(np.float64)
+    order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
+    if len(order) == 0:
+        return np.zeros(0, np.int64)
+    iou = box_iou(boxes[order], boxes[order])
+    alive = np.ones(len(order), bool)
+    keep = []
+    for i in range(len(order)):
+        if not alive[i]:
+            continue
+        keep.append(order[i])
+        alive[i + 1:] &= ~(iou[i, i + 1:] > thr)
+    return np.array(keep, np.int64)
+
+
+def rpn_loss(head, labels, targets, A, beta=1.0 / 9):
+    """float64 loss terms and gradient of their sum w.r.t. head (P, 5 A); labels (P A,) in {1, 0, -1}; targets (P A, 4)."""
+    head = np.asarray(head, np.float64).reshape(-1, 5 * A)
+    P = len(head)
+    lab = np.asarray(labels).reshape(P, A)
+    tgt = np.asarray(targets, np.float64).reshape(P, A, 4)
+    x = head[:, :A]
+    d = head[:, A:].reshape(P, A, 4)
+    n = max(int((lab >= 0).sum()), 1)
+    samp, pos = lab >= 0, lab > 0
+    t = pos.astype(np.float64)
+    bce = np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x)))
+    l_obj = (bce * samp).sum() / n
+    e = (d - tgt) * pos[..., None]
+    ae = np.abs(e)
+    sl1 = np.where(ae < beta, 0.5 * e * e / beta, ae - 0.5 * beta)
+    l_box = sl1.sum() / n
+    g = np.zeros_like(head)
+    g[:, :A] = (1.0 / (1.0 + np.exp(-x)) - t) * samp / n
+    g[:, A:] = (np.where(ae < beta, e / beta, np.sign(e)) / n).reshape(P, 4 * A)
+    return l_obj, l_box, g

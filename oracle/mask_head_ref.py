@@ -72,3 +72,48 @@ def loss_and_grads(state, x_nchw, y):
 
 def train_step(state, adam, x_nchw, y, **kw):
     return unet_ref.train_step(state, adam, x_nchw, y, forward_fn=forward, loss_fn=mask_loss, **kw)
+
+
+# ---------------------------------------------------------------- RPN head (Faster R-CNN; same status: builder-defined)
+class RPNHeadModule(nn.Module):
+    """conv (3x3 + ReLU) x layers, cls_logits (A), bbox_pred (4 A, anchor-major) -- torchvision's RPNHead layer names."""
+
+    def __init__(self, in_channels=256, num_anchors=4, layers=1):
+        super().__init__()
+        self.conv = nn.Sequential(*[nn.Sequential(nn.Conv2d(in_channels, in_channels, 3, padding=1), nn.ReLU()) for _ in range(layers)])
+        self.cls_logits = nn.Conv2d(in_channels, num_anchors, 1)
+        self.bbox_pred = nn.Conv2d(in_channels, 4 * num_anchors, 1)
+
+    def forward(self, x):
+        t = self.conv(x)
+        return self.cls_logits(t), self.bbox_pred(t)
+
+
+def rpn_init_state(in_channels=256, num_anchors=4, layers=1, seed=0):
+    torch.manual_seed(seed)
+    return OrderedDict((k, v.detach().clone()) for k, v in RPNHeadModule(in_channels, num_anchors, layers).state_dict().items())
+
+
+def rpn_forward(state, x_nchw):
+    """-> head output (N, H, W, 5 A): A objectness logits then A x 4 deltas per pixel (the library's layout)."""
+    h, i = x_nchw, 0
+    while f"conv.{i}.0.weight" in state:
+        h = torch.relu(unet_ref._conv3x3(h, state[f"conv.{i}.0.weight"], state[f"conv.{i}.0.bias"]))
+        i += 1
+    cls = F.conv2d(h, state["cls_logits.weight"], state["cls_logits.bias"])
+    box = F.conv2d(h, state["bbox_pred.weight"], state["bbox_pred.bias"])
+    return torch.cat([cls, box], 1).permute(0, 2, 3, 1)
+
+
+def rpn_loss_torch(out, labels, targets, A, beta=1.0 / 9):
+    """The RPN loss (objectness BCE over sampled anchors + smooth L1 over positives, both / num_sampled) in torch ops."""
+    P = out.shape[0] * out.shape[1] * out.shape[2]
+    o = out.reshape(P, 5 * A)
+    lab = torch.as_tensor(labels).reshape(P, A)
+    tgt = torch.as_tensor(targets, dtype=o.dtype).reshape(P, A, 4)
+    n = max(int((lab >= 0).sum()), 1)
+    x, d = o[:, :A], o[:, A:].reshape(P, A, 4)
+    samp, pos = lab >= 0, lab > 0
+    l_obj = F.binary_cross_entropy_with_logits(x[samp], pos[samp].to(o.dtype), reduction="sum") / n
+    l_box = F.smooth_l1_loss(d[pos], tgt[pos], beta=beta, reduction="sum") / n
+    return l_obj, l_box

@@ -66,6 +66,8 @@ _PROTOS = {
     "rfi_unet_resnet_create": (_i, [_vp, _i, _i, _i, _pvp]),
     "rfi_mask_head_create": (_i, [_vp, _i, _i, _i, _pvp]),
     "rfi_model_input_grad": (_i, [_vp, _vp, _i]),
+    "rfi_rpn_head_create": (_i, [_vp, _i, _i, _i, _pvp]),
+    "rfi_model_backward_dlogits": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i]),
     "rfi_model_set_activation": (_i, [_vp, _f]),
     "rfi_model_set_compute_dtype": (_i, [_vp, _i]),
     "rfi_model_set_head_sigmoid": (_i, [_vp, _i]),
@@ -102,6 +104,9 @@ _PROTOS = {
     "rfi_op_roi_align": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _i, _i, _i, _i, _vp]),
     "rfi_op_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _i, _i, _i, _i, _vp]),
     "rfi_op_fpn_merge": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rfi_op_box_decode": (_i, [_vp, _vp, _i64, _vp, _i64, _f, _f, _vp]),
+    "rfi_op_nms": (_i, [_vp, _vp, _i, _f, _vp, _pi]),
+    "rfi_op_rpn_loss": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _f, _vp, _pf, _pf]),
     "rfi_op_fpn_merge_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rfi_comm_allreduce_sum_f32": (_i, [_vp, _vp, _i64]),
     "rfi_model_allreduce_grads": (_i, [_vp]),

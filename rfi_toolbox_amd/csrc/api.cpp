@@ -340,9 +340,30 @@ int rfi_mask_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int out
         *out = m;
     });
 }
+int rfi_rpn_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int anchors_per_pixel, rfi_model** out) {
+    return guarded([&] {
+        RFI_REQUIRE(ctx && out, "rfi_rpn_head_create: null argument");
+        RFI_REQUIRE(anchors_per_pixel > 0 && anchors_per_pixel % 4 == 0, "RPNHead: anchors per pixel must be a positive multiple of 4");
+        auto* m = new rfi_model();
+        m->ctx = ctx;
+        m->arch = 4;
+        m->in_ch = in_channels;
+        m->out_ch = 5 * anchors_per_pixel;
+        m->feat = in_channels;
+        m->depth = conv_layers;
+        try {
+            m->build();
+        } catch (...) {
+            m->ctx = nullptr;
+            delete m;
+            throw;
+        }
+        *out = m;
+    });
+}
 int rfi_model_input_grad(rfi_model* m, float* dx, int dx_mem) {
     return guarded([&] {
-        RFI_REQUIRE(m->arch == 3, "input_grad: only the mask head computes the gradient w.r.t. its input");
+        RFI_REQUIRE(m->arch == 3 || m->arch == 4, "input_grad: only the mask head computes the gradient w.r.t. its input");
         RFI_REQUIRE(m->pN > 0 && dx, "input_grad: no backward pass has run");
         m->ctx->activate();
         const size_t cnt = (size_t)m->pN * m->pH * m->pW * m->in_ch;
@@ -772,6 +793,22 @@ int rfi_train_step_async(rfi_model* m, const float* x_dev, const uint8_t* labels
         exchange_and_apply(m, *hp);
     });
 }
+int rfi_model_backward_dlogits(rfi_model* m, const float* x, int x_mem, const float* dlogits, int dlogits_mem, int n, int h,
+                               int w) {
+    return guarded([&] {
+        RFI_REQUIRE(m->arch == 3 || m->arch == 4, "backward_dlogits: mask / RPN heads only");
+        RFI_REQUIRE(m->pN == n && m->pH == h && m->pW == w, "backward_dlogits: run the forward pass on this input first");
+        m->ctx->activate();
+        const float* xd = stage_input(m, x, x_mem, n, h, w, false);
+        const size_t cnt = (size_t)n * h * w * m->out_scale * m->out_scale * m->out_ch;
+        RFI_CHECK_HIP(hipMemcpyAsync(m->buf(m->dlogits), dlogits, cnt * sizeof(float),
+                                     dlogits_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->ctx->stream));
+        struct Flag { rfi_model* m; ~Flag() { m->ext_dlogits = false; } } flag{m};
+        m->ext_dlogits = true;
+        m->backward(xd, nullptr, n, h, w);
+        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    });
+}
 int rfi_model_last_loss(rfi_model* m, float* loss_out, float* grad_norm_out) {
     return guarded([&] {
         m->ctx->activate();
@@ -895,9 +932,9 @@ int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, 
         // 2*M*K*N over every conv / convT / head, each layer evaluated once
         double f = 0, stem = 0;
         const int D = m->depth;
-        if (m->arch == 3) {             // mask head: L 3x3 convs at the RoI resolution, the transposed conv, the 1x1 head at 2x
-            const double M = (double)n * h * w, C = m->in_ch;
-            f = m->depth * 2.0 * M * 9.0 * C * C + 2.0 * M * 4.0 * C * C + 2.0 * 4.0 * M * C * m->out_ch;
+        if (m->arch == 3 || m->arch == 4) {   // mask / RPN head: L 3x3 convs, (the transposed conv,) the 1x1 head
+            const double M = (double)n * h * w, C = m->in_ch, s2 = (double)m->out_scale * m->out_scale;
+            f = m->depth * 2.0 * M * 9.0 * C * C + (m->arch == 3 ? 2.0 * M * 4.0 * C * C : 0.0) + 2.0 * s2 * M * C * m->out_ch;
             if (fwd) *fwd = f;
             if (step) *step = 3.0 * f;  // the input gradient is computed too (it feeds the RoIAlign adjoint)
             return;
@@ -1575,6 +1612,52 @@ int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int
     return guarded([&] {
         ctx->activate();
         launch_roi_align_bwd(ctx, dout, n, h, w, c, rois, r, spatial_scale, ph, pw, sampling_ratio, aligned != 0, dx);
+    });
+}
+int rfi_op_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,
+                      float clip_w, float* boxes) {
+    return guarded([&] {
+        ctx->activate();
+        launch_box_decode(ctx, anchors, n_anchors, deltas, n, clip_h, clip_w, boxes);
+    });
+}
+int rfi_op_nms(rfi_ctx* ctx, const float* boxes_sorted, int n, float iou_threshold, int32_t* keep_host, int* n_keep) {
+    return guarded([&] {
+        RFI_REQUIRE(keep_host && n_keep, "nms: null output");
+        ctx->activate();
+        if (n <= 0) { *n_keep = 0; return; }
+        const int words = (n + 63) / 64;
+        auto* mask = static_cast<unsigned long long*>(ctx->alloc((size_t)n * words * 8));
+        struct Free { rfi_ctx* c; void* p; ~Free() { try { c->release(p); } catch (...) {} } } fr{ctx, mask};
+        launch_nms_mask(ctx, boxes_sorted, n, iou_threshold, mask);
+        std::vector<unsigned long long> h((size_t)n * words), removed(words, 0ull);
+        RFI_CHECK_HIP(hipMemcpyAsync(h.data(), mask, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        int k = 0;                                   // greedy scan in score order: keep i unless a kept box suppressed it
+        for (int i = 0; i < n; ++i) {
+            if (removed[i / 64] >> (i % 64) & 1ull) continue;
+            keep_host[k++] = i;
+            const unsigned long long* row = h.data() + (size_t)i * words;
+            for (int w = i / 64; w < words; ++w) removed[w] |= row[w];
+        }
+        *n_keep = k;
+    });
+}
+int rfi_op_rpn_loss(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
+                    const float* targets, int64_t num_sampled, float beta, float* dhead, float* loss_objectness,
+                    float* loss_box) {
+    return guarded([&] {
+        ctx->activate();
+        double* ws = static_cast<double*>(ctx->alloc(rpn_loss_ws_doubles() * 8 + 16));
+        struct Free { rfi_ctx* c; void* p; ~Free() { try { c->release(p); } catch (...) {} } } fr{ctx, ws};
+        float* out2 = reinterpret_cast<float*>(ws + rpn_loss_ws_doubles());
+        launch_rpn_loss(ctx, head, pixels, anchors_per_pixel, reinterpret_cast<const signed char*>(labels), targets, num_sampled, beta,
+                        dhead, ws, out2);
+        float h2[2];
+        RFI_CHECK_HIP(hipMemcpyAsync(h2, out2, sizeof(h2), hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (loss_objectness) *loss_objectness = h2[0];
+        if (loss_box) *loss_box = h2[1];
     });
 }
 int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out) {

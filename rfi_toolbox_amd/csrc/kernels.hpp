@@ -283,6 +283,19 @@ void launch_roi_align_bwd(rfi_ctx* ctx, const float* dout, int N, int H, int W, 
 void launch_fpn_merge_fwd(rfi_ctx* ctx, const float* lateral, const float* top, int N, int H, int W, int C, float* out);
 void launch_fpn_merge_bwd_top(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, float* dtop);
 
+// ---------------------------------------------------------------- region proposals (rpn_kernels.hip)
+// boxes = decode(anchors, deltas) (box-coder weights 1, dw / dh clamped at log(1000/16)), clipped to [0, clip_w] x [0, clip_h]
+// when clip_w > 0; anchors [n_anchors][4] repeat over the n = k * n_anchors delta rows
+void launch_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,
+                       float clip_w, float* out);
+// suppression bit matrix [n][ceil(n / 64)] of boxes sorted by descending score (bit j of row i: j > i and IoU > thr)
+void launch_nms_mask(rfi_ctx* ctx, const float* boxes, int n, float thr, unsigned long long* mask);
+// RPN loss on a head output [P][5 A]: BCE on the sampled anchors + smooth L1 on the positives, both / num_sampled;
+// writes the gradient w.r.t. the head output and the two loss terms (device floats)
+size_t rpn_loss_ws_doubles();
+void launch_rpn_loss(rfi_ctx* ctx, const float* head, int64_t P, int A, const signed char* labels, const float* targets,
+                     int64_t num_sampled, float beta, float* dhead, double* partial_ws, float* loss2_dev);
+
 // ---------------------------------------------------------------- ResNet-style encoder pieces (resnet_kernels.hip)
 void launch_s2d(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, float* out);          // [N,H,W,C] -> [N,H/2,W/2,4C]
 void launch_d2s_add(rfi_ctx* ctx, const float* dxp, const float* ds, View extra, int N, int H, int W, int C, float* out);

@@ -66,7 +66,7 @@ void rfi_model::build() {
     if (const char* e = getenv("RFI_BN_FUSE")) fuse_bn_bwd = e[0] == '1';
     if (arch != 0) planesP = 0;                       // the plane data flow exists for the plain U-Net only
     if (arch == 1) return build_cnn3();
-    if (arch == 3) return build_mask();
+    if (arch == 3 || arch == 4) return build_mask();
     if (arch == 2) return build_resnet();
     RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
     RFI_REQUIRE(depth >= 1 && depth <= 6, "UNet: depth must be in [1,6]");
@@ -243,7 +243,7 @@ void rfi_model::prepare(int n, int h, int w) {
         side_seq = 0;
     }
     if (arch == 1) return prepare_cnn3(n, h, w);
-    if (arch == 3) return prepare_mask(n, h, w);
+    if (arch == 3 || arch == 4) return prepare_mask(n, h, w);
     const int div = 1 << depth;
     RFI_REQUIRE(h % div == 0 && w % div == 0,
                 "forward: H and W must be multiples of 2^depth (" + std::to_string(div) +
@@ -453,7 +453,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
     prepare(n, h, w);
     refresh_dgrad_weights();          // derived filter copies (dgrad layout, 3 x bf16 records) follow the parameters
     if (arch == 1) return forward_cnn3(x_dev, n, h, w);
-    if (arch == 3) return forward_mask(x_dev, n, h, w);
+    if (arch == 3 || arch == 4) return forward_mask(x_dev, n, h, w);
     if (planesP) return forward_planes(x_dev, n, h, w, train_mode);
     const int D = depth, IB = i_bott;
     View cur = network_input(x_dev, n, h, w);
@@ -663,7 +663,7 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
 }  // namespace
 
 void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
-    if (arch == 3) {
+    if (arch == 3 || arch == 4) {
         backward_mask(x_dev, labels_dev, n, h, w);
         bucket_ready(0, n_flat);
         return;

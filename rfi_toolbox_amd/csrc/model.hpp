@@ -87,7 +87,8 @@ struct rfi_model {
     int in_ch = 0, out_ch = 0, feat = 0, depth = 0;
     int arch = 0;                     // 0: U-Net (models/unet.py), 1: 3-layer CNN (depth == 0),
                                       // 2: U-Net with a ResNet-18-style encoder (model_resnet.cpp),
-                                      // 3: Mask R-CNN's per-RoI mask head (model_mask.cpp; depth = conv layers)
+                                      // 3: Mask R-CNN's per-RoI mask head (model_mask.cpp; depth = conv layers),
+                                      // 4: RPN head (the same stack without the transposed conv)
     int i_bott = 0;                   // index of the bottleneck's first conv in `convs` (decoder convs follow it)
     bool training = true;
     float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
@@ -149,6 +150,7 @@ struct rfi_model {
     // ---- per-RoI mask head (model_mask.cpp; arch 3): depth conv3x3+ReLU layers, a transposed conv + ReLU, a 1x1 head.
     // The output map is out_scale (= 2) times the input map in each direction
     int out_scale = 1;
+    bool ext_dlogits = false;         // backward from caller-provided dlogits (rfi_model_backward_dlogits)
     std::vector<int> mkY, mkG;
     int mkU = -1, mkGU = -1, mkGx = -1;
     void build_mask();

@@ -11,6 +11,12 @@
 // oracle/mask_head_ref.py holds the same layers as plain torch.nn modules (parity unpinned by the reference).  Only the
 // raw conv outputs are kept; ReLU is applied by the consumers' loads, as in model_cnn.cpp.  rfi_model_input_grad returns
 // the gradient w.r.t. x, which rfi_op_roi_align_backward scatters back into the feature map.
+//
+// arch 4, the RPN head (Ren et al. 2015), is the same stack without the transposed conv: Conv3x3(C -> C) + ReLU, then ONE
+// 1x1 conv with 5 A outputs per pixel = A objectness logits followed by A x 4 box deltas (cls_logits and bbox_pred of the
+// usual implementation stacked; models/rpn_head.py splits them at the state_dict boundary).  Its loss needs per-anchor
+// targets, so it lives outside the model: rfi_op_rpn_loss produces d(loss)/d(head output) and
+// rfi_model_backward_dlogits runs the backward pass from there.
 #include <algorithm>
 
 #include "model.hpp"
@@ -22,8 +28,9 @@ static size_t align4(size_t v) { return (v + 3) & ~size_t(3); }
 void rfi_model::build_mask() {
     RFI_REQUIRE(in_ch > 0 && in_ch % 4 == 0, "MaskHead: in_channels must be a positive multiple of 4 (16-byte NHWC pixels)");
     RFI_REQUIRE(out_ch > 0 && depth >= 1 && depth <= 8, "MaskHead: out_channels > 0, 1..8 conv layers");
+    const bool up = arch == 3;
     feat = in_ch;
-    out_scale = 2;
+    out_scale = up ? 2 : 1;
     loss_kind = 1;                // sigmoid focal loss with gamma = 0 and no alpha = plain mean BCE-with-logits
     focal_alpha = -1.0f;
     focal_gamma = 0.0f;
@@ -33,7 +40,7 @@ void rfi_model::build_mask() {
     size_t off = 0, chan_floats = 0, wd_floats = 0;
     for (int i = 0; i < L; ++i) {
         ConvBN c;
-        c.conv_name = "mask_fcn" + std::to_string(i + 1);
+        c.conv_name = up ? "mask_fcn" + std::to_string(i + 1) : "conv." + std::to_string(i) + ".0";
         c.has_bn = false;
         c.cin = c.cin_p = c.cout = C;
         c.w_off = off; off = align4(off + (size_t)9 * C * C);
@@ -43,7 +50,7 @@ void rfi_model::build_mask() {
         wd_floats += align4((size_t)9 * C * C);
         convs.push_back(c);
     }
-    {
+    if (up) {
         UpConv u;
         u.name = "conv5_mask";
         u.cin = u.cout = C;
@@ -73,7 +80,7 @@ void rfi_model::build_mask() {
         e.name = convs[i].conv_name + ".bias"; e.ndim = 1; e.dims[0] = C; e.kind = 2; e.which = 0;
         push(e);
     }
-    {
+    if (up) {
         Entry e;
         e.layer = 0;
         e.name = "conv5_mask.weight"; e.ndim = 4; e.dims[0] = C; e.dims[1] = C; e.dims[2] = 2; e.dims[3] = 2; e.kind = 1;
@@ -81,11 +88,14 @@ void rfi_model::build_mask() {
         e = Entry(); e.layer = 0;
         e.name = "conv5_mask.bias"; e.ndim = 1; e.dims[0] = C; e.kind = 2; e.which = 3;
         push(e);
-        e = Entry();
-        e.name = "mask_fcn_logits.weight"; e.ndim = 4; e.dims[0] = out_ch; e.dims[1] = C; e.dims[2] = 1; e.dims[3] = 1; e.kind = 6;
+    }
+    {
+        const std::string hn = up ? "mask_fcn_logits" : "head";
+        Entry e;
+        e.name = hn + ".weight"; e.ndim = 4; e.dims[0] = out_ch; e.dims[1] = C; e.dims[2] = 1; e.dims[3] = 1; e.kind = 6;
         push(e);
         e = Entry();
-        e.name = "mask_fcn_logits.bias"; e.ndim = 1; e.dims[0] = out_ch; e.kind = 2; e.which = 4;
+        e.name = hn + ".bias"; e.ndim = 1; e.dims[0] = out_ch; e.kind = 2; e.which = 4;
         push(e);
     }
 
@@ -107,7 +117,7 @@ void rfi_model::build_mask() {
         c.chan = chan_pool + co; co += align4((size_t)8 * c.cout);
         c.wd = wd_pool + wo; wo += align4((size_t)9 * c.cin_p * c.cout);
     }
-    ups[0].wd = wd_pool + wo;
+    if (up) ups[0].wd = wd_pool + wo;
     adam_step = 0;
     wd_dirty = true;
     x3_fresh = false;
@@ -126,10 +136,10 @@ void rfi_model::prepare_mask(int n, int h, int w) {
         x_stage = new_buf(); x_stage2 = new_buf(); x_pad = new_buf(); out_stage = new_buf();
         ws_red = new_buf(); ws_slab = new_buf(); lab_stage = new_buf();
     }
-    const size_t M = (size_t)n * h * w, M4 = 4 * M;
+    const size_t M = (size_t)n * h * w, M4 = (size_t)out_scale * out_scale * M;
     for (int i = 0; i < L; ++i) { bufs[mkY[i]].ensure(ctx, M * C); bufs[mkG[i]].ensure(ctx, M * C); }
-    bufs[mkU].ensure(ctx, M4 * C);
-    bufs[mkGU].ensure(ctx, M4 * C);
+    bufs[mkU].ensure(ctx, arch == 3 ? M4 * C : 16);
+    bufs[mkGU].ensure(ctx, arch == 3 ? M4 * C : 16);
     bufs[mkGx].ensure(ctx, M * C);
     bufs[logits].ensure(ctx, M4 * out_ch);
     bufs[dlogits].ensure(ctx, M4 * out_ch);
@@ -193,14 +203,14 @@ ConvArgs conv3x3_args(rfi_model* m, View in, InXform xf, const float* w, const f
 void rfi_model::forward_mask(const float* x_dev, int n, int h, int w) {
     refresh_dgrad_weights();
     const int L = depth, C = in_ch;
-    const int64_t M4 = (int64_t)4 * n * h * w;
+    const int64_t M4 = (int64_t)out_scale * out_scale * n * h * w;
     for (int i = 0; i < L; ++i) {
         ConvBN& c = convs[i];
         ConvArgs a = conv3x3_args(this, i == 0 ? View{x_dev, C} : View{buf(mkY[i - 1]), C}, i == 0 ? InXform{} : relu_of(convs[i - 1]),
                                   params + c.w_off, c.w3, params + c.b_off, buf(mkY[i]), C, n, h, w);
         launch_conv(ctx, a);
     }
-    {
+    if (arch == 3) {
         UpConv& u = ups[0];
         ConvArgs a;
         a.x = View{buf(mkY[L - 1]), C};
@@ -220,19 +230,23 @@ void rfi_model::forward_mask(const float* x_dev, int n, int h, int w) {
         launch_conv(ctx, a);
     }
     const ConvBN& cl = convs[L - 1];                  // (its scale = 1 / shift = 0 vectors serve the ReLU of U as well)
-    launch_head_fwd(ctx, buf(mkU), M4, C, cl.scale(), cl.shift(), params + head_w_off, params + head_b_off, out_ch, buf(logits));
+    launch_head_fwd(ctx, arch == 3 ? buf(mkU) : buf(mkY[L - 1]), M4, C, cl.scale(), cl.shift(), params + head_w_off, params + head_b_off,
+                    out_ch, buf(logits));
 }
 
 void rfi_model::backward_mask(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
     const int L = depth, C = in_ch;
-    const int64_t M = (int64_t)n * h * w, M4 = 4 * M;
+    const int64_t M = (int64_t)n * h * w, M4 = (int64_t)out_scale * out_scale * M;
     refresh_dgrad_weights();
-    if (loss_kind == 1) launch_focal_bwd(ctx, buf(logits), labels_dev, M4 * out_ch, focal_alpha, focal_gamma, buf(dlogits));
-    else launch_loss_bwd(ctx, buf(logits), labels_dev, M4 * out_ch, d_sums, buf(dlogits));
+    if (!ext_dlogits) {               // (rfi_model_backward_dlogits: the caller's loss kernel has filled dlogits)
+        if (loss_kind == 1) launch_focal_bwd(ctx, buf(logits), labels_dev, M4 * out_ch, focal_alpha, focal_gamma, buf(dlogits));
+        else launch_loss_bwd(ctx, buf(logits), labels_dev, M4 * out_ch, d_sums, buf(dlogits));
+    }
     const ConvBN& cl = convs[L - 1];
-    launch_head_bwd(ctx, buf(mkU), M4, C, cl.scale(), cl.shift(), params + head_w_off, out_ch, buf(dlogits), buf(mkGU), buf(ws_red),
-                    grads + head_w_off, grads + head_b_off);
+    launch_head_bwd(ctx, arch == 3 ? buf(mkU) : buf(mkY[L - 1]), M4, C, cl.scale(), cl.shift(), params + head_w_off, out_ch, buf(dlogits),
+                    arch == 3 ? buf(mkGU) : buf(mkG[L - 1]), buf(ws_red), grads + head_w_off, grads + head_b_off);
     // transposed conv: dU = dUa * (U > 0); bias, weight and input gradients
+    if (arch == 3) {
     UpConv& u = ups[0];
     launch_relu_bwd(ctx, buf(mkGU), buf(mkU), M4 * C);
     launch_channel_sum(ctx, View{buf(mkGU), C}, M4, C, buf(ws_red), grads + u.b_off);
@@ -266,6 +280,7 @@ void rfi_model::backward_mask(const float* x_dev, const uint8_t* labels_dev, int
         a.bf16 = compute_bf16;
         a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
+    }
     }
     for (int i = L - 1; i >= 0; --i) {
         ConvBN& c = convs[i];

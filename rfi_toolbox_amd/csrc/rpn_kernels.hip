@@ -1,0 +1,159 @@
+// Region-proposal pieces of the Mask R-CNN path (BASELINE.json configs[3]).  NOT in the reference
+// (no detector there, no torchvision here): defined by the published algorithms -- Ren et al. 2015 (Faster R-CNN: box
+// parameterisation, RPN loss), Girshick 2015 (smooth L1), greedy IoU non-maximum suppression -- with the conventions of
+// the de-facto implementation (box-coder weights 1, dw / dh clamped at log(1000 / 16), smooth-L1 beta 1/9, both loss
+// terms divided by the number of sampled anchors).  Oracle: oracle/detection_ref.py; parity unpinned by the reference.
+#include "kernels.hpp"
+
+namespace rfi {
+namespace {
+
+constexpr int kB = 256;
+
+// boxes = decode(anchors, deltas), clipped to the image.  One thread per box; anchors repeat with period n_anchors.
+__global__ __launch_bounds__(kB) void box_decode_kernel(const float* __restrict__ anchors, int64_t n_anchors,
+                                                       const float* __restrict__ deltas, int64_t n, float clip_h, float clip_w,
+                                                       float* __restrict__ out) {
+    const float kClamp = 4.135166556742356f;         // log(1000 / 16)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = *reinterpret_cast<const float4*>(anchors + (i % n_anchors) * 4);
+        const float4 d = *reinterpret_cast<const float4*>(deltas + i * 4);
+        const float w = a.z - a.x, h = a.w - a.y, cx = a.x + 0.5f * w, cy = a.y + 0.5f * h;
+        const float dw = fminf(d.z, kClamp), dh = fminf(d.w, kClamp);
+        const float pcx = d.x * w + cx, pcy = d.y * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+        float4 b = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+        if (clip_w > 0.0f) {
+            b.x = fminf(fmaxf(b.x, 0.0f), clip_w); b.z = fminf(fmaxf(b.z, 0.0f), clip_w);
+            b.y = fminf(fmaxf(b.y, 0.0f), clip_h); b.w = fminf(fmaxf(b.w, 0.0f), clip_h);
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = b;
+    }
+}
+
+// Suppression matrix of n boxes given in descending score order: bit j of mask[i][j / 64] is set when j > i and
+// IoU(i, j) > thr.  Block (bi, bj) handles rows 64 bi .. and columns 64 bj ..; the column boxes sit in LDS.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr,
+                                                     unsigned long long* __restrict__ mask, int words) {
+    __shared__ float4 cols[64];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;                              // (j > i only)
+    const int j0 = bj * 64, i = bi * 64 + threadIdx.x;
+    if (j0 + (int)threadIdx.x < n) cols[threadIdx.x] = *reinterpret_cast<const float4*>(boxes + (int64_t)(j0 + threadIdx.x) * 4);
+    __syncthreads();
+    if (i >= n) return;
+    const float4 a = *reinterpret_cast<const float4*>(boxes + (int64_t)i * 4);
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    unsigned long long bits = 0;
+    const int cnt = min(64, n - j0);
+    for (int k = 0; k < cnt; ++k) {
+        if (j0 + k <= i) continue;
+        const float4 b = cols[k];
+        const float iw = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f), ih = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
+        const float inter = iw * ih, uni = area_a + (b.z - b.x) * (b.w - b.y) - inter;
+        if (inter > thr * uni) bits |= 1ull << k;     // IoU > thr without the division (uni >= 0)
+    }
+    mask[(int64_t)i * words + bj] = bits;
+}
+
+// RPN loss over the head output [P][5 A] (A objectness logits, then A x 4 box deltas per pixel): labels [P A] in
+// {1 positive, 0 negative, -1 not sampled}, targets [P A][4].  Writes d(loss)/d(head output) and fp64 partials
+// [block][2] = (sum BCE over sampled, sum smooth-L1 over positives), both terms scaled by inv_count.
+__global__ __launch_bounds__(kB) void rpn_loss_kernel(const float* __restrict__ head, int64_t P, int A,
+                                                     const signed char* __restrict__ labels, const float* __restrict__ targets,
+                                                     float inv_count, float beta, float* __restrict__ dhead,
+                                                     double* __restrict__ partial) {
+    __shared__ double red[2][kB];
+    double s_obj = 0.0, s_box = 0.0;
+    const int64_t total = P * A;
+    const int ps = 5 * A;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / A;
+        const int a = (int)(i % A);
+        const int lab = labels[i];
+        const float x = head[p * ps + a];
+        float dx = 0.0f;
+        if (lab >= 0) {
+            const float t = lab > 0 ? 1.0f : 0.0f;
+            s_obj += (double)(fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x))));
+            dx = (1.0f / (1.0f + expf(-x)) - t) * inv_count;
+        }
+        dhead[p * ps + a] = dx;
+        const float4 d = *reinterpret_cast<const float4*>(head + p * ps + A + 4 * a);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lab > 0) {
+            const float4 t4 = *reinterpret_cast<const float4*>(targets + i * 4);
+            const float e[4] = {d.x - t4.x, d.y - t4.y, d.z - t4.z, d.w - t4.w};
+            float ge[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float ae = fabsf(e[k]);
+                if (ae < beta) { s_box += (double)(0.5f * e[k] * e[k] / beta); ge[k] = e[k] / beta * inv_count; }
+                else { s_box += (double)(ae - 0.5f * beta); ge[k] = (e[k] > 0.0f ? inv_count : -inv_count); }
+            }
+            g = make_float4(ge[0], ge[1], ge[2], ge[3]);
+        }
+        *reinterpret_cast<float4*>(dhead + p * ps + A + 4 * a) = g;
+    }
+    red[0][threadIdx.x] = s_obj;
+    red[1][threadIdx.x] = s_box;
+    __syncthreads();
+    for (int o = kB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2] = red[0][0];
+        partial[blockIdx.x * 2 + 1] = red[1][0];
+    }
+}
+__global__ void rpn_loss_finish_kernel(const double* __restrict__ partial, int blocks, double inv_count, float* __restrict__ out2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < blocks; ++i) { a += partial[i * 2]; b += partial[i * 2 + 1]; }     // fixed order
+        out2[0] = (float)(a * inv_count);
+        out2[1] = (float)(b * inv_count);
+    }
+}
+
+}  // namespace
+
+void launch_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,
+                       float clip_w, float* out) {
+    RFI_REQUIRE(n > 0 && n_anchors > 0, "box_decode: empty input");
+    RFI_REQUIRE(!((reinterpret_cast<uintptr_t>(anchors) | reinterpret_cast<uintptr_t>(deltas) | reinterpret_cast<uintptr_t>(out)) & 15),
+                "box_decode: 16-byte aligned tensors");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * 48);
+    int64_t b = cdiv(n, kB);
+    hipLaunchKernelGGL(box_decode_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(kB), 0, ctx->stream, anchors, n_anchors, deltas, n,
+                       clip_h, clip_w, out);
+    check_launch("box_decode");
+}
+void launch_nms_mask(rfi_ctx* ctx, const float* boxes, int n, float thr, unsigned long long* mask) {
+    RFI_REQUIRE(n > 0 && !(reinterpret_cast<uintptr_t>(boxes) & 15), "nms: empty input or unaligned boxes");
+    const int words = (int)cdiv(n, 64);
+    RFI_CHECK_HIP(hipMemsetAsync(mask, 0, (size_t)n * words * 8, ctx->stream));
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * words * 8);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, ctx->stream, boxes, n, thr, mask, words);
+    check_launch("nms_mask");
+}
+size_t rpn_loss_ws_doubles() { return 2 * 1024; }
+void launch_rpn_loss(rfi_ctx* ctx, const float* head, int64_t P, int A, const signed char* labels, const float* targets,
+                     int64_t num_sampled, float beta, float* dhead, double* partial_ws, float* loss2_dev) {
+    RFI_REQUIRE(P > 0 && A > 0 && A % 4 == 0, "rpn_loss: P > 0 and anchors per pixel a multiple of 4 (16-byte aligned delta groups)");
+    RFI_REQUIRE(!((reinterpret_cast<uintptr_t>(head) | reinterpret_cast<uintptr_t>(targets) | reinterpret_cast<uintptr_t>(dhead)) & 15),
+                "rpn_loss: 16-byte aligned tensors");
+    const float inv = num_sampled > 0 ? 1.0f / (float)num_sampled : 0.0f;
+    int64_t blocks = cdiv(P * A, kB);
+    if (blocks > 1024) blocks = 1024;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)P * A * (5 * 8 + 17));
+    hipLaunchKernelGGL(rpn_loss_kernel, dim3((unsigned)blocks), dim3(kB), 0, ctx->stream, head, P, A, labels, targets, inv, beta, dhead,
+                       partial_ws);
+    check_launch("rpn_loss");
+    hipLaunchKernelGGL(rpn_loss_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial_ws, (int)blocks, (double)inv, loss2_dev);
+    check_launch("rpn_loss_finish");
+}
+
+}  // namespace rfi

@@ -66,3 +66,55 @@ def fpn_merge_backward(dout, device=None, to_host=True):
     check(lib.rfi_op_fpn_merge_backward(ctx.handle, _p(dd), n, h, w, c, _p(dtop)))
     ctx.synchronize()
     return (dd.numpy(), dtop.numpy()) if to_host else (dd, dtop)
+
+
+# ---------------------------------------------------------------- region proposals (rpn_kernels.hip)
+def decode_boxes(anchors, deltas, image_size=None, device=None):
+    """boxes = decode(anchors (A, 4), deltas (k A, 4)) with the Faster R-CNN parameterisation (weights 1, dw / dh clamped at
+    log(1000/16)); clipped to ``image_size = (H, W)`` when given.  -> (k A, 4) float32."""
+    ctx = Context.get(device)
+    da = _dev(ctx, np.asarray(anchors, np.float32).reshape(-1, 4))
+    dd = _dev(ctx, np.asarray(deltas, np.float32).reshape(-1, 4))
+    n, na = dd.shape[0], da.shape[0]
+    if n % na:
+        raise ValueError(f"{n} delta rows are not a multiple of {na} anchors")
+    out = ctx.empty((n, 4), np.float32)
+    h, w = (float(image_size[0]), float(image_size[1])) if image_size is not None else (0.0, 0.0)
+    check(lib.rfi_op_box_decode(ctx.handle, _p(da), na, _p(dd), n, h, w, _p(out)))
+    ctx.synchronize()
+    return out.numpy()
+
+
+def nms(boxes, scores, iou_threshold, device=None):
+    """Greedy non-maximum suppression: indices of the kept boxes, in descending score order (stable for ties)."""
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
+    scores = np.asarray(scores, np.float32).reshape(-1)
+    if len(boxes) != len(scores):
+        raise ValueError("boxes and scores differ in length")
+    if len(boxes) == 0:
+        return np.zeros(0, np.int64)
+    order = np.argsort(-scores, kind="stable")
+    ctx = Context.get(device)
+    db = ctx.to_device(np.ascontiguousarray(boxes[order]))
+    keep = np.empty(len(boxes), np.int32)
+    nk = C.c_int()
+    check(lib.rfi_op_nms(ctx.handle, _p(db), len(boxes), float(iou_threshold), keep.ctypes.data_as(C.c_void_p), C.byref(nk)))
+    return order[keep[:nk.value]]
+
+
+def rpn_loss(head, labels, targets, anchors_per_pixel, beta=1.0 / 9, device=None):
+    """head (P, 5 A) float32 = A objectness logits then A x 4 box deltas per pixel; labels (P A,) int8 in {1, 0, -1};
+    targets (P A, 4).  -> (objectness loss, box loss, d(sum)/d(head) (P, 5 A))."""
+    ctx = Context.get(device)
+    a = int(anchors_per_pixel)
+    dh = _dev(ctx, np.asarray(head, np.float32).reshape(-1, 5 * a))
+    lab = np.ascontiguousarray(np.asarray(labels, np.int8).reshape(-1))
+    if lab.size != dh.shape[0] * a:
+        raise ValueError("labels do not match the head output")
+    dl = ctx.to_device(lab)
+    dt = _dev(ctx, np.asarray(targets, np.float32).reshape(-1, 4))
+    dg = ctx.empty(dh.shape, np.float32)
+    lo, lb = C.c_float(), C.c_float()
+    check(lib.rfi_op_rpn_loss(ctx.handle, _p(dh), dh.shape[0], a, _p(dl), _p(dt), int((lab >= 0).sum()), float(beta), _p(dg),
+                              C.byref(lo), C.byref(lb)))
+    return lo.value, lb.value, dg.numpy()

@@ -64,3 +64,53 @@ def test_fpn_merge_forward_backward(shape):
     assert _rel(dtop, ref.fpn_merge_backward_top(dout)) <= 1e-6
     with pytest.raises(ValueError):
         ops.fpn_merge(lat, np.zeros((n, (h + 1) // 2 + 1, (w + 1) // 2, c), np.float32))
+
+
+def _anchors(rng, n):
+    x1, y1 = rng.uniform(0, 200, n), rng.uniform(0, 200, n)
+    return np.stack([x1, y1, x1 + rng.uniform(4, 120, n), y1 + rng.uniform(4, 120, n)], 1).astype(np.float32)
+
+
+def test_box_decode():
+    rng = np.random.default_rng(1)
+    anchors = _anchors(rng, 36)
+    deltas = (rng.standard_normal((36 * 50, 4)) * np.array([0.5, 0.5, 1.5, 1.5])).astype(np.float32)
+    deltas[3, 2:] = 9.0                                # beyond the clamp
+    got = ops.decode_boxes(anchors, deltas)
+    want = ref.decode_boxes(anchors, deltas)
+    assert _rel(got, want) <= 2e-6
+    got = ops.decode_boxes(anchors, deltas, image_size=(256, 300))
+    want = ref.decode_boxes(anchors, deltas, image_size=(256, 300))
+    assert np.abs(got - want).max() <= 1e-3 and got.min() >= 0 and got[:, 0::2].max() <= 300 and got[:, 1::2].max() <= 256
+
+
+@pytest.mark.parametrize("n,thr", [(1, 0.5), (63, 0.3), (64, 0.7), (65, 0.5), (700, 0.7), (2000, 0.7)])
+def test_nms(n, thr):
+    rng = np.random.default_rng(n)
+    centres = rng.uniform(20, 230, (max(n // 6, 1), 2))                  # clusters of overlapping boxes
+    c = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 6, (n, 2))
+    wh = rng.uniform(15, 60, (n, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    scores = rng.random(n).astype(np.float32)
+    scores[: n // 10] = scores[0]                                       # ties: stable order decides
+    got = ops.nms(boxes, scores, thr)
+    want = ref.nms(boxes, scores, thr)
+    # an IoU within float32 rounding of the threshold may fall on either side; none of these seeds has one
+    np.testing.assert_array_equal(got, want)
+    assert ops.nms(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5).size == 0
+
+
+@pytest.mark.parametrize("p,a", [(37, 4), (64 * 64, 12), (2 * 50 * 76, 4)])
+def test_rpn_loss_forward_backward(p, a):
+    rng = np.random.default_rng(p)
+    head = (rng.standard_normal((p, 5 * a)) * 1.5).astype(np.float32)
+    labels = rng.choice(np.array([-1, -1, -1, 0, 0, 1], np.int8), p * a)
+    targets = (rng.standard_normal((p * a, 4)) * 0.4).astype(np.float32)
+    targets[::7] = head[:, a:].reshape(-1, 4)[::7] + 0.05              # inside the quadratic zone of smooth L1
+    lo, lb, g = ops.rpn_loss(head, labels, targets, a)
+    wo, wb, wg = ref.rpn_loss(head, labels, targets, a)
+    assert lo == pytest.approx(wo, rel=2e-6) and lb == pytest.approx(wb, rel=2e-6)
+    assert _rel(g, wg) <= 5e-6
+    # nothing sampled: zero loss, zero gradient
+    lo, lb, g = ops.rpn_loss(head, np.full(p * a, -1, np.int8), targets, a)
+    assert lo == 0.0 and lb == 0.0 and not g.any()

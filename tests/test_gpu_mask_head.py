@@ -132,3 +132,58 @@ def test_mask_branch_end_to_end():
     assert np.abs(dfeat - dfeat_ref).max() <= 2e-4 * np.abs(dfeat_ref).max()
     k = "mask_fcn1.weight"
     assert np.linalg.norm(m.grad(k) - g_ref[k].numpy()) <= 2e-4 * np.linalg.norm(g_ref[k].numpy())
+
+
+# ---------------------------------------------------------------- RPN head
+def test_rpn_head_step_and_proposals():
+    """RPN head: forward, the loss kernel, backward from its gradient, one Adam step; then proposals from the head output
+    (box decoding + NMS) -- against the torch head / torch loss / NumPy decode + NMS oracles."""
+    from rfi_toolbox_amd.models import RPNHead
+    c, a, n, hh, ww = 32, 4, 2, 24, 20
+    st = mref.rpn_init_state(c, a, 1, seed=51)
+    torch.manual_seed(51)
+    m = RPNHead(c, a, 1)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(st.keys())
+    for k in st:
+        assert torch.equal(sd[k], st[k]), k                              # same draws as constructing the torch module
+    rng = np.random.default_rng(52)
+    x = torch.from_numpy(rng.standard_normal((n, hh, ww, c)).astype(np.float32))
+    xo = unet_ref.nhwc_to_nchw(x)
+    want = mref.rpn_forward(st, xo)
+    got = m.train().forward_nhwc(x.numpy())
+    assert got.shape == (n, hh, ww, 5 * a)
+    np.testing.assert_allclose(got, want.detach().numpy(), rtol=0, atol=3e-5 * float(want.abs().max()))
+    # sampler output (synthetic): ~3 % positives, ~6 % negatives, the rest not sampled
+    P = n * hh * ww
+    labels = rng.choice(np.array([-1] * 30 + [0, 0, 1], np.int8), P * a)
+    targets = (rng.standard_normal((P * a, 4)) * 0.3).astype(np.float32)
+    lo, lb, dout = ops.rpn_loss(got.reshape(P, 5 * a), labels, targets, a)
+    # oracle: torch autograd through head + loss
+    leaves = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in st.items())
+    xg = xo.clone().requires_grad_(True)
+    o_l, b_l = mref.rpn_loss_torch(mref.rpn_forward(leaves, xg), labels, targets, a)
+    grads = torch.autograd.grad(o_l + b_l, list(leaves.values()) + [xg])
+    assert lo == pytest.approx(float(o_l), rel=1e-5) and lb == pytest.approx(float(b_l), rel=1e-5)
+    m.backward(x.numpy(), dout)
+    for (k, _), g in zip(leaves.items(), grads[:-1]):
+        g = g.numpy()
+        assert np.linalg.norm(m.grad(k) - g) <= 1e-4 * np.linalg.norm(g) + 1e-9, k
+    gx = grads[-1].permute(0, 2, 3, 1).numpy()
+    assert np.linalg.norm(m.input_grad((n, hh, ww, c)) - gx) <= 1e-4 * np.linalg.norm(gx)
+    norm = m.apply_gradients(lr=1e-3, weight_decay=0.0)
+    total, _ = unet_ref.clip_coefficient(OrderedDict(zip(leaves.keys(), grads[:-1])), 1.0)
+    assert norm == pytest.approx(float(total), rel=1e-4)
+    # proposals of image 0: anchors of 4 sizes on a stride-8 grid, top 600 by objectness, NMS at 0.7
+    sizes = np.array([16, 32, 64, 128], np.float32)
+    ys, xs = np.meshgrid(np.arange(hh) * 8 + 4, np.arange(ww) * 8 + 4, indexing="ij")
+    anchors = np.stack([(xs[..., None] - sizes / 2), (ys[..., None] - sizes / 2), (xs[..., None] + sizes / 2), (ys[..., None] + sizes / 2)],
+                       -1).reshape(-1, 4).astype(np.float32)             # (H W A, 4), pixel-major, anchor-minor
+    out0 = got[0].reshape(hh * ww, 5 * a)
+    scores, deltas = out0[:, :a].reshape(-1), out0[:, a:].reshape(-1, 4)
+    boxes = ops.decode_boxes(anchors, deltas, image_size=(hh * 8, ww * 8))
+    assert np.abs(boxes - detection_ref.decode_boxes(anchors, deltas, image_size=(hh * 8, ww * 8))).max() <= 1e-3
+    top = np.argsort(-scores, kind="stable")[:600]
+    keep = ops.nms(boxes[top], scores[top], 0.7)
+    np.testing.assert_array_equal(keep, detection_ref.nms(boxes[top], scores[top], 0.7))
+    assert 0 < len(keep) <= 600

@@ -292,3 +292,23 @@ def test_builder_defined_oracles_match_their_torch_modules():
     y = (torch.rand(3, 1, 28, 28) > 0.5).float()
     loss = torch.nn.functional.binary_cross_entropy_with_logits(mh(x), y)
     assert float(loss) == pytest.approx(float(mask_head_ref.mask_loss(mask_head_ref.forward(st, x), y)), abs=1e-7)
+    st = mask_head_ref.rpn_init_state(8, 4, 1, seed=3)
+    rp = mask_head_ref.RPNHeadModule(8, 4, 1)
+    rp.load_state_dict(st)
+    x = torch.randn(2, 8, 6, 5)
+    cls, box = rp(x)
+    out = mask_head_ref.rpn_forward(st, x)
+    assert float((torch.cat([cls, box], 1).permute(0, 2, 3, 1) - out).abs().max()) == 0.0
+    # the torch restatement of the RPN loss against the NumPy one (oracle/detection_ref.py) incl. its gradient
+    import numpy as np
+
+    from oracle import detection_ref
+    rng = np.random.default_rng(0)
+    labels = rng.choice(np.array([-1, -1, 0, 1], np.int8), 2 * 6 * 5 * 4)
+    targets = rng.standard_normal((2 * 6 * 5 * 4, 4)).astype(np.float32) * 0.3
+    o = out.detach().clone().requires_grad_(True)
+    lo, lb = mask_head_ref.rpn_loss_torch(o, labels, targets, 4)
+    (g,) = torch.autograd.grad(lo + lb, [o])
+    wo, wb, wg = detection_ref.rpn_loss(out.detach().numpy().reshape(-1, 20), labels, targets, 4)
+    assert float(lo) == pytest.approx(wo, rel=1e-5) and float(lb) == pytest.approx(wb, rel=1e-5)
+    assert np.abs(g.numpy().reshape(-1, 20) - wg).max() <= 1e-6
