@@ -93,7 +93,7 @@ constexpr int HROW3 = 28;  // halo row of the 3 x bf16 path: [h 32 B | m 32 B | 
 
 template <int R, int S, int TH, int TW, int BN, int WM, int WN, int PREC = 0>
 struct Cfg {
-    static constexpr int HROW = PREC == 2 ? HROW3 : KCP;   // floats per halo-tile row
+    static constexpr int HROW = PREC >= 2 ? HROW3 : KCP;   // floats per halo-tile row
     static constexpr int BM = TH * TW;
     static constexpr int HH = TH * S + R - S;
     static constexpr int HW = TW * S + R - S;
@@ -102,9 +102,9 @@ struct Cfg {
     static constexpr int MT = BM / WM / 32;       // 32-pixel m-tiles per wave
     static constexpr int NTL = BN / WN / 32;      // 32-channel n-tiles per wave
     static constexpr int HALO_ITEMS = (HP * 4 + 255) / 256;
-    static constexpr int W_ITEMS = (NTAP * BN * (PREC == 2 ? 6 : 4) + 255) / 256;
-    static constexpr int WROW = PREC == 2 ? WROW3 : KCP;   // floats per filter-tile row
-    static constexpr int WQ = PREC == 2 ? 6 : 4;           // float4 pieces per filter row (3 x bf16: h | m | l of 16 channels)
+    static constexpr int W_ITEMS = (NTAP * BN * (PREC >= 2 ? 6 : 4) + 255) / 256;
+    static constexpr int WROW = PREC >= 2 ? WROW3 : KCP;   // floats per filter-tile row
+    static constexpr int WQ = PREC >= 2 ? 6 : 4;           // float4 pieces per filter row (3 x bf16: h | m | l of 16 channels)
     static constexpr int STAGE_FLOATS = HP * HROW + NTAP * BN * WROW;
     static constexpr int EPI_FLOATS = 4 * 32 * 36;            // epilogue transpose scratch (4 waves)
     static constexpr int LDS_FLOATS0 = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
@@ -118,7 +118,9 @@ struct Cfg {
 // BF: bf16 compute mode -- the SAME fp32 tiles in HBM and LDS; each lane's k-quad of an operand fragment is
 // rounded to bf16 in registers and ONE v_mfma_f32_32x32x8_bf16 (fp32 accumulate) replaces the four
 // fp32 32x32x2 MFMAs of that quad (identical k-to-lane mapping: lane half lh holds k = 4 lh .. 4 lh + 3).
-// PREC: 0 float32 MFMA, 1 bf16 (above), 2 float32 emulated by 3 x bf16 (Split3 above)
+// PREC: 0 float32 MFMA, 1 bf16 (above), 2 float32 emulated by 3 x bf16 (Split3 above), 3 bf16 on the data path of 2:
+// operands rounded once at staging time, ONE v_mfma_f32_32x32x16_bf16 per K = 16 block (the gfx950 form, twice the rate
+// of the K = 8 instruction of mode 1) -- the h plane of the split is bf16(v), RNE, i.e. the same operand values as mode 1
 template <int R, int S, int TH, int TW, int BN, int WM, int WN, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     using C = Cfg<R, S, TH, TW, BN, WM, WN, PREC>;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         for (int i = tid; i < C::STAT_DOUBLES; i += 256) s_stat[i] = 0.0;   // visible after the first barrier below
     const int z = blockIdx.z;
     const float* __restrict__ wbase =
-        PREC == 2 ? a.w3 + (a.zgroups > 1 ? (size_t)z * a.Cout * ((a.Cin + KC - 1) / KC) * WROW3 : 0)
+        PREC >= 2 ? a.w3 + (a.zgroups > 1 ? (size_t)z * a.Cout * ((a.Cin + KC - 1) / KC) * WROW3 : 0)
                   : a.w + (a.zgroups > 1 ? (size_t)z * a.Cout * a.Cin : 0);
     const int ooy = a.zgroups > 1 ? (z >> 1) : a.ooy;
     const int oox = a.zgroups > 1 ? (z & 1) : a.oox;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         if (idx < C::NTAP * BN * C::WQ) {
             const int tap = row / BN, nloc = row % BN;
             if (n0 + nloc < a.Cout) {
-                if constexpr (PREC == 2) w_off[it] = ((tap * a.Cout + n0 + nloc) * nchunks_w) * WROW3 + q * 4;
+                if constexpr (PREC >= 2) w_off[it] = ((tap * a.Cout + n0 + nloc) * nchunks_w) * WROW3 + q * 4;
                 else w_off[it] = (tap * a.Cout + n0 + nloc) * a.Cin + q * 4;
             }
         }
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 a.x.p + (unsigned)((((h_mask >> it) & 1u) && cv_l) ? h_off[it] + cc : 0));   // never past the tensor
 #pragma unroll
         for (int it = 0; it < C::W_ITEMS; ++it) {
-            if constexpr (PREC == 2)     // pre-split records: chunk c0/16 of the row, always in range (zero padded)
+            if constexpr (PREC >= 2)     // pre-split records: chunk c0/16 of the row, always in range (zero padded)
                 wreg[it] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)(w_off[it] >= 0 ? w_off[it] + (c0 / KC) * WROW3 : 0));
             else
                 wreg[it] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)((w_off[it] >= 0 && cv_l) ? w_off[it] + cc : 0));
@@ -259,16 +261,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 if (a.xf.relu) v = __builtin_elementwise_max(v, v * a.xf.slope);
             }
             v = (((h_mask >> it) & 1u) && cv_l) ? v : zero;      // zero padding AFTER the transform
-            if constexpr (PREC == 2) {
+            if constexpr (PREC >= 2) {
                 // split ONCE per element here (each halo element feeds up to 9 taps): three bf16 planes per row
+                // (mode 3: only the h plane = the bf16-rounded operand is stored and read)
                 unsigned h0, m0, l0, h1, m1, l1;
                 split_pair(v.x, v.y, h0, m0, l0);
                 split_pair(v.z, v.w, h1, m1, l1);
                 if (tid + it * 256 < C::HP * 4) {
                     float* row = s_halo + ((tid >> 2) + it * 64) * C::HROW + (tid & 3) * 2;   // 4 channels = 8 B per plane
                     *reinterpret_cast<u32x2*>(row) = u32x2{h0, h1};
-                    *reinterpret_cast<u32x2*>(row + 8) = u32x2{m0, m1};
-                    *reinterpret_cast<u32x2*>(row + 16) = u32x2{l0, l1};
+                    if constexpr (PREC == 2) {
+                        *reinterpret_cast<u32x2*>(row + 8) = u32x2{m0, m1};
+                        *reinterpret_cast<u32x2*>(row + 16) = u32x2{l0, l1};
+                    }
                 }
             } else {
                 if (tid + it * 256 < C::HP * 4) *reinterpret_cast<f32x4*>(s_halo + lds_item0 + it * 64 * KCP) = v;
@@ -276,10 +281,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < C::W_ITEMS; ++it) {
-            if constexpr (PREC == 2) {      // 6 float4 pieces per 96-byte row: item idx -> row idx/6, piece idx%6
+            if constexpr (PREC >= 2) {      // 6 float4 pieces per 96-byte row: item idx -> row idx/6, piece idx%6
                 const int idx = tid + it * 256;
                 const f32x4 v = w_off[it] >= 0 ? wreg[it] : zero;
-                if (idx < C::NTAP * BN * 6) *reinterpret_cast<f32x4*>(s_w + (idx / 6) * WROW3 + (idx % 6) * 4) = v;
+                if (idx < C::NTAP * BN * 6 && (PREC == 2 || idx % 6 < 2))         // (mode 3: the h plane only)
+                    *reinterpret_cast<f32x4*>(s_w + (idx / 6) * WROW3 + (idx % 6) * 4) = v;
             } else {
                 const f32x4 v = (w_off[it] >= 0 && cv_l) ? wreg[it] : zero;
                 if (tid + it * 256 < C::NTAP * BN * 4) *reinterpret_cast<f32x4*>(s_w + lds_item0 + it * 64 * KCP) = v;
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
         issue_loads(lch * KC);                       // (the very last item is re-read once: harmless)
         RFI_T(t3);
-        if constexpr (PREC == 2) {
+        if constexpr (PREC >= 2) {
             // one K = 16 group per tap: lane half lh holds channels 8 lh .. 8 lh + 7 of the 16-channel chunk row
 #pragma unroll
             for (int tap = 0; tap < C::NTAP; ++tap) {
@@ -361,7 +367,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                                     __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ap + 8)),
                                     __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ap + 16))};
 #pragma unroll
-                    for (int nt = 0; nt < C::NTL; ++nt) acc[mt][nt] = mfma_3xbf16(as, bs[nt], acc[mt][nt]);
+                    for (int nt = 0; nt < C::NTL; ++nt) {
+                        if constexpr (PREC == 2) acc[mt][nt] = mfma_3xbf16(as, bs[nt], acc[mt][nt]);
+                        else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.h, bs[nt].h, acc[mt][nt], 0, 0, 0);
+                    }
                 }
             }
         } else {
@@ -570,6 +579,7 @@ static int occupancy_for(size_t lds_bytes) {
 template <int R, int S, int TH, int TW, int BN, int WM, int WN, int PREC = 0>
 void launch_cfg(rfi_ctx* ctx, ConvArgs& a) {
     if constexpr (PREC == 0) {
+        if (a.bf16 && bf16_k16()) return launch_cfg<R, S, TH, TW, BN, WM, WN, 3>(ctx, a);
         if (a.bf16) return launch_cfg<R, S, TH, TW, BN, WM, WN, 1>(ctx, a);
         if (a.bf16x3) return launch_cfg<R, S, TH, TW, BN, WM, WN, 2>(ctx, a);
     }
@@ -645,7 +655,7 @@ void dispatch_tiles(rfi_ctx* ctx, ConvArgs& a) {
         return (int64_t)a.N * cdiv(a.H, th) * cdiv(a.W, tw) * ych >= 512;
     };
     if constexpr (S == 1) {          // (a stride-2 halo of the double tile would not fit the LDS)
-      if (!a.bf16x3) {               // (the 3 x bf16 halo planes of a double tile would leave one workgroup per CU)
+      if (!a.bf16x3 && !(a.bf16 && bf16_k16())) {   // (the bf16 halo planes of a double tile would leave one workgroup per CU)
         if (a.W >= 32 && a.Cout <= 32 && big_ok(16, 32, a.zgroups)) return launch_cfg<R, S, 16, 32, 32, 4, 1>(ctx, a);
         if (a.W >= 32 && a.Cout > 32 && big_ok(8, 32, ychunks64)) return launch_cfg<R, S, 8, 32, 64, 4, 1>(ctx, a);
         if (a.W >= 16 && a.W < 32 && a.Cout > 32 && big_ok(16, 16, ychunks64))
@@ -776,7 +786,7 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     // 3 x bf16: the filters are read pre-split (ConvArgs::w3); callers that only have float32 weights (the
     // kernel-level API) get a temporary split copy
     float* tmp_w3 = nullptr;
-    if (a.bf16x3 && !a.w3) {
+    if ((a.bf16x3 || (a.bf16 && bf16_k16())) && !a.w3) {
         const int taps = a.R * a.R * a.zgroups;
         tmp_w3 = static_cast<float*>(ctx->alloc(weights_x3_floats(taps, a.Cout, a.Cin) * sizeof(float)));
         launch_weights_to_x3(ctx, a.w, taps, a.Cout, a.Cin, tmp_w3);
@@ -821,5 +831,16 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     else if (a.S == 1) dispatch_tiles<2, 1>(ctx, a);
     else dispatch_tiles<2, 2>(ctx, a);
 }
+
+// bf16 mode on float32 tensors: round 1's K = 8 instruction on float32 LDS tiles (default), or -- RFI_BF16_K16=1 -- the
+// K = 16 instruction on the split path's data flow (mode 3).  Measured (round 2): mode 3 is SLOWER, 28.1 vs 24.0 ms per
+// UNetResNet18 step at 1 x 1024^2 and 8.9 vs 7.5 ms per mask-head step: what it gains in matrix rate it loses to the
+// split path's staging (conversion at staging time, 112-byte rows, no double tiles within the LDS budget).  The bf16
+// mode that does use the K = 16 instruction well is the plane data flow (conv_planes.hip).
+bool bf16_k16() {
+    static const bool k16 = getenv("RFI_BF16_K16") != nullptr;
+    return k16;
+}
+
 
 }  // namespace rfi

@@ -84,6 +84,7 @@ enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 
                 IMPL_PLANES_X3 = 5, IMPL_PLANES_BF16 = 6 };
 
 bool conv_mfma_eligible(const ConvArgs& a);
+bool bf16_k16();           // RFI_BF16_K16=1: the float32-tensor bf16 mode runs the K = 16 MFMA on the split path's data flow (conv_mfma.hip)
 // filters [taps][Cout][Cin] -> [taps][Cout][ceil(Cin/16)][h16 | m16 | l16] bf16 records (24 floats each)
 size_t weights_x3_floats(int taps, int Cout, int Cin);
 void launch_weights_to_x3(rfi_ctx* ctx, const float* w, int taps, int Cout, int Cin, float* out);

@@ -333,7 +333,7 @@ void rfi_model::prepare(int n, int h, int w) {
 }
 
 void rfi_model::refresh_dgrad_weights() {
-    if (!wd_dirty && (!compute_x3 || x3_fresh)) return;
+    if (!wd_dirty && (!use_w3() || x3_fresh)) return;
     if (!relayout_descs) {          // one descriptor per conv-like layer, built once
         std::vector<RelayoutDesc> h;
         relayout_bytes = 0;
@@ -354,7 +354,7 @@ void rfi_model::refresh_dgrad_weights() {
     }
     launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
                                    wd_pool, relayout_bytes, relayout_tiles);
-    if (compute_x3) {     // pre-split records of both layouts of every conv-like layer (the kernels read them as is)
+    if (use_w3()) {       // pre-split records of both layouts of every conv-like layer (the kernels read them as is)
         if (!w3_pool) {
             size_t need = 0;
             for (auto& c : convs) need += weights_x3_floats(c.R * c.R, c.cout, c.cin_p) + weights_x3_floats(c.R * c.R, c.cin_p, c.cout);
@@ -408,7 +408,7 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
     a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
     a.Cin = c.cin_p; a.Cout = c.cout;
     a.w = m->params + c.w_off;
-    a.w3 = m->compute_x3 ? c.w3 : nullptr;
+    a.w3 = m->use_w3() ? c.w3 : nullptr;
     a.bias = m->params + c.b_off;
     a.y = MutView{Y, c.cout};
     a.Hout = s.H; a.Wout = s.W;
@@ -487,7 +487,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = sin.H; a.Win = sin.W;
         a.Cin = u.cin; a.Cout = u.cout;
         a.w = params + u.w_off;
-        a.w3 = compute_x3 ? u.w3 : nullptr;
+        a.w3 = use_w3() ? u.w3 : nullptr;
         a.bias = params + u.b_off;
         a.y = MutView{buf(concat[l]), 2 * u.cout};
         a.Hout = s.H; a.Wout = s.W;
@@ -639,7 +639,7 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
         a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
         a.Cin = c.cout; a.Cout = c.cin;     // dx exists only for layers whose cin == cin_p
         a.w = c.wd;
-        a.w3 = m->compute_x3 ? c.wd3 : nullptr;
+        a.w3 = m->use_w3() ? c.wd3 : nullptr;
         a.bias = nullptr;
         a.y = MutView{dx, c.cin};
         a.Hout = s.H; a.Wout = s.W;
@@ -736,7 +736,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = s.H; a.Win = s.W;
         a.Cin = u.cout; a.Cout = u.cin;
         a.w = u.wd;
-        a.w3 = compute_x3 ? u.wd3 : nullptr;
+        a.w3 = use_w3() ? u.wd3 : nullptr;
         a.bias = nullptr;
         float* dprev = (l == D) ? buf(gBottA) : buf(gA[l + 1]);
         a.y = MutView{dprev, u.cin};

@@ -94,6 +94,7 @@ struct rfi_model {
     float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
     bool compute_bf16 = false;        // conv / wgrad MFMAs on bf16-rounded operands (fp32 storage + accumulate)
     bool compute_x3 = true;           // DEFAULT: float32 contractions by 3 x bf16 pieces (float32-level accuracy)
+    bool use_w3() const { return compute_x3 || (compute_bf16 && rfi::bf16_k16()); }   // who reads the pre-split filter records
     bool fuse_bn_bwd = false;         // BatchNorm-backward sums folded into the epilogue of the kernel producing dA (RFI_BN_FUSE=1: on;
                                       // measured neutral: -0.31 ms of BatchNorm passes, +0.18 ms of conv epilogues)
     int loss_kind = 0;                // 0: BCE-with-logits + dice (the reference's, train_model.py:120-128); 1: focal

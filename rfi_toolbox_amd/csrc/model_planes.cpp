@@ -236,7 +236,7 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = sin.H; a.Win = sin.W;
         a.Cin = u.cin; a.Cout = u.cout;
         a.w = params + u.w_off;
-        a.w3 = compute_x3 ? u.w3 : nullptr;
+        a.w3 = use_w3() ? u.w3 : nullptr;
         a.bias = params + u.b_off;
         a.Hout = s.H; a.Wout = s.W;
         a.osy = 2; a.osx = 2;
@@ -395,7 +395,7 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = s.H; a.Win = s.W;
         a.Cin = u.cout; a.Cout = u.cin;
         a.w = u.wd;
-        a.w3 = compute_x3 ? u.wd3 : nullptr;
+        a.w3 = use_w3() ? u.wd3 : nullptr;
         float* dprev = (l == D) ? buf(gBottA) : buf(gA[l + 1]);
         a.y = MutView{dprev, u.cin};
         a.Hout = sin.H; a.Wout = sin.W;

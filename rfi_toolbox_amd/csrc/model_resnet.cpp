@@ -235,7 +235,7 @@ void conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, const float*
     a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
     a.Cin = cin; a.Cout = c.cout;
     a.w = w;
-    a.w3 = m->compute_x3 ? w3 : nullptr;            // null: the kernel launcher splits a temporary copy
+    a.w3 = m->use_w3() ? w3 : nullptr;            // null: the kernel launcher splits a temporary copy
     a.bias = c.has_bias ? m->params + c.b_off : nullptr;
     a.y = MutView{Y, c.cout};
     a.Hout = s.H; a.Wout = s.W;
@@ -300,7 +300,7 @@ void dgrad(rfi_model* m, const float* dY, int cy, const float* wd, const float* 
     a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
     a.Cin = cy; a.Cout = cx;
     a.w = wd;
-    a.w3 = m->compute_x3 ? wd3 : nullptr;
+    a.w3 = m->use_w3() ? wd3 : nullptr;
     a.y = MutView{dx, cx};
     a.Hout = s.H; a.Wout = s.W;
     a.R = R; a.S = 1; a.pad = pad;
