@@ -78,9 +78,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int R, int S, int BYB, int BXB, int TH, int TW, int P>
+// TG tap groups: a workgroup accumulates NTAP / TG taps (TG = 3: one filter row).  The pixel range is then split
+// TG times less for the same number of workgroups, i.e. TG times fewer partial slabs are written and reduced -- at the
+// price of staging each tile TG times, which the deep layers (small maps, 64 x 64-channel blocks) can afford.
+template <int R, int S, int BYB, int BXB, int TH, int TW, int P, int TG>
 __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
     using C = PWCfg<R, S, BYB, BXB, TH, TW, P>;
+    constexpr int NTG = C::NTAP / TG;
+    static_assert(C::NTAP % TG == 0, "tap groups must divide the taps");
     const PWgradArgs& a = d.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const sY = smem;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
     const int blk = wave % C::BLOCKS, ps = wave / C::BLOCKS;
     const int by = blk / BXB, bx = blk % BXB;
     const int yb0 = blockIdx.y * BYB, xb0 = blockIdx.z * BXB;        // first 32-channel block of the workgroup
-    const int split = blockIdx.x;
+    const int split = blockIdx.x / TG, tap0 = (blockIdx.x % TG) * NTG;
 
     // ---- DMA descriptors: slot s = it * 256 + tid of an operand image [block][pixel][plane][4 pieces of 8 ch]
     // y_d / x_d: pixel row << 20 | pixel column << 8 | (chunk-in-operand * P + plane) * 2 + half  (or ~0: zero)
@@ -157,11 +162,14 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
     auto ypix = [&](int t) { return t; };                                            // Y image is [pixel of the tile]
     auto xpix = [&](int t) { return ((t / TW) * S) * C::HW + (t % TW) * S; };         // halo pixel of tile pixel t (tap 0)
 
-    f32x16 acc[C::NTAP];
+    f32x16 acc[NTG];
+    int toffs[NTG];                                   // LDS byte offset of this workgroup's taps inside a halo image
 #pragma unroll
-    for (int t = 0; t < C::NTAP; ++t)
+    for (int t = 0; t < NTG; ++t) {
+        toffs[t] = (((tap0 + t) / R) * C::HW + ((tap0 + t) % R)) * C::ROW;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    }
 
     const unsigned char* const yimg = sY + by * (C::BM * C::ROW) + lane_off;
     const unsigned char* const ximg = sX + bx * (C::HP * C::ROW) + lane_off;
@@ -179,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
                     af[p] = tr_frag(yimg + ypix(t0) * C::ROW + p * 64, yimg + ypix(t1) * C::ROW + p * 64);
                 const int x0 = xpix(t0), x1 = xpix(t1);
     #pragma unroll
-                for (int tap = 0; tap < C::NTAP; ++tap) {
-                    const int toff = ((tap / R) * C::HW + (tap % R)) * C::ROW;
+                for (int tap = 0; tap < NTG; ++tap) {
+                    const int toff = toffs[tap];
                     bf16x8 bf[P];
     #pragma unroll
                     for (int p = 0; p < P; ++p)
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
                 auto load_b = [&](int kk, int tap, bf16x8 (&bf)[P]) {
                     const int t0 = (ps * C::KS_W + kk) * 16 + 8 * kh + q, t1 = t0 + 4;
                     const int x0 = xpix(t0), x1 = xpix(t1);
-                    const int toff = ((tap / R) * C::HW + (tap % R)) * C::ROW;
+                    const int toff = toffs[tap];
     #pragma unroll
                     for (int p = 0; p < P; ++p)
                         bf[p] = tr_frag(ximg + x0 * C::ROW + toff + p * 64, ximg + x1 * C::ROW + toff + p * 64);
@@ -213,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
                 for (int kk = 0; kk < C::KS_W; ++kk) {
                     load_a(kk);
     #pragma unroll
-                    for (int tap = 0; tap < C::NTAP; ++tap) {
-                        constexpr int NT_ = C::NTAP;
+                    for (int tap = 0; tap < NTG; ++tap) {
+                        constexpr int NT_ = NTG;
                         const int cur = (kk * NT_ + tap) & 1;
                         if (tap + 1 < NT_) load_b(kk, tap + 1, bfr[cur ^ 1]);
                         else if (kk + 1 < C::KS_W) load_b(kk + 1, 0, bfr[cur ^ 1]);
@@ -230,10 +238,10 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
 
     // ---- waves that split the tile's k-steps (WP > 1) add their accumulators through LDS, TC taps at a time
     if constexpr (C::WP > 1) {
-        constexpr int TC = C::TC;
+        constexpr int TC = (NTG % 3 == 0) ? 3 : NTG;          // (<= C::TC: the scratch is sized for that)
         float* s_red = reinterpret_cast<float*>(smem) + blk * TC * 1024;
 #pragma unroll
-        for (int t0 = 0; t0 < C::NTAP; t0 += TC) {
+        for (int t0 = 0; t0 < NTG; t0 += TC) {
 #pragma unroll
             for (int w = 1; w < C::WP; ++w) {
                 __syncthreads();
@@ -266,12 +274,12 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
         // layout entries beyond the true channels (behind the LAST segment) are written as zeros
         const bool xpad = !xok && seg == a.nseg - 1 && cx < a.cx_layout;
 #pragma unroll
-        for (int tap = 0; tap < C::NTAP; ++tap) {
+        for (int tap = 0; tap < NTG; ++tap) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cy = (yb0 + by) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (cy < a.Cy && (xok || xpad))
-                    slab[(int64_t)tap * a.tap_stride + (int64_t)cy * a.sy + (int64_t)cx * a.sx] = xok ? acc[tap][r] : 0.0f;
+                    slab[(int64_t)(tap0 + tap) * a.tap_stride + (int64_t)cy * a.sy + (int64_t)cx * a.sx] = xok ? acc[tap][r] : 0.0f;
             }
         }
     }
@@ -279,29 +287,43 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
 
 struct Plan { int nsplit; int64_t slab_stride; };
 
+// tap groups of a launch: one filter row per workgroup where the output has >= 16 channel blocks of 64 x 64 (the deep
+// layers: their maps are small, so staging them three times costs less than two thirds of the slab traffic saves)
+template <int BYB, int BXB>
+int tap_groups(const PWgradArgs& a, int nkx) {
+    static const int force = getenv("RFI_PWGRAD_TG") ? atoi(getenv("RFI_PWGRAD_TG")) : 0;     // A/B runs: 1 or 3
+    if (force == 1 || force == 3) return force;
+    const int chunks = (int)cdiv(plane_chunks(a.Cy), 2 * BYB) * (int)cdiv(nkx, 2 * BXB);
+    return chunks >= 16 ? 3 : 1;
+}
 template <int R, int S, int BYB, int BXB, int TH, int TW>
 Plan plan_cfg(const PWgradArgs& a, int nkx) {
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
-    const int chunks = (int)cdiv(plane_chunks(a.Cy), 2 * BYB) * (int)cdiv(nkx, 2 * BXB);
+    const int chunks = (int)cdiv(plane_chunks(a.Cy), 2 * BYB) * (int)cdiv(nkx, 2 * BXB) * tap_groups<BYB, BXB>(a, nkx);
     int nsplit = (int)cdiv(512, chunks);             // two workgroups per CU in total
     if (nsplit > ntiles) nsplit = ntiles;
     if (nsplit < 1) nsplit = 1;
     return Plan{nsplit, (int64_t)R * R * a.tap_stride};
 }
 
-template <int R, int S, int BYB, int BXB, int TH, int TW, int P>
+template <int R, int S, int BYB, int BXB, int TH, int TW, int P, int TG = 0>
 void launch_cfg(rfi_ctx* ctx, PWgradDev& d) {
+    if constexpr (TG == 0) {                          // pick the tap grouping of this launch
+        if (tap_groups<BYB, BXB>(d.a, d.nkx) == 3) return launch_cfg<R, S, BYB, BXB, TH, TW, P, 3>(ctx, d);
+        return launch_cfg<R, S, BYB, BXB, TH, TW, P, 1>(ctx, d);
+    }
+    constexpr int TGK = TG == 0 ? 1 : TG;
     using C = PWCfg<R, S, BYB, BXB, TH, TW, P>;
     const PWgradArgs& a = d.a;
     const Plan p = plan_cfg<R, S, BYB, BXB, TH, TW>(a, d.nkx);
     RFI_REQUIRE(a.slab && a.slab_floats >= (size_t)p.nsplit * p.slab_stride, "pwgrad: slab workspace too small");
     d.nsplit = p.nsplit;
     d.slab_stride = p.slab_stride;
-    dim3 grid(p.nsplit, (unsigned)cdiv(plane_chunks(a.Cy), 2 * BYB), (unsigned)cdiv(d.nkx, 2 * BXB));
+    dim3 grid(p.nsplit * TGK, (unsigned)cdiv(plane_chunks(a.Cy), 2 * BYB), (unsigned)cdiv(d.nkx, 2 * BXB));
     const size_t lds = C::LDS_BYTES;
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pwgrad_kernel<R, S, BYB, BXB, TH, TW, P>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pwgrad_kernel<R, S, BYB, BXB, TH, TW, P, TGK>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
     {
@@ -311,11 +333,11 @@ void launch_cfg(rfi_ctx* ctx, PWgradDev& d) {
         if (ctx->profiling)
             label = "pwgrad R" + std::to_string(R) + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
                     std::to_string(a.W) + " cx" + std::to_string(a.seg_c[0] + a.seg_c[1]) + " cy" + std::to_string(a.Cy) +
-                    " split" + std::to_string(p.nsplit) + (P == 3 ? " 3xbf16" : " bf16");
+                    " split" + std::to_string(p.nsplit) + (TGK > 1 ? "x3taps" : "") + (P == 3 ? " 3xbf16" : " bf16");
         const double cx = a.seg_c[0] + a.seg_c[1];
         const double bytes = 2.0 * P * ((double)a.N * a.Hx * a.Wx * cx + (double)a.N * a.H * a.W * a.Cy) + 4.0 * R * R * cx * a.Cy;
         ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, bytes, label);
-        hipLaunchKernelGGL((pwgrad_kernel<R, S, BYB, BXB, TH, TW, P>), grid, dim3(256), lds, ctx->stream, d);
+        hipLaunchKernelGGL((pwgrad_kernel<R, S, BYB, BXB, TH, TW, P, TGK>), grid, dim3(256), lds, ctx->stream, d);
         check_launch("pwgrad");
     }
     launch_reduce_slabs(ctx, a.slab, p.nsplit, p.slab_stride, a.dw);
