@@ -350,6 +350,12 @@ int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int
  *   (beta) over positives / num_sampled; dhead = gradient of (objectness + box) w.r.t. the head output. */
 int rfi_op_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,
                       float clip_w, float* boxes);
+/* anchor_match: the Matcher + BoxCoder.encode of RPN training on device -- per anchor the first-argmax ground truth,
+ *   label 1 (IoU >= fg_iou, or, with allow_low_quality, the anchor attains some ground truth's best IoU), 0 (IoU < bg_iou),
+ *   -1 (between); matched[n] = ground-truth index for labels 1 (else -1); targets[n][4] (may be null) = encoded deltas of the
+ *   positives, zeros elsewhere.  The random 256-anchor sampling that follows stays on the host. */
+int rfi_op_anchor_match(rfi_ctx* ctx, const float* anchors, int64_t n, const float* gt_boxes, int n_gt, float fg_iou, float bg_iou,
+                        int allow_low_quality, int8_t* labels, int32_t* matched, float* targets);
 int rfi_op_nms(rfi_ctx* ctx, const float* boxes_sorted, int n, float iou_threshold, int32_t* keep_host, int* n_keep);
 int rfi_op_rpn_loss(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
                     const float* targets, int64_t num_sampled, float beta, float* dhead, float* loss_objectness,

@@ -173,3 +173,34 @@ def rpn_loss(head, labels, targets, A, beta=1.0 / 9):
     g[:, :A] = (1.0 / (1.0 + np.exp(-x)) - t) * samp / n
     g[:, A:] = (np.where(ae < beta, e / beta, np.sign(e)) / n).reshape(P, 4 * A)
     return l_obj, l_box, g
+
+
+def anchor_match(anchors, gt, hi=0.7, lo=0.3, allow_low_quality=True):
+    """Matcher + BoxCoder.encode of the usual RPN implementation, float32 IoUs (the comparison with the thresholds and the
+    equality of the low-quality rule are decided on the values the device computes: same formula, same order)."""
+    a = np.asarray(anchors, np.float32).reshape(-1, 4)
+    g = np.asarray(gt, np.float32).reshape(-1, 4)
+    n = len(a)
+    if len(g) == 0:
+        return np.zeros(n, np.int8), np.full(n, -1, np.int32), np.zeros((n, 4), np.float32)
+    f = np.float32
+    iw = np.maximum(np.minimum(g[:, None, 2], a[None, :, 2]) - np.maximum(g[:, None, 0], a[None, :, 0]), f(0))
+    ih = np.maximum(np.minimum(g[:, None, 3], a[None, :, 3]) - np.maximum(g[:, None, 1], a[None, :, 1]), f(0))
+    inter = (iw * ih).astype(f)
+    area_g = ((g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1])).astype(f)
+    area_a = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])).astype(f)
+    iou = (inter / ((area_g[:, None] + area_a[None, :]).astype(f) - inter).astype(f)).astype(f)        # (g, n)
+    mv, mi = iou.max(0), iou.argmax(0)
+    lab = np.where(mv >= f(hi), 1, np.where(mv < f(lo), 0, -1)).astype(np.int8)
+    if allow_low_quality:
+        best = iou.max(1)
+        lq = ((iou == best[:, None]) & (iou > 0)).any(0)
+        lab[lq] = 1
+    matched = np.where(lab == 1, mi, -1).astype(np.int32)
+    t = np.zeros((n, 4), np.float64)
+    pos = lab == 1
+    ga, aa = g[matched[pos]].astype(np.float64), a[pos].astype(np.float64)
+    aw, ah, gw, gh = aa[:, 2] - aa[:, 0], aa[:, 3] - aa[:, 1], ga[:, 2] - ga[:, 0], ga[:, 3] - ga[:, 1]
+    t[pos] = np.stack([((ga[:, 0] + 0.5 * gw) - (aa[:, 0] + 0.5 * aw)) / aw, ((ga[:, 1] + 0.5 * gh) - (aa[:, 1] + 0.5 * ah)) / ah,
+                       np.log(gw / aw), np.log(gh / ah)], 1)
+    return lab, matched, t

@@ -1621,6 +1621,16 @@ int rfi_op_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, con
         launch_box_decode(ctx, anchors, n_anchors, deltas, n, clip_h, clip_w, boxes);
     });
 }
+int rfi_op_anchor_match(rfi_ctx* ctx, const float* anchors, int64_t n, const float* gt_boxes, int n_gt, float fg_iou, float bg_iou,
+                        int allow_low_quality, int8_t* labels, int32_t* matched, float* targets) {
+    return guarded([&] {
+        ctx->activate();
+        float* ws = static_cast<float*>(ctx->alloc((size_t)(n_gt > 0 ? n_gt : 1) * sizeof(float)));
+        struct Free { rfi_ctx* c; void* p; ~Free() { (void)hipStreamSynchronize(c->stream); try { c->release(p); } catch (...) {} } } fr{ctx, ws};
+        launch_anchor_match(ctx, anchors, n, gt_boxes, n_gt, fg_iou, bg_iou, allow_low_quality != 0, ws,
+                            reinterpret_cast<signed char*>(labels), matched, targets);
+    });
+}
 int rfi_op_nms(rfi_ctx* ctx, const float* boxes_sorted, int n, float iou_threshold, int32_t* keep_host, int* n_keep) {
     return guarded([&] {
         RFI_REQUIRE(keep_host && n_keep, "nms: null output");

@@ -289,6 +289,10 @@ void launch_fpn_merge_bwd_top(rfi_ctx* ctx, const float* dout, int N, int H, int
 // when clip_w > 0; anchors [n_anchors][4] repeat over the n = k * n_anchors delta rows
 void launch_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,
                        float clip_w, float* out);
+// anchors vs G ground-truth boxes (device pointers): labels int8 (1 / 0 / -1), matched ground-truth index (labels 1, else
+// -1) and, if targets != null, the encoded regression targets [n][4]; best_ws: G floats of scratch
+void launch_anchor_match(rfi_ctx* ctx, const float* anchors, int64_t n, const float* gt, int G, float hi, float lo, bool low_quality,
+                         float* best_ws, signed char* labels, int* matched, float* targets);
 // suppression bit matrix [n][ceil(n / 64)] of boxes sorted by descending score (bit j of row i: j > i and IoU > thr)
 void launch_nms_mask(rfi_ctx* ctx, const float* boxes, int n, float thr, unsigned long long* mask);
 // RPN loss on a head output [P][5 A]: BCE on the sampled anchors + smooth L1 on the positives, both / num_sampled;

@@ -118,7 +118,86 @@ __global__ void rpn_loss_finish_kernel(const double* __restrict__ partial, int b
     }
 }
 
+// ---- anchor <-> ground-truth matching (the Matcher of the usual implementation): IoU matrix never materialised
+__device__ __forceinline__ float iou_of(const float4 a, const float4 b) {
+    const float iw = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f), ih = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
+    const float inter = iw * ih;
+    return inter / ((a.z - a.x) * (a.w - a.y) + (b.z - b.x) * (b.w - b.y) - inter);
+}
+// best[g] = max over anchors of IoU(gt g, anchor): one block per ground-truth box
+__global__ __launch_bounds__(kB) void gt_best_iou_kernel(const float* __restrict__ anchors, int64_t n, const float* __restrict__ gt,
+                                                        float* __restrict__ best) {
+    __shared__ float red[kB];
+    const float4 g = *reinterpret_cast<const float4*>(gt + (int64_t)blockIdx.x * 4);
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += kB) m = fmaxf(m, iou_of(g, *reinterpret_cast<const float4*>(anchors + i * 4)));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = kB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) best[blockIdx.x] = red[0];
+}
+// per anchor: matched ground truth = first argmax of the IoU; label 1 (IoU >= hi, or -- low-quality rule -- the anchor
+// attains some ground truth's best IoU), 0 (IoU < lo), -1 (between); matched index kept for labels 1 only (else -1)
+__global__ __launch_bounds__(kB) void anchor_match_kernel(const float* __restrict__ anchors, int64_t n, const float* __restrict__ gt,
+                                                         int G, const float* __restrict__ best, float hi, float lo, int low_quality,
+                                                         signed char* __restrict__ labels, int* __restrict__ matched) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = *reinterpret_cast<const float4*>(anchors + i * 4);
+        float mv = -1.0f;
+        int mi = -1;
+        bool lq = false;
+        for (int g = 0; g < G; ++g) {
+            const float v = iou_of(*reinterpret_cast<const float4*>(gt + (int64_t)g * 4), a);
+            if (v > mv) { mv = v; mi = g; }
+            lq = lq || (low_quality && v == best[g] && v > 0.0f);
+        }
+        int lab = G == 0 ? 0 : (mv >= hi ? 1 : (mv < lo ? 0 : -1));
+        if (lq) lab = 1;
+        labels[i] = (signed char)lab;
+        matched[i] = lab == 1 ? mi : -1;
+    }
+}
+// regression targets of the positive anchors: encode(gt[matched], anchor) with weights 1; zeros elsewhere
+__global__ __launch_bounds__(kB) void box_encode_kernel(const float* __restrict__ anchors, int64_t n, const float* __restrict__ gt,
+                                                       const int* __restrict__ matched, float* __restrict__ targets) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int m = matched[i];
+        if (m >= 0) {
+            const float4 a = *reinterpret_cast<const float4*>(anchors + i * 4), g = *reinterpret_cast<const float4*>(gt + (int64_t)m * 4);
+            const float aw = a.z - a.x, ah = a.w - a.y, gw = g.z - g.x, gh = g.w - g.y;
+            t = make_float4(((g.x + 0.5f * gw) - (a.x + 0.5f * aw)) / aw, ((g.y + 0.5f * gh) - (a.y + 0.5f * ah)) / ah, logf(gw / aw),
+                            logf(gh / ah));
+        }
+        *reinterpret_cast<float4*>(targets + i * 4) = t;
+    }
+}
+
 }  // namespace
+
+void launch_anchor_match(rfi_ctx* ctx, const float* anchors, int64_t n, const float* gt, int G, float hi, float lo, bool low_quality,
+                         float* best_ws, signed char* labels, int* matched, float* targets) {
+    RFI_REQUIRE(n > 0 && G >= 0, "anchor_match: empty anchors");
+    RFI_REQUIRE(!((reinterpret_cast<uintptr_t>(anchors) | reinterpret_cast<uintptr_t>(gt) | reinterpret_cast<uintptr_t>(targets)) & 15),
+                "anchor_match: 16-byte aligned boxes");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n * (16.0 * (G > 0 ? 2 : 1) + 21));
+    if (G > 0) {
+        hipLaunchKernelGGL(gt_best_iou_kernel, dim3(G), dim3(kB), 0, ctx->stream, anchors, n, gt, best_ws);
+        check_launch("gt_best_iou");
+    }
+    int64_t b = cdiv(n, kB);
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(anchor_match_kernel, dim3((unsigned)b), dim3(kB), 0, ctx->stream, anchors, n, gt, G, best_ws, hi, lo,
+                       low_quality ? 1 : 0, labels, matched);
+    check_launch("anchor_match");
+    if (targets) {
+        hipLaunchKernelGGL(box_encode_kernel, dim3((unsigned)b), dim3(kB), 0, ctx->stream, anchors, n, gt, matched, targets);
+        check_launch("box_encode");
+    }
+}
 
 void launch_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,
                        float clip_w, float* out) {

@@ -118,3 +118,18 @@ def rpn_loss(head, labels, targets, anchors_per_pixel, beta=1.0 / 9, device=None
     check(lib.rfi_op_rpn_loss(ctx.handle, _p(dh), dh.shape[0], a, _p(dl), _p(dt), int((lab >= 0).sum()), float(beta), _p(dg),
                               C.byref(lo), C.byref(lb)))
     return lo.value, lb.value, dg.numpy()
+
+
+def anchor_match(anchors, gt_boxes, fg_iou=0.7, bg_iou=0.3, allow_low_quality=True, device=None):
+    """RPN training targets of one image: anchors (n, 4) vs ground truth (g, 4) -> labels int8 (n,) in {1, 0, -1}, matched
+    ground-truth index int32 (n,) (-1 unless positive), regression targets float32 (n, 4) (zeros unless positive)."""
+    ctx = Context.get(device)
+    da = _dev(ctx, np.asarray(anchors, np.float32).reshape(-1, 4))
+    g = np.asarray(gt_boxes, np.float32).reshape(-1, 4)
+    dg = ctx.to_device(np.ascontiguousarray(g if len(g) else np.zeros((1, 4), np.float32)))
+    n = da.shape[0]
+    labels, matched, targets = ctx.empty((n,), np.int8), ctx.empty((n,), np.int32), ctx.empty((n, 4), np.float32)
+    check(lib.rfi_op_anchor_match(ctx.handle, _p(da), n, _p(dg), len(g), float(fg_iou), float(bg_iou), 1 if allow_low_quality else 0,
+                                  _p(labels), _p(matched), _p(targets)))
+    ctx.synchronize()
+    return labels.numpy(), matched.numpy(), targets.numpy()

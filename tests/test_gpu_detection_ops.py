@@ -114,3 +114,28 @@ def test_rpn_loss_forward_backward(p, a):
     # nothing sampled: zero loss, zero gradient
     lo, lb, g = ops.rpn_loss(head, np.full(p * a, -1, np.int8), targets, a)
     assert lo == 0.0 and lb == 0.0 and not g.any()
+
+
+@pytest.mark.parametrize("n,g", [(500, 0), (3000, 1), (20000, 7), (257, 40)])
+def test_anchor_match_and_encode(n, g):
+    rng = np.random.default_rng(n + g)
+    anchors = _anchors(rng, n)
+    gt = _anchors(rng, g) if g else np.zeros((0, 4), np.float32)
+    if g:
+        anchors[5] = gt[0]                                    # an exact hit (IoU 1)
+    lab, matched, targets = ops.anchor_match(anchors, gt)
+    wl, wm, wt = ref.anchor_match(anchors, gt)
+    # the device contracts a*b+c into FMAs where NumPy rounds twice: an IoU within 1 ulp of a threshold may differ
+    diff = np.flatnonzero(lab != wl)
+    assert len(diff) <= max(1, n // 5000), (len(diff), n)
+    same = lab == wl
+    np.testing.assert_array_equal(matched[same & (lab == 1)], wm[same & (lab == 1)])
+    assert (matched[lab != 1] == -1).all()
+    pos = same & (lab == 1)
+    if pos.any():
+        assert np.abs(targets[pos] - wt[pos]).max() <= 2e-5 * max(1.0, np.abs(wt[pos]).max())
+    assert not targets[lab != 1].any()
+    if g:
+        assert lab[5] == 1 and matched[5] == 0
+        for k in range(g):                                   # every ground truth keeps at least one positive anchor
+            assert (matched == k).any() or (wm == k).sum() == 0
