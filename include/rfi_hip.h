@@ -109,6 +109,19 @@ int rfi_model_input_grad(rfi_model* m, float* dx, int dx_mem);
  * gradients and the input gradient (rfi_model_input_grad), rfi_train_apply steps the optimiser.  Also valid for the
  * mask head. */
 int rfi_rpn_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int anchors_per_pixel, rfi_model** out);
+/* The ResNet-50-FPN backbone of the Mask R-CNN path (not in the reference: the published networks with the
+ * layer names and the FROZEN BatchNorm of the usual detection backbone, oracle/backbone_ref.py).  base_width 64 and
+ * fpn_channels 256 give ResNet-50; both must be multiples of 4, H and W multiples of 64.  Entries: body.conv1.weight,
+ * body.bn1.{weight,bias,running_mean,running_var}, body.layer{1..4}.{b}.conv{1,2,3}.weight / .bn{1,2,3}.* /
+ * .downsample.{0.weight,1.*}, fpn.inner_blocks.{i}.0.{weight,bias}, fpn.layer_blocks.{i}.0.{weight,bias}; BatchNorm entries
+ * are buffers (never updated), every conv weight and FPN bias is a parameter of rfi_train_apply.
+ * backbone_forward: feats[0..4] = P2..P6, [n, h >> (2 + i), w >> (2 + i), fpn_channels] each (null entries are skipped);
+ * backbone_backward (after a forward pass on the same input): dfeats[i] = d(loss)/d(P_{2+i}) (null = zero) -> parameter
+ * gradients. */
+int rfi_resnet50_fpn_create(rfi_ctx* ctx, int in_channels, int base_width, int fpn_channels, rfi_model** out);
+int rfi_backbone_forward(rfi_model* m, const float* x, int x_mem, int n, int h, int w, float* const feats[5], int feats_mem);
+int rfi_backbone_backward(rfi_model* m, const float* x, int x_mem, int n, int h, int w, const float* const dfeats[5],
+                          int dfeats_mem);
 int rfi_model_backward_dlogits(rfi_model* m, const float* x, int x_mem, const float* dlogits, int dlogits_mem, int n, int h,
                                int w);
 int rfi_model_destroy(rfi_model* m);

@@ -67,6 +67,9 @@ _PROTOS = {
     "rfi_mask_head_create": (_i, [_vp, _i, _i, _i, _pvp]),
     "rfi_model_input_grad": (_i, [_vp, _vp, _i]),
     "rfi_rpn_head_create": (_i, [_vp, _i, _i, _i, _pvp]),
+    "rfi_resnet50_fpn_create": (_i, [_vp, _i, _i, _i, _pvp]),
+    "rfi_backbone_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _pvp, _i]),
+    "rfi_backbone_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _pvp, _i]),
     "rfi_model_backward_dlogits": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i]),
     "rfi_model_set_activation": (_i, [_vp, _f]),
     "rfi_model_set_compute_dtype": (_i, [_vp, _i]),

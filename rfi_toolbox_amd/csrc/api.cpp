@@ -340,6 +340,25 @@ int rfi_mask_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int out
         *out = m;
     });
 }
+int rfi_resnet50_fpn_create(rfi_ctx* ctx, int in_channels, int base_width, int fpn_channels, rfi_model** out) {
+    return guarded([&] {
+        RFI_REQUIRE(ctx && out, "rfi_resnet50_fpn_create: null argument");
+        auto* m = new rfi_model();
+        m->ctx = ctx;
+        m->arch = 5;
+        m->in_ch = in_channels;
+        m->feat = base_width;
+        m->out_ch = fpn_channels;
+        try {
+            m->build();
+        } catch (...) {
+            m->ctx = nullptr;
+            delete m;
+            throw;
+        }
+        *out = m;
+    });
+}
 int rfi_rpn_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int anchors_per_pixel, rfi_model** out) {
     return guarded([&] {
         RFI_REQUIRE(ctx && out, "rfi_rpn_head_create: null argument");
@@ -455,10 +474,10 @@ void store_from_flat(rfi_model* m, const float* flat, const Entry& e, void* host
                     std::to_string(bytes));
     const size_t off = flat_offset(m, e);
     const int cin_p = e.kind == 0 ? m->convs[e.layer].cin_p : 0;
-    std::vector<float> tmp(e.kind == 0 ? (size_t)9 * e.dims[0] * cin_p : (size_t)e.numel());
+    std::vector<float> tmp(e.kind == 0 ? (size_t)e.dims[2] * e.dims[3] * e.dims[0] * cin_p : (size_t)e.numel());
     download(m, tmp.data(), flat + off, tmp.size());
     float* out = static_cast<float*>(host);
-    if (e.kind == 0) from_lib_conv(tmp.data(), (int)e.dims[0], (int)e.dims[1], 3, out, cin_p);
+    if (e.kind == 0) from_lib_conv(tmp.data(), (int)e.dims[0], (int)e.dims[1], (int)e.dims[2], out, cin_p);
     else if (e.kind == 1) from_lib_convt(tmp.data(), (int)e.dims[0], (int)e.dims[1], out);
     else std::memcpy(out, tmp.data(), bytes);
 }
@@ -482,7 +501,7 @@ int rfi_model_init(rfi_model* m, uint64_t seed) {
                 float* w = flat.data() + flat_offset(m, e);
                 if (e.kind == 0) {                      // [tap][cout][cin_p], padded channels stay 0
                     const int cin_p = m->convs[e.layer].cin_p, cin = (int)e.dims[1];
-                    for (int64_t r = 0; r < 9 * e.dims[0]; ++r)
+                    for (int64_t r = 0; r < e.dims[2] * e.dims[3] * e.dims[0]; ++r)
                         for (int ci = 0; ci < cin; ++ci) w[r * cin_p + ci] = uni(last_bound);
                 } else {
                     for (int64_t i = 0; i < e.numel(); ++i) w[i] = uni(last_bound);   // layout-agnostic iid
@@ -536,13 +555,15 @@ int rfi_model_load_entry(rfi_model* m, const char* name, const void* host, size_
                     "size mismatch for " + e.name + ": expected " + std::to_string(e.numel() * 4) +
                         " bytes, got " + std::to_string(bytes));
         const float* src = static_cast<const float*>(host);
-        if (e.kind == 3 || e.kind == 4) {
+        if (e.kind == 3 || e.kind == 4 || e.kind == 8 || e.kind == 9) {     // (8 / 9: frozen BatchNorm weight / bias)
             ConvBN& c = m->convs[e.layer];
-            upload(m, e.kind == 3 ? c.running_mean() : c.running_var(), src, (size_t)c.cout);
+            float* dst = e.kind == 3 ? c.running_mean() : (e.kind == 4 ? c.running_var() : (e.kind == 8 ? c.mean() : c.invstd()));
+            upload(m, dst, src, (size_t)c.cout);
+            m->frozen_dirty = true;
             return;
         }
         std::vector<float> tmp;
-        if (e.kind == 0) to_lib_conv(src, (int)e.dims[0], (int)e.dims[1], 3, tmp, m->convs[e.layer].cin_p);
+        if (e.kind == 0) to_lib_conv(src, (int)e.dims[0], (int)e.dims[1], (int)e.dims[2], tmp, m->convs[e.layer].cin_p);
         else if (e.kind == 1) to_lib_convt(src, (int)e.dims[0], (int)e.dims[1], tmp);
         else tmp.assign(src, src + e.numel());
         upload(m, m->params + flat_offset(m, e), tmp.data(), tmp.size());
@@ -560,11 +581,11 @@ int rfi_model_store_entry(rfi_model* m, const char* name, void* host, size_t byt
             *static_cast<int64_t*>(host) = m->convs[e.layer].nbt;
             return;
         }
-        if (e.kind == 3 || e.kind == 4) {
+        if (e.kind == 3 || e.kind == 4 || e.kind == 8 || e.kind == 9) {
             RFI_REQUIRE(bytes == (size_t)e.numel() * sizeof(float), "size mismatch for " + e.name);
             ConvBN& c = m->convs[e.layer];
-            download(m, static_cast<float*>(host), e.kind == 3 ? c.running_mean() : c.running_var(),
-                     (size_t)c.cout);
+            const float* srcd = e.kind == 3 ? c.running_mean() : (e.kind == 4 ? c.running_var() : (e.kind == 8 ? c.mean() : c.invstd()));
+            download(m, static_cast<float*>(host), srcd, (size_t)c.cout);
             return;
         }
         store_from_flat(m, m->params, e, host, bytes);
@@ -599,7 +620,7 @@ int rfi_model_load_adam(rfi_model* m, const char* name, const void* host_m, cons
             const float* src = static_cast<const float*>(which ? host_v : host_m);
             if (!src) continue;
             std::vector<float> tmp;
-            if (e.kind == 0) to_lib_conv(src, (int)e.dims[0], (int)e.dims[1], 3, tmp, m->convs[e.layer].cin_p);
+            if (e.kind == 0) to_lib_conv(src, (int)e.dims[0], (int)e.dims[1], (int)e.dims[2], tmp, m->convs[e.layer].cin_p);
             else if (e.kind == 1) to_lib_convt(src, (int)e.dims[0], (int)e.dims[1], tmp);
             else tmp.assign(src, src + e.numel());
             upload(m, (which ? m->adam_v : m->adam_m) + off, tmp.data(), tmp.size());
@@ -809,6 +830,43 @@ int rfi_model_backward_dlogits(rfi_model* m, const float* x, int x_mem, const fl
         RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
     });
 }
+int rfi_backbone_forward(rfi_model* m, const float* x, int x_mem, int n, int h, int w, float* const feats[5], int feats_mem) {
+    return guarded([&] {
+        RFI_REQUIRE(m->arch == 5 && feats, "backbone_forward: ResNet-50-FPN models only");
+        m->ctx->activate();
+        m->prepare(n, h, w);
+        const float* xd = stage_input(m, x, x_mem, n, h, w, false);
+        m->forward(xd, n, h, w, false);
+        for (int i = 0; i < 5; ++i) {
+            if (!feats[i]) continue;
+            const int lvl = i + 2;
+            const size_t cnt = (size_t)n * (h >> lvl) * (w >> lvl) * m->out_ch;
+            RFI_CHECK_HIP(hipMemcpyAsync(feats[i], m->buf(i < 4 ? m->fP[i] : m->fP6), cnt * sizeof(float),
+                                         feats_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
+        }
+        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    });
+}
+int rfi_backbone_backward(rfi_model* m, const float* x, int x_mem, int n, int h, int w, const float* const dfeats[5], int dfeats_mem) {
+    return guarded([&] {
+        RFI_REQUIRE(m->arch == 5 && dfeats, "backbone_backward: ResNet-50-FPN models only");
+        RFI_REQUIRE(m->pN == n && m->pH == h && m->pW == w, "backbone_backward: run the forward pass on this input first");
+        m->ctx->activate();
+        const float* xd = stage_input(m, x, x_mem, n, h, w, false);
+        for (int i = 0; i < 5; ++i) {
+            const int lvl = i + 2;
+            const size_t cnt = (size_t)n * (h >> lvl) * (w >> lvl) * m->out_ch;
+            float* dst = m->buf(i < 4 ? m->fdP[i] : m->fdP6);
+            if (dfeats[i])
+                RFI_CHECK_HIP(hipMemcpyAsync(dst, dfeats[i], cnt * sizeof(float),
+                                             dfeats_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->ctx->stream));
+            else
+                RFI_CHECK_HIP(hipMemsetAsync(dst, 0, cnt * sizeof(float), m->ctx->stream));
+        }
+        m->backward(xd, nullptr, n, h, w);
+        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    });
+}
 int rfi_model_last_loss(rfi_model* m, float* loss_out, float* grad_norm_out) {
     return guarded([&] {
         m->ctx->activate();
@@ -932,6 +990,12 @@ int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, 
         // 2*M*K*N over every conv / convT / head, each layer evaluated once
         double f = 0, stem = 0;
         const int D = m->depth;
+        if (m->arch == 5) {             // every conv once at its output resolution (the stem's 7x7 has stride 2)
+            for (auto& c : m->convs) f += 2.0 * n * (double)(h >> c.level) * (w >> c.level) * c.R * c.R * c.cin * c.cout;
+            if (fwd) *fwd = f;
+            if (step) *step = 3.0 * f - 2.0 * n * (double)(h >> 1) * (w >> 1) * 49.0 * m->convs[0].cin * m->convs[0].cout;
+            return;
+        }
         if (m->arch == 3 || m->arch == 4) {   // mask / RPN head: L 3x3 convs, (the transposed conv,) the 1x1 head
             const double M = (double)n * h * w, C = m->in_ch, s2 = (double)m->out_scale * m->out_scale;
             f = m->depth * 2.0 * M * 9.0 * C * C + (m->arch == 3 ? 2.0 * M * 4.0 * C * C : 0.0) + 2.0 * s2 * M * C * m->out_ch;

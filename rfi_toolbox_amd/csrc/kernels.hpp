@@ -311,6 +311,14 @@ void launch_add_inplace(rfi_ctx* ctx, float* x, const float* y, int64_t n);
 // 3x3 stride-2 filters [9][Cout][Cin] <-> their 2x2 form on the space-to-depth input [4][Cout][4 Cin]
 void launch_w_s2d(rfi_ctx* ctx, float* w3, int Cout, int Cin, float* w2, bool to_s2d);
 
+// MaxPool2d(3, 2, 1) of act(y * scale + shift) (scale null: of y) + first-argmax bytes (4 channels per word); its adjoint
+// (gather); x[:, ::2, ::2] and its adjoint added into dx
+void launch_maxpool3_fwd(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale, const float* shift, float* out,
+                         unsigned* arg4);
+void launch_maxpool3_bwd(rfi_ctx* ctx, const float* dout, const unsigned* arg4, int N, int H, int W, int C, float* da);
+void launch_subsample2(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, float* out);
+void launch_subsample2_bwd_add(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, float* dx);
+
 // generic: out[i] = sum_s slabs[s*n + i]
 void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n, float* out);
 

@@ -48,7 +48,7 @@ rfi_model::~rfi_model() {
     for (auto& b : pl) b.free();
     if (wb_pool) ctx->release(wb_pool);
     if (wb_descs) ctx->release(wb_descs);
-    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool})
+    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool})   // (rs_wpool: arch 2 and 5)
         if (p) ctx->release(p);
     if (relayout_descs) ctx->release(relayout_descs);
     if (x3_descs) ctx->release(x3_descs);
@@ -67,6 +67,7 @@ void rfi_model::build() {
     if (arch != 0) planesP = 0;                       // the plane data flow exists for the plain U-Net only
     if (arch == 1) return build_cnn3();
     if (arch == 3 || arch == 4) return build_mask();
+    if (arch == 5) return build_backbone();
     if (arch == 2) return build_resnet();
     RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
     RFI_REQUIRE(depth >= 1 && depth <= 6, "UNet: depth must be in [1,6]");
@@ -244,6 +245,7 @@ void rfi_model::prepare(int n, int h, int w) {
     }
     if (arch == 1) return prepare_cnn3(n, h, w);
     if (arch == 3 || arch == 4) return prepare_mask(n, h, w);
+    if (arch == 5) return prepare_backbone(n, h, w);
     const int div = 1 << depth;
     RFI_REQUIRE(h % div == 0 && w % div == 0,
                 "forward: H and W must be multiples of 2^depth (" + std::to_string(div) +
@@ -454,6 +456,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
     refresh_dgrad_weights();          // derived filter copies (dgrad layout, 3 x bf16 records) follow the parameters
     if (arch == 1) return forward_cnn3(x_dev, n, h, w);
     if (arch == 3 || arch == 4) return forward_mask(x_dev, n, h, w);
+    if (arch == 5) return forward_backbone(x_dev, n, h, w);
     if (planesP) return forward_planes(x_dev, n, h, w, train_mode);
     const int D = depth, IB = i_bott;
     View cur = network_input(x_dev, n, h, w);
@@ -663,6 +666,11 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
 }  // namespace
 
 void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
+    if (arch == 5) {
+        backward_backbone(x_dev, n, h, w);
+        bucket_ready(0, n_flat);
+        return;
+    }
     if (arch == 3 || arch == 4) {
         backward_mask(x_dev, labels_dev, n, h, w);
         bucket_ready(0, n_flat);

@@ -69,7 +69,7 @@ struct Entry {
     int ndim = 0;
     int64_t dims[4] = {0, 0, 0, 0};
     int kind = 0;        // 0 conv weight (OIHW), 1 convT weight (IOHW), 2 vector param, 3 running_mean,
-                         // 4 running_var, 5 num_batches_tracked, 6 final weight, 7 1x1 conv weight of convs[layer]
+                         // 4 running_var, 5 num_batches_tracked, 6 final weight, 8 / 9 frozen BatchNorm weight / bias (buffers), 7 1x1 conv weight of convs[layer]
                          // ([cout][cin][1][1] is the library's [1 tap][cout][cin] as is)
     int layer = -1;      // index into convs / ups; -1 for the head
     int which = 0;       // vector param: 0 conv bias, 1 bn gamma, 2 bn beta, 3 up bias, 4 head bias
@@ -88,7 +88,8 @@ struct rfi_model {
     int arch = 0;                     // 0: U-Net (models/unet.py), 1: 3-layer CNN (depth == 0),
                                       // 2: U-Net with a ResNet-18-style encoder (model_resnet.cpp),
                                       // 3: Mask R-CNN's per-RoI mask head (model_mask.cpp; depth = conv layers),
-                                      // 4: RPN head (the same stack without the transposed conv)
+                                      // 4: RPN head (the same stack without the transposed conv),
+                                      // 5: ResNet-50-FPN backbone, frozen BatchNorm (model_backbone.cpp)
     int i_bott = 0;                   // index of the bottleneck's first conv in `convs` (decoder convs follow it)
     bool training = true;
     float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
@@ -147,6 +148,25 @@ struct rfi_model {
     void reset_channel_state();       // running stats 0/1, BN-less layers: scale 1, shift 0
     float* buf(int i) { return bufs[i].p; }
     int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
+
+    // ---- ResNet-50-FPN backbone with frozen BatchNorm (model_backbone.cpp; arch 5): feat = base width (64), out_ch = FPN channels
+    struct BBlock {
+        int stage = 0, stride = 1, cin = 0, width = 0, cout = 0, lvl_in = 2, lvl = 2;      // resolution H >> lvl
+        int c1 = -1, c2 = -1, c3 = -1, cd = -1;                                           // convs indices (cd: projection shortcut)
+        int Y1 = -1, Y2 = -1, Y3 = -1, Yd = -1, A = -1, xs1 = -1, xsA = -1;               // bufs indices
+        float *sc4 = nullptr, *sh4 = nullptr;             // conv1's affine coefficients tiled x 4 (space-to-depth input of a stride-2 conv2)
+    };
+    std::vector<BBlock> bb;
+    int fpn_inner[4] = {-1, -1, -1, -1}, fpn_layer[4] = {-1, -1, -1, -1};
+    int bY0 = -1, bP0 = -1, bArg = -1, bdW = -1, bS = -1, fP6 = -1, fdP6 = -1;
+    int fL[4] = {-1, -1, -1, -1}, fM[4] = {-1, -1, -1, -1}, fP[4] = {-1, -1, -1, -1}, fdM[4] = {-1, -1, -1, -1}, fdP[4] = {-1, -1, -1, -1};
+    int bG[6] = {-1, -1, -1, -1, -1, -1};
+    bool frozen_dirty = true;         // frozen BatchNorm buffers changed: scale / shift must be recomputed
+    void build_backbone();
+    void prepare_backbone(int n, int h, int w);
+    void refresh_backbone();
+    void forward_backbone(const float* x_dev, int n, int h, int w);
+    void backward_backbone(const float* x_dev, int n, int h, int w);
 
     // ---- per-RoI mask head (model_mask.cpp; arch 3): depth conv3x3+ReLU layers, a transposed conv + ReLU, a 1x1 head.
     // The output map is out_scale (= 2) times the input map in each direction

@@ -129,7 +129,127 @@ __global__ __launch_bounds__(256) void w_s2d_kernel(const float* __restrict__ w3
     }
 }
 
+// MaxPool2d(3, stride 2, padding 1) of a = act(y * scale + shift) (scale == null: a = y), four channels per thread; the
+// position of the FIRST maximum of each window (row-major, 0..8; as torch's CPU kernel: strict >) is kept for the
+// backward pass, which gathers: an input pixel belongs to at most four windows
+__global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const float* __restrict__ y, int N, int H, int W, int C,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ out, unsigned* __restrict__ arg4) {
+    const int C4 = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t t = i / C4;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int n = (int)(t / OH);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (scale) { sc = *reinterpret_cast<const f32x4*>(scale + c); sh = *reinterpret_cast<const f32x4*>(shift + c); }
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned arg = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(y + (((int64_t)n * H + iy) * W + ix) * C + c);
+            if (scale) {
+                v = v * sc + sh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] > best[e]) { best[e] = v[e]; arg = (arg & ~(0xffu << (8 * e))) | ((unsigned)k << (8 * e)); }
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = best;
+        arg4[i] = arg;
+    }
+}
+__global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const float* __restrict__ dout, const unsigned* __restrict__ arg4, int N, int H,
+                                                          int W, int C, float* __restrict__ da) {
+    const int C4 = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int x = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // windows (oy, ox) with 2 oy - 1 <= y <= 2 oy + 1
+        for (int oy = yy / 2; oy <= (yy + 1) / 2; ++oy)
+            for (int ox = x / 2; ox <= (x + 1) / 2; ++ox) {
+                if (oy >= OH || ox >= OW) continue;
+                const int k = (yy - (2 * oy - 1)) * 3 + (x - (2 * ox - 1));
+                const int64_t o = (((int64_t)n * OH + oy) * OW + ox) * C4 + c4;
+                const unsigned arg = arg4[o];
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dout + o * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((arg >> (8 * e)) & 0xffu) == (unsigned)k) g[e] += d[e];
+            }
+        *reinterpret_cast<f32x4*>(da + i * 4) = g;
+    }
+}
+// x[:, ::2, ::2, :] (FPN's extra level) and its adjoint added into dx
+__global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ x, int N, int H, int W, int C, float* __restrict__ out) {
+    const int C4 = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int n = (int)(t / OH);
+        *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(x + ((((int64_t)n * H + 2 * oy) * W + 2 * ox) * C4 + c4) * 4);
+    }
+}
+__global__ __launch_bounds__(256) void subsample2_bwd_add_kernel(const float* __restrict__ dout, int N, int H, int W, int C,
+                                                                float* __restrict__ dx) {
+    const int C4 = C / 4, OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int n = (int)(t / OH);
+        float* q = dx + ((((int64_t)n * H + 2 * oy) * W + 2 * ox) * C4 + c4) * 4;
+        *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(q) + *reinterpret_cast<const f32x4*>(dout + i * 4);
+    }
+}
+
 }  // namespace
+
+void launch_maxpool3_fwd(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale, const float* shift, float* out,
+                         unsigned* arg4) {
+    RFI_REQUIRE(C % 4 == 0, "maxpool3: C % 4 == 0");
+    const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 4 + (double)total * 20);
+    hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(grid_of(total)), dim3(256), 0, ctx->stream, y, N, H, W, C, scale, shift, out, arg4);
+    check_launch("maxpool3_fwd");
+}
+void launch_maxpool3_bwd(rfi_ctx* ctx, const float* dout, const unsigned* arg4, int N, int H, int W, int C, float* da) {
+    RFI_REQUIRE(C % 4 == 0, "maxpool3: C % 4 == 0");
+    const int64_t total = (int64_t)N * H * W * C / 4;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * 16 * 2);
+    hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(grid_of(total)), dim3(256), 0, ctx->stream, dout, arg4, N, H, W, C, da);
+    check_launch("maxpool3_bwd");
+}
+void launch_subsample2(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, float* out) {
+    RFI_REQUIRE(C % 4 == 0, "subsample2: C % 4 == 0");
+    const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * 32);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_of(total)), dim3(256), 0, ctx->stream, x, N, H, W, C, out);
+    check_launch("subsample2");
+}
+void launch_subsample2_bwd_add(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, float* dx) {
+    RFI_REQUIRE(C % 4 == 0, "subsample2: C % 4 == 0");
+    const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * 48);
+    hipLaunchKernelGGL(subsample2_bwd_add_kernel, dim3(grid_of(total)), dim3(256), 0, ctx->stream, dout, N, H, W, C, dx);
+    check_launch("subsample2_bwd_add");
+}
 
 void launch_s2d(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, float* out) {
     RFI_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "space-to-depth: C % 4 == 0, even H and W");
