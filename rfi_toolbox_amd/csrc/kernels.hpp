@@ -319,6 +319,11 @@ void launch_maxpool3_bwd(rfi_ctx* ctx, const float* dout, const unsigned* arg4, 
 void launch_subsample2(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, float* out);
 void launch_subsample2_bwd_add(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, float* dx);
 
+// K-packed stem: out [N, OH, OW, Kp] with k = (r R + s) C + c (zeros beyond R R C and outside the image); the filters
+// [R R][Cout][C] <-> [Cout][Kp] (to_packed = false writes the packed GRADIENT back into the tap layout)
+void launch_im2col(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, int R, int S, int pad, int OH, int OW, int Kp, float* out);
+void launch_w_pack(rfi_ctx* ctx, float* w, int taps, int Cout, int C, int Kp, float* wp, bool to_packed);
+
 // generic: out[i] = sum_s slabs[s*n + i]
 void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n, float* out);
 

@@ -158,7 +158,8 @@ struct rfi_model {
     };
     std::vector<BBlock> bb;
     int fpn_inner[4] = {-1, -1, -1, -1}, fpn_layer[4] = {-1, -1, -1, -1};
-    int bY0 = -1, bP0 = -1, bArg = -1, bdW = -1, bS = -1, fP6 = -1, fdP6 = -1;
+    int bY0 = -1, bP0 = -1, bArg = -1, bdW = -1, bS = -1, bCol = -1, bWp = -1, fP6 = -1, fdP6 = -1;
+    int stem_kp() const { return (49 * in_ch + 15) / 16 * 16; }      // K of the K-packed 7x7 stem
     int fL[4] = {-1, -1, -1, -1}, fM[4] = {-1, -1, -1, -1}, fP[4] = {-1, -1, -1, -1}, fdM[4] = {-1, -1, -1, -1}, fdP[4] = {-1, -1, -1, -1};
     int bG[6] = {-1, -1, -1, -1, -1, -1};
     bool frozen_dirty = true;         // frozen BatchNorm buffers changed: scale / shift must be recomputed

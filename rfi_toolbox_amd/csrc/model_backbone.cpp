@@ -12,8 +12,9 @@
 // Every BatchNorm is FROZEN (per-channel affine from its buffers, as detection fine-tuning does): a conv's raw output is
 // stored and the affine (+ ReLU) is applied by its consumers' loads, exactly like the train-mode BatchNorm of the U-Net
 // but with constant coefficients, so the backward pass needs no statistics: dY = dA * scale * [z > 0].  Trainable: every
-// conv weight and the FPN biases (flat parameter buffer; clip + Adam as everywhere).  The 7x7 stem (3 input channels,
-// 0.2 % of the FLOPs) runs on the direct kernels; stride-2 3x3 convs and projections use the space-to-depth forms of
+// conv weight and the FPN biases (flat parameter buffer; clip + Adam as everywhere).  The 7x7 stem (3 input channels)
+// runs as a GEMM on its K-packed (im2col) input: K = 147 -> 160; on the direct VALU kernels it took 3.8 of 18.5 ms of
+// the forward + backward pass at batch 64 x 128^2.  Stride-2 3x3 convs and projections use the space-to-depth forms of
 // resnet_kernels.hip; everything else is the MFMA conv / split weight-gradient kernels.
 #include <algorithm>
 
@@ -175,7 +176,7 @@ void rfi_model::prepare_backbone(int n, int h, int w) {
         for (int i = 0; i < 4; ++i) { fL[i] = new_buf(); fM[i] = new_buf(); fP[i] = new_buf(); fdM[i] = new_buf(); fdP[i] = new_buf(); }
         fP6 = new_buf(); fdP6 = new_buf();
         for (int i = 0; i < 6; ++i) bG[i] = new_buf();
-        bdW = new_buf(); bS = new_buf();
+        bdW = new_buf(); bS = new_buf(); bCol = new_buf(); bWp = new_buf();
         x_stage = new_buf(); x_stage2 = new_buf(); x_pad = new_buf(); out_stage = new_buf();
         ws_red = new_buf(); ws_slab = new_buf(); lab_stage = new_buf(); logits = new_buf(); dlogits = new_buf();
     }
@@ -206,6 +207,8 @@ void rfi_model::prepare_backbone(int n, int h, int w) {
     bufs[fdP6].ensure(ctx, px(6) * F);
     for (int i = 0; i < 6; ++i) bufs[bG[i]].ensure(ctx, gmax);
     bufs[bS].ensure(ctx, gmax);
+    bufs[bCol].ensure(ctx, px(1) * stem_kp());
+    bufs[bWp].ensure(ctx, (size_t)feat * stem_kp() + 16);
     bufs[bdW].ensure(ctx, wmax + 16);
     bufs[x_stage].ensure(ctx, (size_t)n * h * w * in_ch);
     bufs[x_stage2].ensure(ctx, (size_t)n * h * w * in_ch);
@@ -220,7 +223,7 @@ void rfi_model::prepare_backbone(int n, int h, int w) {
         a.Cx = c.cin; a.Cy = c.cout;
         a.R = c.R; a.S = 1; a.pad = c.R / 2;
         if (c.R == 3 && c.stride == 2) { a.Cx *= 4; a.R = 2; a.pad = 1; }
-        if (c.R == 7) { a.S = 2; a.Hx = h; a.Wx = w; }
+        if (c.R == 7) { a.R = 1; a.pad = 0; a.Cx = stem_kp(); }          // the K-packed stem
         a.xop.pstride = a.Cx; a.yop.pstride = a.Cy;
         a.tap_stride = (int64_t)a.Cx * a.Cy;
         a.bf16x3 = true;
@@ -303,10 +306,12 @@ InXform act_of(const ConvBN& c) { return InXform{c.scale(), c.shift(), 1, 0.0f};
 void rfi_model::forward_backbone(const float* x_dev, int n, int h, int w) {
     refresh_dgrad_weights();
     refresh_backbone();
-    {   // stem: 7x7 / 2 on the direct kernels, then max-pool of the activated output
+    {   // stem: 7x7 / 2 as a GEMM on its K-packed input (K = 49 C padded to a multiple of 16), then max-pool of the activated output
         ConvBN& c = convs[0];
-        conv(this, View{x_dev, in_ch}, InXform{}, Sh{n, h / 2, w / 2}, h, w, params + c.w_off, nullptr, nullptr, in_ch, c.cout, 7, 2, 3,
-             buf(bY0));
+        const int Kp = stem_kp();
+        launch_im2col(ctx, x_dev, n, h, w, in_ch, 7, 2, 3, h / 2, w / 2, Kp, buf(bCol));
+        launch_w_pack(ctx, params + c.w_off, 49, c.cout, in_ch, Kp, buf(bWp), true);
+        conv(this, View{buf(bCol), Kp}, InXform{}, Sh{n, h / 2, w / 2}, h / 2, w / 2, buf(bWp), nullptr, nullptr, Kp, c.cout, 1, 1, 0, buf(bY0));
         launch_maxpool3_fwd(ctx, buf(bY0), n, h / 2, w / 2, c.cout, c.scale(), c.shift(), buf(bP0), reinterpret_cast<unsigned*>(buf(bArg)));
     }
     const float* a_in = buf(bP0);
@@ -450,6 +455,9 @@ void rfi_model::backward_backbone(const float* x_dev, int n, int h, int w) {
         float* dA0 = gother;
         launch_maxpool3_bwd(ctx, gout, reinterpret_cast<const unsigned*>(buf(bArg)), n, H2, W2, c.cout, dA0);
         affine_bwd(this, c, dA0, buf(bY0), (int64_t)n * H2 * W2, 0.0f);
-        wgrad(this, View{x_dev, in_ch}, InXform{}, dA0, c.cout, in_ch, Sh{n, H2, W2}, h, w, 7, 2, 3, grads + c.w_off);
+        (void)x_dev;                                  // (its K-packed copy from the forward pass is the operand)
+        const int Kp = stem_kp();
+        wgrad(this, View{buf(bCol), Kp}, InXform{}, dA0, c.cout, Kp, Sh{n, H2, W2}, H2, W2, 1, 1, 0, buf(bWp));
+        launch_w_pack(ctx, grads + c.w_off, 49, c.cout, in_ch, Kp, buf(bWp), false);
     }
 }

@@ -219,7 +219,60 @@ __global__ __launch_bounds__(256) void subsample2_bwd_add_kernel(const float* __
     }
 }
 
+// K-packing of a small-channel stem conv: out[n, oy, ox, (r * R + s) * C + c] = x[n, oy * S + r - pad, ox * S + s - pad, c]
+// (zero outside the image and for k >= R R C): the R x R conv becomes a 1x1 conv (a GEMM with K = Kp) on the matrix
+// cores instead of a direct VALU kernel.  One thread per 4 consecutive k of one output pixel.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, int N, int H, int W, int C, int R, int S, int pad,
+                                                    int OH, int OW, int Kp, float* __restrict__ out) {
+    const int K4 = Kp / 4, K = R * R * C;
+    const int64_t total = (int64_t)N * OH * OW * K4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k0 = (int)(i % K4) * 4;
+        int64_t t = i / K4;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int n = (int)(t / OH);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            if (k < K) {
+                const int c = k % C, tap = k / C;
+                const int iy = oy * S + tap / R - pad, ix = ox * S + tap % R - pad;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v[e] = x[(((int64_t)n * H + iy) * W + ix) * C + c];
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+// filters [R R][Cout][C] <-> [Cout][Kp] (k = tap * C + c; zero padding), the second direction for the gradient
+__global__ __launch_bounds__(256) void w_pack_kernel(float* __restrict__ w, int taps, int Cout, int C, int Kp, float* __restrict__ wp,
+                                                    int to_packed) {
+    const int64_t total = (int64_t)Cout * Kp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp), co = (int)(i / Kp);
+        const bool in = k < taps * C;
+        const int64_t j = in ? ((int64_t)(k / C) * Cout + co) * C + (k % C) : 0;
+        if (to_packed) wp[i] = in ? w[j] : 0.0f;
+        else if (in) w[j] = wp[i];
+    }
+}
+
 }  // namespace
+
+void launch_im2col(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, int R, int S, int pad, int OH, int OW, int Kp, float* out) {
+    RFI_REQUIRE(Kp % 4 == 0 && Kp >= R * R * C, "im2col: packed K must be a multiple of 4 and cover R R C");
+    const int64_t total = (int64_t)N * OH * OW * Kp / 4;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * 16 + (double)N * H * W * C * 4);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_of(total)), dim3(256), 0, ctx->stream, x, N, H, W, C, R, S, pad, OH, OW, Kp, out);
+    check_launch("im2col");
+}
+void launch_w_pack(rfi_ctx* ctx, float* w, int taps, int Cout, int C, int Kp, float* wp, bool to_packed) {
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)Cout * Kp * 8);
+    hipLaunchKernelGGL(w_pack_kernel, dim3(grid_of((int64_t)Cout * Kp)), dim3(256), 0, ctx->stream, w, taps, Cout, C, Kp, wp,
+                       to_packed ? 1 : 0);
+    check_launch("w_pack");
+}
 
 void launch_maxpool3_fwd(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale, const float* shift, float* out,
                          unsigned* arg4) {
