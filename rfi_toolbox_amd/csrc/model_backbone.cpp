@@ -228,6 +228,11 @@ void rfi_model::prepare_backbone(int n, int h, int w) {
         a.tap_stride = (int64_t)a.Cx * a.Cy;
         a.bf16x3 = true;
         slab_need = std::max(slab_need, wgrad_slab_floats(a, IMPL_AUTO));
+        const int64_t M = (int64_t)a.N * a.H * a.W;
+        if (a.R == 1 && a.W < 32 && M % 32 == 0) {      // the flattened layout wgrad() runs small 1x1 maps in
+            a.N = 1; a.H = a.Hx = (int)(M / 32); a.W = a.Wx = 32;
+            slab_need = std::max(slab_need, wgrad_slab_floats(a, IMPL_AUTO));
+        }
     }
     bufs[ws_slab].ensure(ctx, slab_need + 16);
     pN = n; pH = h; pW = w;
@@ -262,6 +267,13 @@ struct Sh { int N, H, W; };
 
 void conv(rfi_model* m, View in, InXform xf, Sh s, int Hin, int Win, const float* w, const float* w3, const float* bias, int cin,
           int cout, int R, int S, int pad, float* Y) {
+    // a 1x1 conv does not see the image structure: on small maps (W < 32) run it on the same pixels laid out as one
+    // [M / 32] x 32 image, so that the 32-pixel-wide tiles of the kernels are full instead of mostly padding
+    const int64_t M = (int64_t)s.N * s.H * s.W;
+    if (R == 1 && S == 1 && Hin == s.H && Win == s.W && s.W < 32 && M % 32 == 0) {
+        s = Sh{1, (int)(M / 32), 32};
+        Hin = s.H; Win = s.W;
+    }
     ConvArgs a;
     a.x = in;
     a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = Hin; a.Win = Win;
@@ -278,6 +290,11 @@ void conv(rfi_model* m, View in, InXform xf, Sh s, int Hin, int Win, const float
     launch_conv(m->ctx, a);
 }
 void wgrad(rfi_model* m, View x, InXform xf_x, const float* dY, int cy, int cx, Sh s, int Hx, int Wx, int R, int S, int pad, float* dw) {
+    const int64_t M = (int64_t)s.N * s.H * s.W;
+    if (R == 1 && S == 1 && Hx == s.H && Wx == s.W && s.W < 32 && M % 32 == 0) {       // (as in conv())
+        s = Sh{1, (int)(M / 32), 32};
+        Hx = s.H; Wx = s.W;
+    }
     WgradArgs wa;
     wa.xop = x;
     wa.yop = View{dY, cy};
