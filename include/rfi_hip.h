@@ -124,6 +124,10 @@ int rfi_backbone_backward(rfi_model* m, const float* x, int x_mem, int n, int h,
                           int dfeats_mem);
 int rfi_model_backward_dlogits(rfi_model* m, const float* x, int x_mem, const float* dlogits, int dlogits_mem, int n, int h,
                                int w);
+/* A backward pass OVERWRITES the model's gradient buffer.  To sum the gradients of several passes (a head shared by the
+ * pyramid levels, several micro-batches): phase 0 zeroes an accumulator, phase 1 adds the current gradients to it (call
+ * after each backward pass), phase 2 copies the sum into the gradient buffer, ready for rfi_train_apply. */
+int rfi_model_grad_accumulate(rfi_model* m, int phase);
 int rfi_model_destroy(rfi_model* m);
 /* variants of models/unet.py:120-268 on the same graph: UNetDifferentActivation's activation
  * (0 = ReLU, 0 < s < 1 = LeakyReLU(negative_slope=s), after every BatchNorm) and UNetOverfit's head

@@ -71,6 +71,7 @@ _PROTOS = {
     "rfi_backbone_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _pvp, _i]),
     "rfi_backbone_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _pvp, _i]),
     "rfi_model_backward_dlogits": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i]),
+    "rfi_model_grad_accumulate": (_i, [_vp, _i]),
     "rfi_model_set_activation": (_i, [_vp, _f]),
     "rfi_model_set_compute_dtype": (_i, [_vp, _i]),
     "rfi_model_set_head_sigmoid": (_i, [_vp, _i]),

@@ -912,6 +912,17 @@ int rfi_model_eval_batch(rfi_model* m, const float* x, int x_mem, const uint8_t*
     });
 }
 
+int rfi_model_grad_accumulate(rfi_model* m, int phase) {
+    return guarded([&] {
+        RFI_REQUIRE(phase >= 0 && phase <= 2, "grad_accumulate: phase 0 (begin), 1 (add the current gradients), 2 (end: sum -> gradients)");
+        m->ctx->activate();
+        const size_t bytes = m->n_flat * sizeof(float);
+        if (!m->grad_acc) m->grad_acc = static_cast<float*>(m->ctx->alloc(bytes));
+        if (phase == 0) RFI_CHECK_HIP(hipMemsetAsync(m->grad_acc, 0, bytes, m->ctx->stream));
+        else if (phase == 1) launch_add_inplace(m->ctx, m->grad_acc, m->grads, (int64_t)m->n_flat);
+        else RFI_CHECK_HIP(hipMemcpyAsync(m->grads, m->grad_acc, bytes, hipMemcpyDeviceToDevice, m->ctx->stream));
+    });
+}
 int rfi_model_grad_buffer(rfi_model* m, float** dptr, int64_t* n_floats) {
     return guarded([&] {
         *dptr = m->grads;

@@ -48,7 +48,7 @@ rfi_model::~rfi_model() {
     for (auto& b : pl) b.free();
     if (wb_pool) ctx->release(wb_pool);
     if (wb_descs) ctx->release(wb_descs);
-    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool})   // (rs_wpool: arch 2 and 5)
+    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool, grad_acc})   // (rs_wpool: arch 2 and 5)
         if (p) ctx->release(p);
     if (relayout_descs) ctx->release(relayout_descs);
     if (x3_descs) ctx->release(x3_descs);

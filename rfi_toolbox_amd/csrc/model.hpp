@@ -112,6 +112,7 @@ struct rfi_model {
     size_t n_flat = 0;                // floats in each flat buffer (padded)
     int64_t n_params = 0;             // true scalar parameter count
     float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    float* grad_acc = nullptr;        // rfi_model_grad_accumulate: sum of the gradients of several backward passes
     float* chan_pool = nullptr;
     float* wd_pool = nullptr;
     float* w3_pool = nullptr;         // pre-split (3 x bf16) filter records, rebuilt with the dgrad layouts

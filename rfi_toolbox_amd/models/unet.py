@@ -331,6 +331,11 @@ class HipSegmenter:
         check(lib.rfi_train_apply(self._h, C.byref(hp), float(grad_scale), C.byref(norm)))
         return norm.value
 
+    def accumulate_gradients(self, phase):
+        """Sum the gradients of several backward passes (each pass overwrites the gradient buffer): ``"begin"`` zeroes
+        the accumulator, ``"add"`` after each backward pass, ``"end"`` makes the sum the gradient ``apply_gradients`` sees."""
+        check(lib.rfi_model_grad_accumulate(self._h, {"begin": 0, "add": 1, "end": 2}[phase]))
+
     def allreduce_gradients(self):
         check(lib.rfi_model_allreduce_grads(self._h))
 

@@ -187,3 +187,32 @@ def test_rpn_head_step_and_proposals():
     keep = ops.nms(boxes[top], scores[top], 0.7)
     np.testing.assert_array_equal(keep, detection_ref.nms(boxes[top], scores[top], 0.7))
     assert 0 < len(keep) <= 600
+
+
+def test_rpn_head_shared_over_two_levels_accumulates_gradients():
+    """One RPN head applied to two pyramid levels: the parameter gradients of the two backward passes are summed by
+    `accumulate_gradients` and equal the oracle's gradient of the sum of the two losses."""
+    from rfi_toolbox_amd.models import RPNHead
+    c, a, n = 16, 4, 2
+    st = mref.rpn_init_state(c, a, 1, seed=61)
+    m = RPNHead(c, a, 1).load_state_dict(st).train()
+    rng = np.random.default_rng(62)
+    leaves = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in st.items())
+    total = 0
+    m.accumulate_gradients("begin")
+    for hh in (16, 8):
+        x = rng.standard_normal((n, hh, hh, c)).astype(np.float32)
+        P = n * hh * hh
+        labels = rng.choice(np.array([-1] * 8 + [0, 0, 1], np.int8), P * a)
+        targets = (rng.standard_normal((P * a, 4)) * 0.3).astype(np.float32)
+        out = m.forward_nhwc(x)
+        _, _, dout = ops.rpn_loss(out.reshape(P, 5 * a), labels, targets, a)
+        m.backward(x, dout)
+        m.accumulate_gradients("add")
+        o_l, b_l = mref.rpn_loss_torch(mref.rpn_forward(leaves, unet_ref.nhwc_to_nchw(torch.from_numpy(x))), labels, targets, a)
+        total = total + o_l + b_l
+    m.accumulate_gradients("end")
+    grads = torch.autograd.grad(total, list(leaves.values()))
+    for (k, _), g in zip(leaves.items(), grads):
+        g = g.numpy()
+        assert np.linalg.norm(m.grad(k) - g) <= 1e-4 * np.linalg.norm(g) + 1e-9, k
