@@ -118,6 +118,18 @@ int rfi_rpn_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int anch
  * backbone_forward: feats[0..4] = P2..P6, [n, h >> (2 + i), w >> (2 + i), fpn_channels] each (null entries are skipped);
  * backbone_backward (after a forward pass on the same input): dfeats[i] = d(loss)/d(P_{2+i}) (null = zero) -> parameter
  * gradients. */
+/* The box head (not in the reference: two FC layers + ReLU on the flattened RoI features, then class scores and
+ * per-class box deltas -- TwoMLPHead + FastRCNNPredictor of the usual implementation, oracle/mask_head_ref.py): input
+ * [R, in_features] (n = R, h = w = 1), output [R, num_outputs] with num_outputs = 5 K1 = K1 class logits followed by K1 x 4
+ * deltas (cls_score and bbox_pred stacked).  Entries: fc6.weight [hidden, in_features, 1, 1] / .bias, fc7..., head.weight /
+ * .bias.  Loss outside the model: rfi_op_fastrcnn_loss (labels int32 in [0, K1), 0 = background; targets [R][4]; mean
+ * cross-entropy + smooth L1 (beta) of the ground-truth class's deltas over the foreground RoIs, both / R) ->
+ * rfi_model_backward_dlogits -> rfi_model_input_grad / rfi_train_apply. */
+int rfi_box_head_create(rfi_ctx* ctx, int in_features, int hidden, int fc_layers, int num_outputs, rfi_model** out);
+/* x += y on the device (n % 4 == 0): sums the feature-map gradients of several branches */
+int rfi_op_add_inplace(rfi_ctx* ctx, float* x, const float* y, int64_t n);
+int rfi_op_fastrcnn_loss(rfi_ctx* ctx, const float* head, int64_t rois, int num_classes, const int32_t* labels, const float* targets,
+                         float beta, float* dhead, float* loss_classifier, float* loss_box_reg);
 int rfi_resnet50_fpn_create(rfi_ctx* ctx, int in_channels, int base_width, int fpn_channels, rfi_model** out);
 int rfi_backbone_forward(rfi_model* m, const float* x, int x_mem, int n, int h, int w, float* const feats[5], int feats_mem);
 int rfi_backbone_backward(rfi_model* m, const float* x, int x_mem, int n, int h, int w, const float* const dfeats[5],

@@ -117,3 +117,27 @@ def rpn_loss_torch(out, labels, targets, A, beta=1.0 / 9):
     l_obj = F.binary_cross_entropy_with_logits(x[samp], pos[samp].to(o.dtype), reduction="sum") / n
     l_box = F.smooth_l1_loss(d[pos], tgt[pos], beta=beta, reduction="sum") / n
     return l_obj, l_box
+
+
+# ---------------------------------------------------------------- box head (TwoMLPHead + FastRCNNPredictor; builder-defined)
+class BoxHeadModule(nn.Module):
+    def __init__(self, in_channels=256, resolution=7, representation_size=1024, num_classes=2):
+        super().__init__()
+        self.fc6 = nn.Linear(in_channels * resolution ** 2, representation_size)
+        self.fc7 = nn.Linear(representation_size, representation_size)
+        self.cls_score = nn.Linear(representation_size, num_classes)
+        self.bbox_pred = nn.Linear(representation_size, 4 * num_classes)
+
+    def forward(self, x_nchw):                                    # (R, C, res, res)
+        x = F.relu(self.fc7(F.relu(self.fc6(x_nchw.flatten(1)))))
+        return self.cls_score(x), self.bbox_pred(x)
+
+
+def fastrcnn_loss_torch(cls, box, labels, targets, beta=1.0 / 9):
+    labels = torch.as_tensor(labels, dtype=torch.long)
+    tgt = torch.as_tensor(targets, dtype=box.dtype)
+    l_cls = F.cross_entropy(cls, labels)
+    pos = torch.where(labels > 0)[0]
+    b = box.reshape(box.shape[0], -1, 4)
+    l_box = F.smooth_l1_loss(b[pos, labels[pos]], tgt[pos], beta=beta, reduction="sum") / labels.numel()
+    return l_cls, l_box

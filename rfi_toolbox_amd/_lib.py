@@ -67,6 +67,9 @@ _PROTOS = {
     "rfi_mask_head_create": (_i, [_vp, _i, _i, _i, _pvp]),
     "rfi_model_input_grad": (_i, [_vp, _vp, _i]),
     "rfi_rpn_head_create": (_i, [_vp, _i, _i, _i, _pvp]),
+    "rfi_box_head_create": (_i, [_vp, _i, _i, _i, _i, _pvp]),
+    "rfi_op_add_inplace": (_i, [_vp, _vp, _vp, _i64]),
+    "rfi_op_fastrcnn_loss": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _f, _vp, _pf, _pf]),
     "rfi_resnet50_fpn_create": (_i, [_vp, _i, _i, _i, _pvp]),
     "rfi_backbone_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _pvp, _i]),
     "rfi_backbone_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _pvp, _i]),

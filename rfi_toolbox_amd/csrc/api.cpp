@@ -340,6 +340,26 @@ int rfi_mask_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int out
         *out = m;
     });
 }
+int rfi_box_head_create(rfi_ctx* ctx, int in_features, int hidden, int fc_layers, int num_outputs, rfi_model** out) {
+    return guarded([&] {
+        RFI_REQUIRE(ctx && out, "rfi_box_head_create: null argument");
+        auto* m = new rfi_model();
+        m->ctx = ctx;
+        m->arch = 6;
+        m->in_ch = in_features;
+        m->feat = hidden;
+        m->depth = fc_layers;
+        m->out_ch = num_outputs;
+        try {
+            m->build();
+        } catch (...) {
+            m->ctx = nullptr;
+            delete m;
+            throw;
+        }
+        *out = m;
+    });
+}
 int rfi_resnet50_fpn_create(rfi_ctx* ctx, int in_channels, int base_width, int fpn_channels, rfi_model** out) {
     return guarded([&] {
         RFI_REQUIRE(ctx && out, "rfi_resnet50_fpn_create: null argument");
@@ -382,7 +402,7 @@ int rfi_rpn_head_create(rfi_ctx* ctx, int in_channels, int conv_layers, int anch
 }
 int rfi_model_input_grad(rfi_model* m, float* dx, int dx_mem) {
     return guarded([&] {
-        RFI_REQUIRE(m->arch == 3 || m->arch == 4, "input_grad: only the mask head computes the gradient w.r.t. its input");
+        RFI_REQUIRE(m->arch == 3 || m->arch == 4 || m->arch == 6, "input_grad: only the mask head computes the gradient w.r.t. its input");
         RFI_REQUIRE(m->pN > 0 && dx, "input_grad: no backward pass has run");
         m->ctx->activate();
         const size_t cnt = (size_t)m->pN * m->pH * m->pW * m->in_ch;
@@ -817,7 +837,7 @@ int rfi_train_step_async(rfi_model* m, const float* x_dev, const uint8_t* labels
 int rfi_model_backward_dlogits(rfi_model* m, const float* x, int x_mem, const float* dlogits, int dlogits_mem, int n, int h,
                                int w) {
     return guarded([&] {
-        RFI_REQUIRE(m->arch == 3 || m->arch == 4, "backward_dlogits: mask / RPN heads only");
+        RFI_REQUIRE(m->arch == 3 || m->arch == 4 || m->arch == 6, "backward_dlogits: mask / RPN / box heads only");
         RFI_REQUIRE(m->pN == n && m->pH == h && m->pW == w, "backward_dlogits: run the forward pass on this input first");
         m->ctx->activate();
         const float* xd = stage_input(m, x, x_mem, n, h, w, false);
@@ -1001,6 +1021,13 @@ int rfi_model_algorithmic_flops(rfi_model* m, int n, int h, int w, double* fwd, 
         // 2*M*K*N over every conv / convT / head, each layer evaluated once
         double f = 0, stem = 0;
         const int D = m->depth;
+        if (m->arch == 6) {
+            for (auto& c : m->convs) f += 2.0 * n * c.cin * c.cout;
+            f += 2.0 * n * (double)m->feat * m->out_ch;
+            if (fwd) *fwd = f;
+            if (step) *step = 3.0 * f;
+            return;
+        }
         if (m->arch == 5) {             // every conv once at its output resolution (the stem's 7x7 has stride 2)
             for (auto& c : m->convs) f += 2.0 * n * (double)(h >> c.level) * (w >> c.level) * c.R * c.R * c.cin * c.cout;
             if (fwd) *fwd = f;
@@ -1694,6 +1721,27 @@ int rfi_op_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, con
     return guarded([&] {
         ctx->activate();
         launch_box_decode(ctx, anchors, n_anchors, deltas, n, clip_h, clip_w, boxes);
+    });
+}
+int rfi_op_add_inplace(rfi_ctx* ctx, float* x, const float* y, int64_t n) {
+    return guarded([&] {
+        ctx->activate();
+        launch_add_inplace(ctx, x, y, n);
+    });
+}
+int rfi_op_fastrcnn_loss(rfi_ctx* ctx, const float* head, int64_t rois, int num_classes, const int32_t* labels, const float* targets,
+                         float beta, float* dhead, float* loss_classifier, float* loss_box_reg) {
+    return guarded([&] {
+        ctx->activate();
+        double* ws = static_cast<double*>(ctx->alloc(rpn_loss_ws_doubles() * 8 + 16));
+        struct Free { rfi_ctx* c; void* p; ~Free() { try { c->release(p); } catch (...) {} } } fr{ctx, ws};
+        float* out2 = reinterpret_cast<float*>(ws + rpn_loss_ws_doubles());
+        launch_fastrcnn_loss(ctx, head, rois, num_classes, labels, targets, beta, dhead, ws, out2);
+        float h2[2];
+        RFI_CHECK_HIP(hipMemcpyAsync(h2, out2, sizeof(h2), hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (loss_classifier) *loss_classifier = h2[0];
+        if (loss_box_reg) *loss_box_reg = h2[1];
     });
 }
 int rfi_op_anchor_match(rfi_ctx* ctx, const float* anchors, int64_t n, const float* gt_boxes, int n_gt, float fg_iou, float bg_iou,

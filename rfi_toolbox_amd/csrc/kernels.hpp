@@ -298,6 +298,10 @@ void launch_nms_mask(rfi_ctx* ctx, const float* boxes, int n, float thr, unsigne
 // RPN loss on a head output [P][5 A]: BCE on the sampled anchors + smooth L1 on the positives, both / num_sampled;
 // writes the gradient w.r.t. the head output and the two loss terms (device floats)
 size_t rpn_loss_ws_doubles();
+// Fast R-CNN loss on the box head's output [R][5 K1]: mean cross-entropy + smooth L1 of the ground-truth class's deltas over the
+// foreground RoIs / R; labels int32 in [0, K1) (0 = background); writes the gradient and the two terms (partial_ws as rpn_loss)
+void launch_fastrcnn_loss(rfi_ctx* ctx, const float* head, int64_t R, int K1, const int* labels, const float* targets, float beta,
+                          float* dhead, double* partial_ws, float* loss2_dev);
 void launch_rpn_loss(rfi_ctx* ctx, const float* head, int64_t P, int A, const signed char* labels, const float* targets,
                      int64_t num_sampled, float beta, float* dhead, double* partial_ws, float* loss2_dev);
 

@@ -68,6 +68,7 @@ void rfi_model::build() {
     if (arch == 1) return build_cnn3();
     if (arch == 3 || arch == 4) return build_mask();
     if (arch == 5) return build_backbone();
+    if (arch == 6) return build_mlp();
     if (arch == 2) return build_resnet();
     RFI_REQUIRE(in_ch > 0 && out_ch > 0 && feat > 0, "UNet: channel counts must be positive");
     RFI_REQUIRE(depth >= 1 && depth <= 6, "UNet: depth must be in [1,6]");
@@ -246,6 +247,7 @@ void rfi_model::prepare(int n, int h, int w) {
     if (arch == 1) return prepare_cnn3(n, h, w);
     if (arch == 3 || arch == 4) return prepare_mask(n, h, w);
     if (arch == 5) return prepare_backbone(n, h, w);
+    if (arch == 6) return prepare_mlp(n, h, w);
     const int div = 1 << depth;
     RFI_REQUIRE(h % div == 0 && w % div == 0,
                 "forward: H and W must be multiples of 2^depth (" + std::to_string(div) +
@@ -457,6 +459,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
     if (arch == 1) return forward_cnn3(x_dev, n, h, w);
     if (arch == 3 || arch == 4) return forward_mask(x_dev, n, h, w);
     if (arch == 5) return forward_backbone(x_dev, n, h, w);
+    if (arch == 6) return forward_mlp(x_dev, n);
     if (planesP) return forward_planes(x_dev, n, h, w, train_mode);
     const int D = depth, IB = i_bott;
     View cur = network_input(x_dev, n, h, w);
@@ -666,6 +669,11 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
 }  // namespace
 
 void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
+    if (arch == 6) {
+        backward_mlp(x_dev, n);
+        bucket_ready(0, n_flat);
+        return;
+    }
     if (arch == 5) {
         backward_backbone(x_dev, n, h, w);
         bucket_ready(0, n_flat);

@@ -89,7 +89,7 @@ struct rfi_model {
                                       // 2: U-Net with a ResNet-18-style encoder (model_resnet.cpp),
                                       // 3: Mask R-CNN's per-RoI mask head (model_mask.cpp; depth = conv layers),
                                       // 4: RPN head (the same stack without the transposed conv),
-                                      // 5: ResNet-50-FPN backbone, frozen BatchNorm (model_backbone.cpp)
+                                      // 5: ResNet-50-FPN backbone, frozen BatchNorm (model_backbone.cpp), 6: FC box head (model_mlp.cpp)
     int i_bott = 0;                   // index of the bottleneck's first conv in `convs` (decoder convs follow it)
     bool training = true;
     float act_slope = 0.0f;           // 0: ReLU; > 0: LeakyReLU(negative_slope) (UNetDifferentActivation)
@@ -149,6 +149,12 @@ struct rfi_model {
     void reset_channel_state();       // running stats 0/1, BN-less layers: scale 1, shift 0
     float* buf(int i) { return bufs[i].p; }
     int new_buf() { bufs.emplace_back(); return (int)bufs.size() - 1; }
+
+    // ---- fully connected box head (model_mlp.cpp; arch 6): depth FC + ReLU layers in_ch -> feat -> feat, head feat -> out_ch
+    void build_mlp();
+    void prepare_mlp(int n, int h, int w);
+    void forward_mlp(const float* x_dev, int n);
+    void backward_mlp(const float* x_dev, int n);
 
     // ---- ResNet-50-FPN backbone with frozen BatchNorm (model_backbone.cpp; arch 5): feat = base width (64), out_ch = FPN channels
     struct BBlock {

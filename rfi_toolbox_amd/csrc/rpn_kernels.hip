@@ -118,6 +118,51 @@ __global__ void rpn_loss_finish_kernel(const double* __restrict__ partial, int b
     }
 }
 
+// Fast R-CNN loss over the box head's output [R][5 K1] (K1 = classes incl. background: K1 class logits, then K1 x 4 box
+// deltas): mean cross-entropy over the RoIs + smooth L1 of the ground-truth class's deltas over the foreground RoIs,
+// both / R.  One thread per RoI (K1 is small); gradient w.r.t. the head output; fp64 block partials.
+__global__ __launch_bounds__(kB) void fastrcnn_loss_kernel(const float* __restrict__ head, int64_t R, int K1, const int* __restrict__ labels,
+                                                          const float* __restrict__ targets, float inv_R, float beta,
+                                                          float* __restrict__ dhead, double* __restrict__ partial) {
+    __shared__ double red[2][kB];
+    double s_cls = 0.0, s_box = 0.0;
+    const int ps = 5 * K1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* x = head + i * ps;
+        float* g = dhead + i * ps;
+        const int lab = labels[i];
+        float mx = x[0];
+        for (int j = 1; j < K1; ++j) mx = fmaxf(mx, x[j]);
+        float se = 0.0f;
+        for (int j = 0; j < K1; ++j) se += expf(x[j] - mx);
+        const float lse = mx + logf(se);
+        s_cls += (double)(lse - x[lab]);
+        for (int j = 0; j < K1; ++j) g[j] = (expf(x[j] - lse) - (j == lab ? 1.0f : 0.0f)) * inv_R;
+        for (int j = 0; j < 4 * K1; ++j) g[K1 + j] = 0.0f;
+        if (lab > 0) {
+            for (int k = 0; k < 4; ++k) {
+                const float e = x[K1 + 4 * lab + k] - targets[i * 4 + k], ae = fabsf(e);
+                if (ae < beta) { s_box += (double)(0.5f * e * e / beta); g[K1 + 4 * lab + k] = e / beta * inv_R; }
+                else { s_box += (double)(ae - 0.5f * beta); g[K1 + 4 * lab + k] = e > 0.0f ? inv_R : -inv_R; }
+            }
+        }
+    }
+    red[0][threadIdx.x] = s_cls;
+    red[1][threadIdx.x] = s_box;
+    __syncthreads();
+    for (int o = kB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2] = red[0][0];
+        partial[blockIdx.x * 2 + 1] = red[1][0];
+    }
+}
+
 // ---- anchor <-> ground-truth matching (the Matcher of the usual implementation): IoU matrix never materialised
 __device__ __forceinline__ float iou_of(const float4 a, const float4 b) {
     const float iw = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f), ih = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
@@ -197,6 +242,20 @@ void launch_anchor_match(rfi_ctx* ctx, const float* anchors, int64_t n, const fl
         hipLaunchKernelGGL(box_encode_kernel, dim3((unsigned)b), dim3(kB), 0, ctx->stream, anchors, n, gt, matched, targets);
         check_launch("box_encode");
     }
+}
+
+void launch_fastrcnn_loss(rfi_ctx* ctx, const float* head, int64_t R, int K1, const int* labels, const float* targets, float beta,
+                          float* dhead, double* partial_ws, float* loss2_dev) {
+    RFI_REQUIRE(R > 0 && K1 >= 2, "fastrcnn_loss: R > 0 and at least background + one class");
+    const float inv = 1.0f / (float)R;
+    int64_t blocks = cdiv(R, kB);
+    if (blocks > 1024) blocks = 1024;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)R * (10.0 * K1 * 4 + 20));
+    hipLaunchKernelGGL(fastrcnn_loss_kernel, dim3((unsigned)blocks), dim3(kB), 0, ctx->stream, head, R, K1, labels, targets, inv, beta,
+                       dhead, partial_ws);
+    check_launch("fastrcnn_loss");
+    hipLaunchKernelGGL(rpn_loss_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial_ws, (int)blocks, (double)inv, loss2_dev);
+    check_launch("fastrcnn_loss_finish");
 }
 
 void launch_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,

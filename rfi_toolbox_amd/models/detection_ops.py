@@ -133,3 +133,20 @@ def anchor_match(anchors, gt_boxes, fg_iou=0.7, bg_iou=0.3, allow_low_quality=Tr
                                   _p(labels), _p(matched), _p(targets)))
     ctx.synchronize()
     return labels.numpy(), matched.numpy(), targets.numpy()
+
+
+def fastrcnn_loss(head, labels, targets, beta=1.0 / 9, device=None):
+    """head (R, 5 K1) float32 = K1 class logits then K1 x 4 box deltas per RoI; labels (R,) in [0, K1) (0 = background);
+    targets (R, 4).  -> (classification loss, box loss, d(sum)/d(head) (R, 5 K1))."""
+    ctx = Context.get(device)
+    h = np.asarray(head, np.float32)
+    r, k1 = h.shape[0], h.shape[1] // 5
+    dh = _dev(ctx, h)
+    lab = np.ascontiguousarray(np.asarray(labels, np.int32).reshape(-1))
+    if lab.size != r or lab.min() < 0 or lab.max() >= k1:
+        raise ValueError("labels must be one class index in [0, K1) per RoI")
+    dl, dt = ctx.to_device(lab), _dev(ctx, np.asarray(targets, np.float32).reshape(r, 4))
+    dg = ctx.empty((r, 5 * k1), np.float32)
+    lc, lb = C.c_float(), C.c_float()
+    check(lib.rfi_op_fastrcnn_loss(ctx.handle, _p(dh), r, k1, _p(dl), _p(dt), float(beta), _p(dg), C.byref(lc), C.byref(lb)))
+    return lc.value, lb.value, dg.numpy()

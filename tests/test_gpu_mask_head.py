@@ -216,3 +216,42 @@ def test_rpn_head_shared_over_two_levels_accumulates_gradients():
     for (k, _), g in zip(leaves.items(), grads):
         g = g.numpy()
         assert np.linalg.norm(m.grad(k) - g) <= 1e-4 * np.linalg.norm(g) + 1e-9, k
+
+
+# ---------------------------------------------------------------- box head
+@pytest.mark.parametrize("c,res,hid,k1,r", [(16, 7, 64, 2, 96), (256, 7, 1024, 2, 512), (8, 3, 32, 5, 37)])
+def test_box_head_step_vs_oracle(c, res, hid, k1, r):
+    """TwoMLPHead + FastRCNNPredictor: default init == constructing the torch modules, forward, the Fast R-CNN loss kernel,
+    backward from its gradient (every parameter, the RoI features), one Adam step -- against torch autograd."""
+    from rfi_toolbox_amd.models import BoxHead
+    torch.manual_seed(71)
+    mod = mref.BoxHeadModule(c, res, hid, k1)
+    torch.manual_seed(71)
+    m = BoxHead(c, res, hid, k1).train()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(mod.state_dict().keys())
+    for k, v in mod.state_dict().items():
+        assert torch.equal(sd[k], v), k
+    rng = np.random.default_rng(72)
+    x = rng.standard_normal((r, res, res, c)).astype(np.float32)                 # NHWC, as roi_align returns it
+    xo = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    cls, box = mod(xo)
+    got = m.forward_rois(x)
+    want = torch.cat([cls, box], 1).detach().numpy()
+    assert np.abs(got - want).max() <= 5e-5 * max(1.0, np.abs(want).max())
+    labels = rng.integers(0, k1, r).astype(np.int32)
+    targets = (rng.standard_normal((r, 4)) * 0.3).astype(np.float32)
+    lc, lb, dout = ops.fastrcnn_loss(got, labels, targets)
+    o_c, o_b = mref.fastrcnn_loss_torch(cls, box, labels, targets)
+    assert lc == pytest.approx(float(o_c.detach()), rel=1e-5) and lb == pytest.approx(float(o_b.detach()), rel=1e-5, abs=1e-7)
+    params = list(mod.parameters())
+    grads = torch.autograd.grad(o_c + o_b, params + [xo])
+    m.backward(x, dout)
+    for (k, _), g in zip(mod.named_parameters(), grads[:-1]):
+        g = g.numpy()
+        assert np.linalg.norm(m.grad(k) - g) <= 2e-4 * np.linalg.norm(g) + 1e-9, k
+    gx = grads[-1].permute(0, 2, 3, 1).numpy()
+    assert np.linalg.norm(m.input_grad(x.shape) - gx) <= 2e-4 * np.linalg.norm(gx)
+    norm = m.apply_gradients(lr=1e-3, weight_decay=0.0)
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads[:-1])))
+    assert norm == pytest.approx(total, rel=2e-4)

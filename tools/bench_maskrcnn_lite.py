@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """One training step of the Mask R-CNN PIECES built so far, chained on the GPU (BASELINE configs[3] shape:
 batch 64 x 128 x 128 x 3 patches): ResNet-50-FPN backbone -> RPN head on P3 (stride 8) with its loss -> RoIAlign of the
-ground-truth boxes on P2 (stride 4) -> mask head with its loss -> gradients back through RoIAlign and the RPN head into
-the pyramid -> backbone backward -> clip + Adam of the three parameter sets.  NOT a full detector: no box head, the RPN
-runs on one pyramid level, anchor labels / regression targets of the (static, synthetic) boxes are prepared once.  Every
+ground-truth boxes on P2 (stride 4): 7 x 7 -> box head with the Fast R-CNN loss, 14 x 14 -> mask head with its loss ->
+gradients back through RoIAlign and the RPN head into the pyramid -> backbone backward -> clip + Adam of the four
+parameter sets.  NOT a full detector: the RoIs are the ground-truth boxes (no proposal sampling), the RPN runs on one
+pyramid level, anchor labels / regression targets of the (static, synthetic) boxes are prepared once.  Every
 tensor stays in HBM; one host sync per step (the two RPN loss scalars).
 
     python tools/bench_maskrcnn_lite.py [--batch 64] [--rois-per-image 4] [--dtype f32|bf16]
@@ -28,7 +29,7 @@ def main():
     a = ap.parse_args()
     import torch
     from rfi_toolbox_amd._lib import DEVICE, Hyper, check, lib
-    from rfi_toolbox_amd.models import MaskHead, ResNet50FPN, RPNHead
+    from rfi_toolbox_amd.models import BoxHead, MaskHead, ResNet50FPN, RPNHead
     from rfi_toolbox_amd.models import detection_ops as ops
     from rfi_toolbox_amd.runtime import Context
     ctx = Context.get(0)
@@ -38,6 +39,7 @@ def main():
     backbone = ResNet50FPN(3, 64, F).set_compute_dtype(mode)
     rpn = RPNHead(F, A, 1).train().set_compute_dtype(mode)
     mask = MaskHead(F, 1, 4).train().set_compute_dtype(mode)
+    box = BoxHead(F, 7, 1024, 2).train().set_compute_dtype(mode)
     rng = np.random.default_rng(0)
     x = ctx.to_device(rng.standard_normal((n, s, s, 3)).astype(np.float32))
     # synthetic ground truth: k boxes per image, their masks; RPN anchors of 4 sizes on the stride-8 grid
@@ -70,6 +72,12 @@ def main():
     rpn_dout = ctx.empty((n, g3, g3, 5 * A), np.float32)
     roi_feats = ctx.empty((R, 14, 14, F), np.float32)
     roi_grad = ctx.empty((R, 14, 14, F), np.float32)
+    roi7, roi7_grad = ctx.empty((R, 7, 7, F), np.float32), ctx.empty((R, 7, 7, F), np.float32)
+    box_out, box_dout = ctx.empty((R, 10), np.float32), ctx.empty((R, 10), np.float32)
+    d_box_lab = ctx.to_device(np.ones(R, np.int32))                       # every RoI is a ground-truth box of class 1
+    d_box_tgt = ctx.to_device(np.zeros((R, 4), np.float32))
+    dfeat2b = ctx.empty(shapes[0], np.float32)
+    lc, lr = C.c_float(), C.c_float()
     hp = Hyper(1e-4, 0.9, 0.999, 1e-8, 1e-5, 1.0)
     lo, lb, lm, nrm = C.c_float(), C.c_float(), C.c_float(), C.c_float()
     P = lambda d: C.c_void_p(d.ptr)
@@ -87,10 +95,19 @@ def main():
         check(lib.rfi_train_forward_backward(mask._h, P(roi_feats), DEVICE, P(d_mask_t), DEVICE, R, 14, 14, C.byref(lm)))
         check(lib.rfi_model_input_grad(mask._h, P(roi_grad), DEVICE))
         check(lib.rfi_op_roi_align_backward(ctx.handle, P(roi_grad), n, s // 4, s // 4, F, P(d_rois), R, 0.25, 14, 14, 2, 0, P(dfeat2)))
+        # box branch on P2
+        check(lib.rfi_op_roi_align(ctx.handle, P(feats[0]), n, s // 4, s // 4, F, P(d_rois), R, 0.25, 7, 7, 2, 0, P(roi7)))
+        check(lib.rfi_model_forward_nhwc(box._h, P(roi7), DEVICE, R, 1, 1, P(box_out), DEVICE))
+        check(lib.rfi_op_fastrcnn_loss(ctx.handle, P(box_out), R, 2, P(d_box_lab), P(d_box_tgt), 1.0 / 9, P(box_dout), C.byref(lc),
+                                       C.byref(lr)))
+        check(lib.rfi_model_backward_dlogits(box._h, P(roi7), DEVICE, P(box_dout), DEVICE, R, 1, 1))
+        check(lib.rfi_model_input_grad(box._h, P(roi7_grad), DEVICE))
+        check(lib.rfi_op_roi_align_backward(ctx.handle, P(roi7_grad), n, s // 4, s // 4, F, P(d_rois), R, 0.25, 7, 7, 2, 0, P(dfeat2b)))
+        check(lib.rfi_op_add_inplace(ctx.handle, P(dfeat2), P(dfeat2b), n * (s // 4) * (s // 4) * F))
         check(lib.rfi_backbone_backward(backbone._h, P(x), DEVICE, n, s, s, pdf, DEVICE))
-        for m in (backbone, rpn, mask):
+        for m in (backbone, rpn, mask, box):
             check(lib.rfi_train_apply(m._h, C.byref(hp), 1.0, C.byref(nrm)))
-        return lo.value + lb.value + lm.value
+        return lo.value + lb.value + lm.value + lc.value + lr.value
 
     losses = [step() for _ in range(3)]
     ctx.synchronize()
@@ -99,7 +116,7 @@ def main():
         losses.append(step())
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"metric": "Mask R-CNN pieces, training patches/s (backbone + RPN on P3 + RoIAlign + mask head; no box head)",
+    print(json.dumps({"metric": "Mask R-CNN pieces, training patches/s (backbone + RPN on P3 + RoIAlign + box head + mask head)",
                       "value": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 2), "batch": n, "rois": R, "dtype": a.dtype,
                       "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}))
 
