@@ -102,9 +102,10 @@ def nms(boxes, scores, iou_threshold, device=None):
     return order[keep[:nk.value]]
 
 
-def rpn_loss(head, labels, targets, anchors_per_pixel, beta=1.0 / 9, device=None):
+def rpn_loss(head, labels, targets, anchors_per_pixel, beta=1.0 / 9, device=None, num_sampled=None):
     """head (P, 5 A) float32 = A objectness logits then A x 4 box deltas per pixel; labels (P A,) int8 in {1, 0, -1};
-    targets (P A, 4).  -> (objectness loss, box loss, d(sum)/d(head) (P, 5 A))."""
+    targets (P A, 4).  -> (objectness loss, box loss, d(sum)/d(head) (P, 5 A)).  ``num_sampled``: the normaliser (default:
+    the sampled anchors of THESE labels; pass the total over all pyramid levels when the loss is evaluated level by level)."""
     ctx = Context.get(device)
     a = int(anchors_per_pixel)
     dh = _dev(ctx, np.asarray(head, np.float32).reshape(-1, 5 * a))
@@ -115,7 +116,8 @@ def rpn_loss(head, labels, targets, anchors_per_pixel, beta=1.0 / 9, device=None
     dt = _dev(ctx, np.asarray(targets, np.float32).reshape(-1, 4))
     dg = ctx.empty(dh.shape, np.float32)
     lo, lb = C.c_float(), C.c_float()
-    check(lib.rfi_op_rpn_loss(ctx.handle, _p(dh), dh.shape[0], a, _p(dl), _p(dt), int((lab >= 0).sum()), float(beta), _p(dg),
+    check(lib.rfi_op_rpn_loss(ctx.handle, _p(dh), dh.shape[0], a, _p(dl), _p(dt),
+                              int((lab >= 0).sum()) if num_sampled is None else int(num_sampled), float(beta), _p(dg),
                               C.byref(lo), C.byref(lb)))
     return lo.value, lb.value, dg.numpy()
 
