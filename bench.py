@@ -228,12 +228,13 @@ def measure(model, ctx, D, d_x, d_y, hp, args, dtype, rank, launch_csv=None):
     ctx.timer_start()
     for _ in range(args.steps):
         model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+    enq = time.perf_counter() - t0                # host time to enqueue the K steps (the GPU runs behind it)
     ev_ms = ctx.timer_stop()                      # HIP events on the ctx stream; synchronises
     ctx.synchronize()
     wall = time.perf_counter() - t0
     D.barrier()
     wall = D.max_over_ranks(wall)
-    log(f"[{dtype}] timed region done: {wall * 1e3 / args.steps:.2f} ms/step")
+    log(f"[{dtype}] timed region done: {wall * 1e3 / args.steps:.2f} ms/step (host enqueue {enq * 1e3 / args.steps:.2f} ms/step)")
     loss, _ = model.last_loss()
     if not np.isfinite(loss):
         raise SystemExit(f"non-finite loss {loss}")

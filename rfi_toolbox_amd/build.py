@@ -38,13 +38,26 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# ROCm 7.2 / gfx950: a packed-fp32 VALU result (v_pk_mul_f32 ...) converted by v_cvt_f64_f32 a few instructions later is
+# occasionally read stale in lanes 48-63 when another kernel shares the CU (found with tools/race_probe.py: the fp64
+# BatchNorm-backward sums of pool_bwd_merge next to a weight-gradient kernel).  The sources below accumulate
+# float32 products in fp64, so they are built without the SLP vectoriser (which forms the packed ops); they are bound
+# by HBM, the packed forms bought nothing.  tools/scan_pk_f64_hazard.py checks the ISA of every source for the pair.
+NO_SLP = {"elem_kernels.hip", "planes_elem.hip", "resnet_kernels.hip", "rpn_kernels.hip", "detect_kernels.hip",
+          "preprocess.hip", "order_stats.hip", "synth.hip", "conv_direct.hip"}
+
+
+def flags_for(src):
+    return ["-fno-slp-vectorize"] if src in NO_SLP else []
+
+
 def _compile(src, force, extra):
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ, src.replace(".", "_") + ".o")
     deps = [path] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     if not force and not _newer(obj, deps):
         return obj, None
-    cmd = [HIPCC, *COMMON, *extra, "-x", "hip", "-c", path, "-o", obj]
+    cmd = [HIPCC, *COMMON, *flags_for(src), *extra, "-x", "hip", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

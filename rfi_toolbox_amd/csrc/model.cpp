@@ -549,7 +549,8 @@ void rfi_model::side_end() {
     const int ring = (int)ctx->side_done.size();
     RFI_CHECK_HIP(hipEventRecord(ctx->side_done[side_seq % ring], ctx->side_stream));
     ctx->stream = ctx->main_stream;
-    if (side_seq >= 2) RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->side_done[(side_seq - 2) % ring], 0));
+    if (side_bound > 0 && side_seq >= side_bound)
+        RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->side_done[(side_seq - side_bound) % ring], 0));
     ++side_seq;
 }
 void rfi_model::side_join() {

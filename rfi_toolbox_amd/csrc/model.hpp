@@ -209,7 +209,7 @@ struct rfi_model {
     // activations (the bfloat16 compute mode), 3 float32 as three bf16 pieces
     int planesP = 0;
     std::vector<rfi::PlaneBuf> pl;
-    std::vector<int> pA1e, pSkip, pPool, pUp, pA1d, pdYa, pdYb, upf;
+    std::vector<int> pA1e, pSkip, pPool, pUp, pA1d, pdYa, pdYb, pdYaE, pdYbE, upf;
     int pXin = -1, pA1b = -1, pdYbottA = -1, pdYbottB = -1;
     // bf16 data flow (P = 1, feat % 4 == 0): raw conv outputs that only elementwise kernels read are stored as bfloat16
     // (indices into pl; -1: float32 in bufs): both convs of every encoder, the first of the bottleneck and of every
@@ -230,6 +230,7 @@ struct rfi_model {
 
     // backward-pass overlap: wgrad launches go to the context's side stream (see model.cpp)
     int side_seq = 0;
+    int side_bound = 2;               // main may run this many side launches ahead (0: no bound -- nothing the side work reads is rewritten before side_join)
     void side_begin();                // side stream waits for everything enqueued on the main stream so far
     void side_end();                  // marks the side launch; bounds the main stream's run-ahead
     void side_join();                 // main stream waits for all side work

@@ -47,7 +47,7 @@ void rfi_model::prepare_planes(int n, int h, int w) {
     const int P = planesP, D = depth;
     if (pl.empty()) {
         auto mk = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) { pl.emplace_back(); v[l] = (int)pl.size() - 1; } };
-        mk(pA1e); mk(pSkip); mk(pPool); mk(pUp); mk(pA1d); mk(pdYa); mk(pdYb);
+        mk(pA1e); mk(pSkip); mk(pPool); mk(pUp); mk(pA1d); mk(pdYa); mk(pdYb); mk(pdYaE); mk(pdYbE);
         auto one = [&]() { pl.emplace_back(); return (int)pl.size() - 1; };
         pXin = one(); pA1b = one(); pdYbottA = one(); pdYbottB = one();
         upf.assign(D + 1, -1);
@@ -58,7 +58,7 @@ void rfi_model::prepare_planes(int n, int h, int w) {
     for (int l = 1; l <= D; ++l) {
         const int64_t M = (int64_t)n * (h >> (l - 1)) * (w >> (l - 1));
         const int C = feat << (l - 1);
-        for (int i : {pA1e[l], pSkip[l], pUp[l], pA1d[l], pdYa[l], pdYb[l]}) pl[i].ensure(ctx, M, C, P);
+        for (int i : {pA1e[l], pSkip[l], pUp[l], pA1d[l], pdYa[l], pdYb[l], pdYaE[l], pdYbE[l]}) pl[i].ensure(ctx, M, C, P);
         pl[pPool[l]].ensure(ctx, M / 4, C, P);
         bufs[upf[l]].ensure(ctx, (size_t)M * C);
     }
@@ -339,6 +339,10 @@ void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, YRef Y, const P
 void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
     (void)x_dev;
     const int D = depth;
+    // every layer owns its dY plane tensor and the other side-stream inputs (forward planes, dconcat, raw conv outputs)
+    // are not rewritten before side_join(): the main stream never has to wait for a weight gradient inside the pass
+    static const int bound_env = getenv("RFI_SIDE_BOUND") ? atoi(getenv("RFI_SIDE_BOUND")) : 0;
+    side_bound = bound_env;
     // a raw conv output of the forward pass: bfloat16 tensor pl[hi] in the bf16 flow, else float32 bufs[fi]
     auto yr = [&](int fi, int hi) { return (y16_flow && hi >= 0) ? YRef(pl[hi].p, pl[hi].pstride) : YRef(buf(fi)); };
     const int64_t M1 = (int64_t)n * h * w;
@@ -423,11 +427,12 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
             launch_pool_bwd_merge(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
                                   View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
         const PlaneSeg a1 = seg_of(pl[pA1e[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, buf(gB[l]), pl[pdYa[l]], have);
+        backward_pconv_bn(this, c2, buf(gA[l]), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, buf(gB[l]), pl[pdYaE[l]], have);
         const PlaneSeg in = seg_of(l == 1 ? pl[pXin] : pl[pPool[l - 1]]);
         backward_pconv_bn(this, c1, buf(gB[l]), yr(encY1[l], y16_flow ? yE1[l] : -1), &in, 1, s, (l == 1) ? nullptr : buf(dpool[l - 1]),
-                          pl[pdYb[l]]);
+                          pl[pdYbE[l]]);
         bucket_ready(c1.w_off, convs[2 * l].w_off);
     }
     side_join();
+    side_bound = 2;
 }

@@ -1,0 +1,23 @@
+"""Bitwise reproducibility of the backward pass (no float atomics, fixed-order reductions: DESIGN.md): the same model on
+the same batch must give bit-identical gradients every time, although the weight-gradient kernels share the CUs with the
+main stream's kernels.  This is the test that would have caught the packed-fp32 -> v_cvt_f64_f32 hazard (build.py,
+tools/scan_pk_f64_hazard.py): a few lanes of a BatchNorm-backward sum changed in about 2 % of the passes."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+
+
+@pytest.mark.parametrize("mode,reps", [("bfloat16", 400), ("float32", 200)])
+def test_backward_is_bitwise_reproducible(mode, reps):
+    from race_probe import probe
+    bad = probe(mode, reps)
+    assert not bad, {k: v[:2] for k, v in bad.items()}
+
+
+def test_bitwise_reproducible_with_bucketed_exchange():
+    from race_probe import probe
+    assert not probe("bfloat16", 200, emulate=2)
