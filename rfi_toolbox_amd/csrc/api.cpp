@@ -129,6 +129,7 @@ int rfi_ctx_destroy(rfi_ctx* ctx) {
         hipEventDestroy(ctx->t1);
         hipStreamSynchronize(ctx->side_stream);
         hipEventDestroy(ctx->fork_ev);
+        for (auto e : ctx->fork_ring) hipEventDestroy(e);
         for (auto e : ctx->side_done) hipEventDestroy(e);
         hipStreamSynchronize(ctx->comm_stream);
         for (auto e : ctx->bucket_ev) hipEventDestroy(e);

@@ -111,6 +111,8 @@ struct rfi_ctx {
     // dgrad / batch-norm chain (model.cpp); `stream` is swapped to it for those launches
     hipStream_t main_stream = nullptr, side_stream = nullptr;
     hipEvent_t fork_ev = nullptr;
+    std::vector<hipEvent_t> fork_ring;   // stop events of producer kernels (launch_*(..., done)): one per side launch of a pass
+    size_t fork_ring_used = 0;
     std::vector<hipEvent_t> side_done;   // ring, one per in-flight side launch
     bool overlap = true;
     // RCCL.  The gradient exchange is BUCKETED: contiguous ranges of the flat gradient buffer are all-reduced on

@@ -5,6 +5,8 @@
 // BatchNorm-apply is x*scale + shift with the product and the sum rounded SEPARATELY (the build
 // uses -ffp-contract=off): torch's CPU kernel applies x*alpha+beta with a vector multiply and a
 // vector add, and the ReLU mask of elements at the threshold follows that rounding.
+#include <hip/hip_ext.h>
+
 #include "kernels.hpp"
 
 namespace rfi {
@@ -1191,26 +1193,27 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, YRef y, int64_t M, int C
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
                          float* partial_ws, float* dbias, float slope, unsigned short* planes_out,
-                         int64_t planes_pstride, int planes_P) {
+                         int64_t planes_pstride, int planes_P, hipEvent_t done, bool finish_dbias) {
     ChanGeom g = geom_rows(M, C);
     {
         ProfScope ps(ctx, FAM_BN, 0, (double)M * C * ((planes_out ? 8 + 2 * planes_P : 12) - (y.bf16 ? 2 : 0)));
-        if (g.V == 4)
-            hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
-                               da_inout, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
-                               c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
-        else
-            hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
-                               da_inout, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
-                               c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
+        auto launch = [&](auto kernel) {
+            hipExtLaunchKernelGGL(kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, nullptr, done, 0,
+                                  da_inout, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
+                                  c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
+        };
+        if (g.V == 4) launch(bn_bwd_apply_kernel<4>);
+        else launch(bn_bwd_apply_kernel<1>);
         check_launch("bn_bwd_apply");
     }
-    if (dbias) {
-        ProfScope ps(ctx, FAM_BN);
-        hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0,
-                           ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, dbias);
-        check_launch("finish_channel_sum");
-    }
+    if (dbias && finish_dbias) launch_bn_bwd_apply_finish(ctx, partial_ws, M, C, dbias);
+}
+void launch_bn_bwd_apply_finish(rfi_ctx* ctx, const float* partial_ws, int64_t M, int C, float* dbias) {
+    ChanGeom g = geom_rows(M, C);
+    ProfScope ps(ctx, FAM_BN);
+    hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0,
+                       ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, dbias);
+    check_launch("finish_channel_sum");
 }
 
 size_t channel_sum_ws_floats(int64_t M, int C) {

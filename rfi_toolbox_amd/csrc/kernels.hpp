@@ -160,8 +160,15 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, YRef y, int64_t M, int C
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
                          float* partial_ws, float* dbias, float slope = 0.0f,
-                         unsigned short* planes_out = nullptr, int64_t planes_pstride = 0, int planes_P = 0);
+                         unsigned short* planes_out = nullptr, int64_t planes_pstride = 0, int planes_P = 0,
+                         hipEvent_t done = nullptr, bool finish_dbias = true);
+// finish_dbias = false: the per-block sums of dy stay in partial_ws (channel_sum_ws_floats(M, C) floats) and
+// launch_bn_bwd_apply_finish turns them into dbias later, e.g. on another stream (nothing consumes dbias before the optimiser)
+void launch_bn_bwd_apply_finish(rfi_ctx* ctx, const float* partial_ws, int64_t M, int C, float* dbias);
 // planes_out != null: dy is written as a plane tensor (planes.hpp; P bf16 pieces per value) instead of in place
+// done != null: the event completes with the kernel that writes dy (hipExtLaunchKernel's stop event: the dispatch's own
+// completion signal) -- another stream can wait for dy without an event-record packet in this stream's queue, which
+// costs the next kernel ~6.5 us of idle queue (rocprofv3 kernel trace, tools/trace_gaps.py)
 
 // ---------------------------------------------------------------- pool / head / loss
 // a = relu(y*scale+shift) -> skip view (full res) and 2x2 max-pooled p

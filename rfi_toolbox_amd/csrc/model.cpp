@@ -544,6 +544,22 @@ void rfi_model::side_begin() {
     RFI_CHECK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->fork_ev, 0));
     ctx->stream = ctx->side_stream;
 }
+hipEvent_t rfi_model::next_fork_event() {
+    static const bool off = getenv("RFI_NO_STOP_EVENTS") != nullptr;        // A/B runs: event-record packets as before
+    if (!ctx->overlap || off) return nullptr;
+    if (ctx->fork_ring_used == ctx->fork_ring.size()) {
+        hipEvent_t e;
+        RFI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->fork_ring.push_back(e);
+    }
+    return ctx->fork_ring[ctx->fork_ring_used++];
+}
+void rfi_model::side_begin_after(hipEvent_t producer_done) {
+    if (!producer_done) return side_begin();
+    if (!ctx->overlap) return;
+    RFI_CHECK_HIP(hipStreamWaitEvent(ctx->side_stream, producer_done, 0));
+    ctx->stream = ctx->side_stream;
+}
 void rfi_model::side_end() {
     if (!ctx->overlap) return;
     const int ring = (int)ctx->side_done.size();
@@ -558,6 +574,7 @@ void rfi_model::side_join() {
     const int ring = (int)ctx->side_done.size();
     RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->side_done[(side_seq - 1) % ring], 0));
     side_seq = 0;
+    ctx->fork_ring_used = 0;                      // (every wait on these events has been passed)
 }
 
 namespace rfi { void comm_bucket_allreduce(rfi_ctx* ctx, float* dptr, int64_t count); }

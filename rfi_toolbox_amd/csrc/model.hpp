@@ -232,6 +232,8 @@ struct rfi_model {
     int side_seq = 0;
     int side_bound = 2;               // main may run this many side launches ahead (0: no bound -- nothing the side work reads is rewritten before side_join)
     void side_begin();                // side stream waits for everything enqueued on the main stream so far
+    hipEvent_t next_fork_event();     // a fresh event for launch_*(..., done) (null: overlap off)
+    void side_begin_after(hipEvent_t producer_done);   // side stream waits for that producer kernel only (null: as side_begin)
     void side_end();                  // marks the side launch; bounds the main stream's run-ahead
     void side_join();                 // main stream waits for all side work
     // bucketed gradient exchange (common.hpp): grads[lo, hi) are final once everything enqueued so far on the main

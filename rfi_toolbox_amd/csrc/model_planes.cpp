@@ -278,7 +278,7 @@ namespace {
 struct SideScopeP {
     rfi_model* m;
     bool ended = false;
-    explicit SideScopeP(rfi_model* model) : m(model) { m->side_begin(); }
+    explicit SideScopeP(rfi_model* model, hipEvent_t after = nullptr) : m(model) { m->side_begin_after(after); }
     void end() { m->side_end(); ended = true; }
     ~SideScopeP() { if (!ended) m->ctx->stream = m->ctx->main_stream; }
 };
@@ -295,9 +295,10 @@ void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, YRef Y, const P
     else
         launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(), c.c2(),
                              m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
+    const hipEvent_t dy_done = m->next_fork_event();         // completes with the kernel that writes dY
     launch_bn_bwd_apply(ctx, const_cast<float*>(dA), Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
                         m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope, dYp.p, dYp.pstride,
-                        m->planesP);
+                        m->planesP, dy_done);
     PWgradArgs wa;
     wa.xop[0] = in[0];
     if (nseg > 1) wa.xop[1] = in[1];
@@ -316,7 +317,7 @@ void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, YRef Y, const P
     wa.slab = m->buf(m->ws_slab);
     wa.slab_floats = m->bufs[m->ws_slab].n;
     {
-        SideScopeP side(m);
+        SideScopeP side(m, dy_done);
         launch_pwgrad(ctx, wa);
         side.end();
     }
