@@ -203,9 +203,10 @@ def _bf(t):
 
 class _ConvBF16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, padding):
+    def forward(ctx, x, w, b, padding, round_dx=False):
         ctx.save_for_backward(x, w)
         ctx.padding = padding
+        ctx.round_dx = bool(round_dx)
         y = F.conv2d(_bf(x), _bf(w), b, padding=padding)
         return _bf(y) if _BF16_ROUND_OUTPUTS else y       # (straight-through: the gradient passes unchanged)
 
@@ -214,8 +215,10 @@ class _ConvBF16(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dyb = _bf(dy)
         dx = torch.nn.grad.conv2d_input(x.shape, _bf(w), dyb, padding=ctx.padding)
+        if ctx.round_dx:                                   # the input gradient is stored as a bfloat16 tensor
+            dx = _bf(dx)
         dw = torch.nn.grad.conv2d_weight(_bf(x), w.shape, dyb, padding=ctx.padding)
-        return dx, dw, dy.sum(dim=(0, 2, 3)), None
+        return dx, dw, dy.sum(dim=(0, 2, 3)), None, None
 
 
 class _ConvT2x2BF16(torch.autograd.Function):
@@ -235,29 +238,39 @@ class _ConvT2x2BF16(torch.autograd.Function):
 
 _BF16_OPERANDS = False
 _BF16_ROUND_OUTPUTS = False
+_BF16_ROUND_GRADS = False
+_WIDTHS_16 = False          # set by forward(): the model's first width is a multiple of 16 (then every width is)
 
 
 class bf16_operands:
     """``with unet_ref.bf16_operands(): ...`` -- forward/backward of the oracle in the bf16-operand arithmetic.
     ``round_outputs=True``: every 3x3 conv output (conv + bias, before BatchNorm) is additionally rounded to bfloat16,
     as torch.autocast does (its conv outputs ARE bf16 tensors) and as the HIP library's bf16 data flow does, which
-    stores them as bf16; BatchNorm statistics are then those of the rounded values."""
+    stores them as bf16; BatchNorm statistics are then those of the rounded values.
+    ``round_grads`` (default: as ``round_outputs``; needs widths that are multiples of 16, as the library does): the
+    input gradients of the 3x3 convs that feed a BatchNorm backward or the max-pool backward -- every second conv of
+    a DoubleConv, and the first conv of the bottleneck and of encoders 2.. -- are rounded to bfloat16 as well (under
+    torch.autocast they ARE bf16 tensors; the library stores them as bf16).  The decoder's first conv, whose input
+    gradient feeds the transposed conv and the skip, keeps float32."""
 
-    def __init__(self, round_outputs=False):
+    def __init__(self, round_outputs=False, round_grads=None):
         self.round_outputs = bool(round_outputs)
+        self.round_grads = self.round_outputs if round_grads is None else bool(round_grads)
 
     def __enter__(self):
-        global _BF16_OPERANDS, _BF16_ROUND_OUTPUTS
-        self.prev = (_BF16_OPERANDS, _BF16_ROUND_OUTPUTS)
-        _BF16_OPERANDS, _BF16_ROUND_OUTPUTS = True, self.round_outputs
+        global _BF16_OPERANDS, _BF16_ROUND_OUTPUTS, _BF16_ROUND_GRADS
+        self.prev = (_BF16_OPERANDS, _BF16_ROUND_OUTPUTS, _BF16_ROUND_GRADS)
+        _BF16_OPERANDS, _BF16_ROUND_OUTPUTS, _BF16_ROUND_GRADS = True, self.round_outputs, self.round_grads
 
     def __exit__(self, *exc):
-        global _BF16_OPERANDS, _BF16_ROUND_OUTPUTS
-        _BF16_OPERANDS, _BF16_ROUND_OUTPUTS = self.prev
+        global _BF16_OPERANDS, _BF16_ROUND_OUTPUTS, _BF16_ROUND_GRADS
+        _BF16_OPERANDS, _BF16_ROUND_OUTPUTS, _BF16_ROUND_GRADS = self.prev
 
 
-def _conv3x3(x, w, b):
-    return _ConvBF16.apply(x, w, b, 1) if _BF16_OPERANDS else F.conv2d(x, w, b, padding=1)
+def _conv3x3(x, w, b, round_dx=False):
+    if _BF16_OPERANDS:
+        return _ConvBF16.apply(x, w, b, 1, round_dx and _BF16_ROUND_GRADS and _WIDTHS_16)
+    return F.conv2d(x, w, b, padding=1)
 
 
 def _convt2x2(x, w, b):
@@ -266,7 +279,8 @@ def _convt2x2(x, w, b):
 
 def _double_conv(x, st, prefix, training, ema_repeats, buffer_updates, tape, negative_slope=0.0):
     for conv_idx, bn_idx in ((0, 1), (3, 4)):
-        x = _conv3x3(x, st[f"{prefix}.{conv_idx}.weight"], st[f"{prefix}.{conv_idx}.bias"])
+        x = _conv3x3(x, st[f"{prefix}.{conv_idx}.weight"], st[f"{prefix}.{conv_idx}.bias"],
+                     round_dx=conv_idx == 3 or not prefix.startswith("decoder"))
         if tape is not None:
             tape[f"{prefix}.{conv_idx}.out"] = x
         x = _bn(x, st, f"{prefix}.{bn_idx}", training, ema_repeats, buffer_updates, tape,
@@ -282,7 +296,9 @@ def forward(state, x_nchw, training=False, buffer_updates=None, tape=None, negat
     """Logits (N,out,H,W).  ``buffer_updates`` (dict) receives new BN buffers in train mode.
     ``negative_slope`` > 0: UNetDifferentActivation with LeakyReLU (models/unet.py:198-268);
     ``head_sigmoid``: UNetOverfit, which returns sigmoid(final_conv(.)) (models/unet.py:196)."""
+    global _WIDTHS_16
     _, _, _, depth = infer_config(state)
+    _WIDTHS_16 = state["encoder1.conv.conv.0.weight"].shape[0] % 16 == 0
     skips = []
     h = x_nchw
     ns = negative_slope

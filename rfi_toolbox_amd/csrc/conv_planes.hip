@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
         float* s_ep = reinterpret_cast<float*>(smem + wave * C::EPI_WAVE_BYTES);
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (g0 + g < my_tiles) epilogue(tile_of(g0 + g), acc[g], s_ep);
+            if (g0 + g < my_tiles && !(d.diag & 4)) epilogue(tile_of(g0 + g), acc[g], s_ep);
     };
 
     const unsigned char* const sA = smem;

@@ -225,7 +225,7 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
 // ------------------------------------------------------------------ batch-norm backward
 // partial[(rb*C+c)*2 + {0,1}] = sum dz, sum dz*xhat;  dz = da * (y*scale+shift > 0)
 template <int V>
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const void* __restrict__ y, int y16, int64_t yps,
+__global__ void bn_bwd_reduce_kernel(const void* __restrict__ da, int da16, const void* __restrict__ y, int y16, int64_t yps,
                                      int64_t M, int C, int CL, int64_t rows_per_block,
                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -246,7 +246,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ da, const void* _
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             float yv[V], dv[V];
             ldy<V>(y, y16, r * yps + c, yv);
-            ldv<V>(da + r * C + c, dv);
+            ldy<V>(da, da16, r * C + c, dv);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
@@ -291,7 +291,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int r
 
 // in place: da <- dy;  partial[rb*C+c] = sum dy (double)
 template <int V>
-__global__ void bn_bwd_apply_kernel(float* __restrict__ da, const void* __restrict__ y, int y16, int64_t yps, int64_t M,
+__global__ void bn_bwd_apply_kernel(void* __restrict__ da_, int da16, const void* __restrict__ y, int y16, int64_t yps, int64_t M,
                                     int C, int CL, int64_t rows_per_block,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -317,7 +317,7 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const void* __restri
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             float yv[V], dv[V], o[V];
             ldy<V>(y, y16, r * yps + c, yv);
-            ldv<V>(da + r * C + c, dv);
+            ldy<V>(da_, da16, r * C + c, dv);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
@@ -339,7 +339,7 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ da, const void* __restri
                     }
                 }
             } else {
-                stv<V>(da + r * C + c, o);
+                stv<V>(static_cast<float*>(da_) + r * C + c, o);        // (float32 tensors only: the launcher checks)
             }
         }
     }
@@ -480,7 +480,7 @@ template <bool SUMS>
 __global__ __launch_bounds__(256) void pool_bwd_merge_vec_kernel(
     const void* __restrict__ y, int y16, int64_t yps, int N, int H, int W, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ dskip, int dskip_ps, const float* __restrict__ dpool, float* __restrict__ da, float slope,
+    const float* __restrict__ dskip, int dskip_ps, const void* __restrict__ dpool, int dp16, float* __restrict__ da, float slope,
     double* __restrict__ records) {
     __shared__ double red[SUMS ? 8 * kBlock : 1];
     const int Hp = H >> 1, Wp = W >> 1, C4 = C >> 2;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void pool_bwd_merge_vec_kernel(
             }
         }
         float g[4];
-        ldv<4>(dpool + i * 4, g);
+        ldy<4>(dpool, dp16, i * 4, g);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float d[4];
@@ -1163,20 +1163,21 @@ void launch_bn_bwd_finalize_records(rfi_ctx* ctx, const float* partial_ws, int r
     check_launch("bn_bwd_finalize");
 }
 
-void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, YRef y, int64_t M, int C,
+void launch_bn_bwd_reduce(rfi_ctx* ctx, YRef da, YRef y, int64_t M, int C,
                           const float* scale, const float* shift, const float* mean,
                           const float* invstd, float* partial_ws, float* c1, float* c2,
                           float* dgamma, float* dbeta, float slope) {
     ChanGeom g = geom_rows(M, C);
     {
-        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * (y.bf16 ? 6 : 8));
+        RFI_REQUIRE(da.stride(C) == C && (!da.bf16 || g.V == 4), "bn_bwd_reduce: the gradient tensor must be dense (bfloat16: C % 4 == 0)");
+        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * ((y.bf16 ? 2 : 4) + (da.bf16 ? 2 : 4)));
         if (g.V == 4)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
-                               ctx->stream, da, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
+                               ctx->stream, da.p, da.bf16, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
                                reinterpret_cast<double*>(partial_ws), slope);
         else
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0,
-                               ctx->stream, da, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
+                               ctx->stream, da.p, da.bf16, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd,
                                reinterpret_cast<double*>(partial_ws), slope);
         check_launch("bn_bwd_reduce");
     }
@@ -1189,17 +1190,19 @@ void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, YRef y, int64_t M, int 
     }
 }
 
-void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, YRef y, int64_t M, int C,
+void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
                          float* partial_ws, float* dbias, float slope, unsigned short* planes_out,
                          int64_t planes_pstride, int planes_P, hipEvent_t done, bool finish_dbias) {
     ChanGeom g = geom_rows(M, C);
     {
-        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * ((planes_out ? 8 + 2 * planes_P : 12) - (y.bf16 ? 2 : 0)));
+        RFI_REQUIRE(da_inout.stride(C) == C && (!da_inout.bf16 || (planes_out && g.V == 4)),
+                    "bn_bwd_apply: a bfloat16 gradient tensor needs the plane output and C % 4 == 0");
+        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * ((planes_out ? 8 + 2 * planes_P : 12) - (y.bf16 ? 2 : 0) - (da_inout.bf16 ? 2 : 0)));
         auto launch = [&](auto kernel) {
             hipExtLaunchKernelGGL(kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, nullptr, done, 0,
-                                  da_inout, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
+                                  const_cast<void*>(da_inout.p), da_inout.bf16, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
                                   c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
         };
         if (g.V == 4) launch(bn_bwd_apply_kernel<4>);
@@ -1261,15 +1264,16 @@ void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int 
     }
 }
 
-static bool pool_vec_ok(YRef y, int C, const float* scale, const float* shift, View dskip, const float* dpool, const float* da) {
+static bool pool_vec_ok(YRef y, int C, const float* scale, const float* shift, View dskip, YRef dpool_, const float* da) {
+    const void* dpool = dpool_.p;
     return C % 4 == 0 && dskip.pstride % 4 == 0 && y.stride(C) % 4 == 0 &&
            !((reinterpret_cast<uintptr_t>(y.p) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
               reinterpret_cast<uintptr_t>(dskip.p) | reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(da)) & 15);
 }
 int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C, const float* scale,
-                               const float* shift, const float* mean, const float* invstd, View dskip, const float* dpool,
+                               const float* shift, const float* mean, const float* invstd, View dskip, YRef dpool,
                                float* da, float slope, float* partial_ws) {
-    if (!pool_vec_ok(y, C, scale, shift, dskip, dpool, da) ||
+    if (!pool_vec_ok(y, C, scale, shift, dskip, dpool, da) || dpool.stride(C) != C ||
         ((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(invstd)) & 15))
         return 0;
     const int C4 = C / 4;
@@ -1284,25 +1288,27 @@ int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
         records = grid / per;
     }
     if ((int64_t)grid * kBlock > total) return 0;   // (every thread must own at least one element)
-    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * 16);
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * (dpool.bf16 ? 8 : 16));
     hipLaunchKernelGGL(pool_bwd_merge_vec_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, y.p, y.bf16, y.stride(C), N, H, W,
-                       C, scale, shift, mean, invstd, dskip.p, dskip.pstride, dpool, da, slope, reinterpret_cast<double*>(partial_ws));
+                       C, scale, shift, mean, invstd, dskip.p, dskip.pstride, dpool.p, dpool.bf16, da, slope, reinterpret_cast<double*>(partial_ws));
     check_launch("pool_bwd_merge_sums");
     return records;
 }
 
 void launch_pool_bwd_merge(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
-                           const float* scale, const float* shift, View dskip, const float* dpool,
+                           const float* scale, const float* shift, View dskip, YRef dpool,
                            float* da, float slope) {
+    const bool vec = pool_vec_ok(y, C, scale, shift, dskip, dpool, da) && dpool.stride(C) == C;
+    RFI_REQUIRE(vec || !dpool.bf16, "pool_bwd_merge: a bfloat16 pooled gradient needs C % 4 == 0 and aligned tensors");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
     {
-        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * 4);
-        if (pool_vec_ok(y, C, scale, shift, dskip, dpool, da))
+        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * (dpool.bf16 ? 2 : 4));
+        if (vec)
             hipLaunchKernelGGL(pool_bwd_merge_vec_kernel<false>, dim3(grid_for(total / 4)), dim3(kBlock), 0, ctx->stream, y.p, y.bf16,
-                               y.stride(C), N, H, W, C, scale, shift, nullptr, nullptr, dskip.p, dskip.pstride, dpool, da, slope, nullptr);
+                               y.stride(C), N, H, W, C, scale, shift, nullptr, nullptr, dskip.p, dskip.pstride, dpool.p, dpool.bf16, da, slope, nullptr);
         else
             hipLaunchKernelGGL(pool_bwd_merge_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y.p, y.bf16, y.stride(C),
-                               N, H, W, C, scale, shift, dskip.p, dskip.pstride, dpool, da, slope);
+                               N, H, W, C, scale, shift, dskip.p, dskip.pstride, static_cast<const float*>(dpool.p), da, slope);
         check_launch("pool_bwd_merge");
     }
     if ((H & 1) || (W & 1)) {

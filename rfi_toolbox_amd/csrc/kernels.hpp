@@ -119,6 +119,7 @@ void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);
 
 // The raw output Y of a conv layer as the elementwise kernels read it: float32 [M][C] or, in the bf16 data flow
 // (planes.hpp, P = 1), bfloat16 [M][ps].  A `const float*` converts implicitly, so float32 call sites read as before.
+// (also the gradient tensors a conv kernel writes: float32, or bfloat16 in the bf16 data flow)
 struct YRef {
     const void* p = nullptr;
     int bf16 = 0;
@@ -146,7 +147,7 @@ void launch_bn_eval_coeffs(rfi_ctx* ctx, int C, const float* gamma, const float*
                            float* shift);
 // backward, pass 1: per-channel sum(dz), sum(dz * xhat) with dz = da * (act > 0)
 //   -> c1 = mean(dz), c2 = mean(dz*xhat), dgamma, dbeta   (two launches: partial + finalize)
-void launch_bn_bwd_reduce(rfi_ctx* ctx, const float* da, YRef y, int64_t M, int C,
+void launch_bn_bwd_reduce(rfi_ctx* ctx, YRef da, YRef y, int64_t M, int C,
                           const float* scale, const float* shift, const float* mean,
                           const float* invstd, float* partial_ws, float* c1, float* c2,
                           float* dgamma, float* dbeta, float slope = 0.0f);
@@ -156,7 +157,7 @@ void launch_bn_bwd_finalize_records(rfi_ctx* ctx, const float* partial_ws, int r
                                     float* c2, float* dgamma, float* dbeta);
 // backward, pass 2 (in place on da): dy = gamma*invstd * (dz - c1 - xhat*c2); also per-channel
 // sum(dy) -> dbias_conv (partials in ws, finished by the same launch pair)
-void launch_bn_bwd_apply(rfi_ctx* ctx, float* da_inout, YRef y, int64_t M, int C,
+void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
                          float* partial_ws, float* dbias, float slope = 0.0f,
@@ -176,13 +177,13 @@ void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int 
                          const float* scale, const float* shift, MutView skip, float* pooled, float slope = 0.0f);
 // da[n,y,x,c] = dskip[n,y,x,c] + (argmax of the 2x2 window of a == (y,x) ? dpool : 0)
 void launch_pool_bwd_merge(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
-                           const float* scale, const float* shift, View dskip, const float* dpool,
+                           const float* scale, const float* shift, View dskip, YRef dpool,
                            float* da, float slope = 0.0f);
 // the same pass, also writing the BatchNorm-backward sums of that layer (sum dz, sum dz * xhat) as fp64 records into
 // partial_ws (bn_bwd_ws_floats) for launch_bn_bwd_finalize_records; returns the record count, or 0 when the shape does
 // not fit the scheme (nothing launched: call launch_pool_bwd_merge and the separate reduction instead)
 int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C, const float* scale,
-                               const float* shift, const float* mean, const float* invstd, View dskip, const float* dpool,
+                               const float* shift, const float* mean, const float* invstd, View dskip, YRef dpool,
                                float* da, float slope, float* partial_ws);
 // logits[m,o] = b[o] + sum_c relu(y*scale+shift)[m,c] * w[o][c]
 void launch_head_fwd(rfi_ctx* ctx, YRef y, int64_t M, int C, const float* scale,

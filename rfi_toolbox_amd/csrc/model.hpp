@@ -218,6 +218,11 @@ struct rfi_model {
     bool y16_flow = false;
     std::vector<int> yE1, yE2, yD1;
     int yB1 = -1, yD2top = -1;
+    // bf16 data flow: the gradient tensors the input-gradient convs write (dA of every first conv, the pooled gradients) are
+    // bfloat16 too -- as torch.autocast's are -- when the level widths are multiples of 16
+    bool g16_flow = false;
+    std::vector<int> g16B, g16pool;
+    int g16BottB = -1;
     rfi::bf16_t* wb_pool = nullptr;
     void* wb_descs = nullptr;
     int wb_n = 0;

@@ -80,6 +80,21 @@ void rfi_model::prepare_planes(int n, int h, int w) {
         pl[yB1].ensure(ctx, Mb, feat << D, 1);
         pl[yD2top].ensure(ctx, M1, feat, 1);
     }
+    static const bool no_g16 = getenv("RFI_NO_G16") != nullptr;                 // A/B runs: float32 gradient tensors
+    g16_flow = y16_flow && feat % 16 == 0 && !no_g16;
+    if (g16_flow) {
+        if (g16BottB < 0) {
+            auto mk1 = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) { pl.emplace_back(); v[l] = (int)pl.size() - 1; } };
+            mk1(g16B); mk1(g16pool);
+            pl.emplace_back(); g16BottB = (int)pl.size() - 1;
+        }
+        for (int l = 1; l <= D; ++l) {
+            const int64_t M = (int64_t)n * (h >> (l - 1)) * (w >> (l - 1));
+            pl[g16B[l]].ensure(ctx, M, feat << (l - 1), 1);
+            pl[g16pool[l]].ensure(ctx, M / 4, feat << (l - 1), 1);
+        }
+        pl[g16BottB].ensure(ctx, Mb, feat << D, 1);
+    }
     // weight-gradient slabs of the plane kernel
     size_t slab_need = 0;
     for (size_t ci = 0; ci < convs.size(); ++ci) {
@@ -285,8 +300,19 @@ struct SideScopeP {
 
 // dA: gradient w.r.t. the ACTIVATED output of conv c (float32, left untouched).  Writes dW / db / dgamma / dbeta
 // and, if dx != null, the gradient w.r.t. the conv's input (float32 raw, `cin` channels per pixel).
-void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, YRef Y, const PlaneSeg* in, int nseg, Shape s,
-                       float* dx, PlaneBuf& dYp, int have_records = 0) {
+// a gradient tensor a conv kernel writes: float32 buffer, or (bf16 data flow) a dense bfloat16 [pixel][C] tensor
+struct GT {
+    float* f = nullptr;
+    PlaneBuf* h = nullptr;
+    GT(float* p) : f(p) {}
+    GT(std::nullptr_t) {}
+    GT(PlaneBuf& b) : h(&b) {}
+    explicit operator bool() const { return f || h; }
+    YRef ref() const { return h ? YRef(h->p, h->pstride) : YRef(f); }
+};
+
+void backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg* in, int nseg, Shape s,
+                       GT dx, PlaneBuf& dYp, int have_records = 0) {
     rfi_ctx* ctx = m->ctx;
     const int64_t M = (int64_t)s.N * s.H * s.W;
     float* ws = m->buf(m->ws_red);
@@ -296,7 +322,7 @@ void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, YRef Y, const P
         launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(), c.c2(),
                              m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
     const hipEvent_t dy_done = m->next_fork_event();         // completes with the kernel that writes dY
-    launch_bn_bwd_apply(ctx, const_cast<float*>(dA), Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
+    launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
                         m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope, dYp.p, dYp.pstride,
                         m->planesP, dy_done);
     PWgradArgs wa;
@@ -328,7 +354,8 @@ void backward_pconv_bn(rfi_model* m, ConvBN& c, const float* dA, YRef Y, const P
         a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
         a.Cout = c.cin;                           // dx exists only for layers whose cin == cin_p
         a.wB = c.wBd;
-        a.y = dx; a.y_pstride = c.cin;
+        if (dx.h) { a.y16 = dx.h->p; a.y_pstride = (int)dx.h->pstride; }
+        else { a.y = dx.f; a.y_pstride = c.cin; }
         a.Hout = s.H; a.Wout = s.W;
         a.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
         launch_pconv(ctx, a);
@@ -346,6 +373,8 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     side_bound = bound_env;
     // a raw conv output of the forward pass: bfloat16 tensor pl[hi] in the bf16 flow, else float32 bufs[fi]
     auto yr = [&](int fi, int hi) { return (y16_flow && hi >= 0) ? YRef(pl[hi].p, pl[hi].pstride) : YRef(buf(fi)); };
+    // a gradient tensor an input-gradient conv writes: bfloat16 tensor pl[hi] in the bf16 flow, else float32 bufs[fi]
+    auto gt = [&](int fi, int hi) { return hi >= 0 ? GT(pl[hi]) : GT(buf(fi)); };
     const int64_t M1 = (int64_t)n * h * w;
     if (loss_kind == 1)
         launch_focal_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, focal_alpha, focal_gamma, buf(dlogits));
@@ -367,10 +396,10 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         const PlaneSeg a1 = seg_of(pl[pA1d[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), yr(decY2[l], y16_flow && l == 1 ? yD2top : -1), &a1, 1, s, buf(gB[l]), pl[pdYa[l]],
+        backward_pconv_bn(this, c2, buf(gA[l]), yr(decY2[l], y16_flow && l == 1 ? yD2top : -1), &a1, 1, s, gt(gB[l], g16_flow ? g16B[l] : -1), pl[pdYa[l]],
                           l == 1 ? head_records : 0);
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};
-        backward_pconv_bn(this, c1, buf(gB[l]), yr(decY1[l], y16_flow ? yD1[l] : -1), in2, 2, s, buf(dconcat[l]), pl[pdYb[l]]);
+        backward_pconv_bn(this, c1, gt(gB[l], g16_flow ? g16B[l] : -1).ref(), yr(decY1[l], y16_flow ? yD1[l] : -1), in2, 2, s, buf(dconcat[l]), pl[pdYb[l]]);
         // ConvTranspose: dUp = dconcat[..., 0:C]; the round-1 kernels on float32 tensors
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
         ConvBN& prevBN = (l == D) ? convs[2 * D + 1] : convs[2 * D + 2 + 2 * (k - 1) + 1];
@@ -413,8 +442,9 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     {                                             // bottleneck
         Shape s{n, h >> D, w >> D};
         const PlaneSeg a1 = seg_of(pl[pA1b]), p4 = seg_of(pl[pPool[D]]);
-        backward_pconv_bn(this, convs[2 * D + 1], buf(gBottA), buf(bottY2), &a1, 1, s, buf(gBottB), pl[pdYbottA]);
-        backward_pconv_bn(this, convs[2 * D], buf(gBottB), yr(bottY1, y16_flow ? yB1 : -1), &p4, 1, s, buf(dpool[D]), pl[pdYbottB]);
+        backward_pconv_bn(this, convs[2 * D + 1], buf(gBottA), buf(bottY2), &a1, 1, s, gt(gBottB, g16_flow ? g16BottB : -1), pl[pdYbottA]);
+        backward_pconv_bn(this, convs[2 * D], gt(gBottB, g16_flow ? g16BottB : -1).ref(), yr(bottY1, y16_flow ? yB1 : -1), &p4, 1, s,
+                          gt(dpool[D], g16_flow ? g16pool[D] : -1), pl[pdYbottB]);
         bucket_ready(convs[2 * D].w_off, ups[0].w_off);
     }
     for (int l = D; l >= 1; --l) {                // encoders, deep to shallow
@@ -422,15 +452,16 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
         const int have = launch_pool_bwd_merge_sums(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), c2.mean(),
-                                                    c2.invstd(), View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]),
+                                                    c2.invstd(), View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(),
                                                     buf(gA[l]), act_slope, buf(ws_red));
         if (!have)
             launch_pool_bwd_merge(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
-                                  View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, buf(dpool[l]), buf(gA[l]), act_slope);
+                                  View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(), buf(gA[l]), act_slope);
         const PlaneSeg a1 = seg_of(pl[pA1e[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, buf(gB[l]), pl[pdYaE[l]], have);
+        backward_pconv_bn(this, c2, buf(gA[l]), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, gt(gB[l], g16_flow ? g16B[l] : -1), pl[pdYaE[l]], have);
         const PlaneSeg in = seg_of(l == 1 ? pl[pXin] : pl[pPool[l - 1]]);
-        backward_pconv_bn(this, c1, buf(gB[l]), yr(encY1[l], y16_flow ? yE1[l] : -1), &in, 1, s, (l == 1) ? nullptr : buf(dpool[l - 1]),
+        backward_pconv_bn(this, c1, gt(gB[l], g16_flow ? g16B[l] : -1).ref(), yr(encY1[l], y16_flow ? yE1[l] : -1), &in, 1, s,
+                          (l == 1) ? GT(nullptr) : gt(dpool[l - 1], g16_flow ? g16pool[l - 1] : -1),
                           pl[pdYbE[l]]);
         bucket_ready(c1.w_off, convs[2 * l].w_off);
     }
