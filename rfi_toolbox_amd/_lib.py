@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librfi_hip.so")
+LIB_PATH = os.environ.get("RFI_HIP_LIB") or os.path.join(_HERE, "librfi_hip.so")     # (override: A/B runs of two builds)
 
 HOST, DEVICE = 0, 1
 C128, C64, F64, F32 = 0, 1, 2, 3

@@ -91,7 +91,7 @@ __device__ __forceinline__ f32x16 mma(const bf16x8 (&a)[P], const bf16x8 (&b)[P]
 // other workgroup's MFMAs, LDS reads and output stores fill the wait).  A workgroup walks its tiles in GROUPS of
 // G: for each K chunk the filter tile is staged ONCE and used by the G tiles of the group (G sets of
 // accumulators), so the filter traffic per MFMA drops G-fold.
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD>
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD, bool BWD>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>;
     const PConvArgs& a = d.a;
@@ -226,11 +226,50 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
         // keeping 5 registers, and each of those loads drains the vector-memory queue
         asm volatile("" : "+v"(bias4[nt].x), "+v"(bias4[nt].y), "+v"(bias4[nt].z), "+v"(bias4[nt].w), "+v"(bias1[nt]));
     }
+    // BatchNorm-backward sums in the epilogue (PConvArgs::bwd_y16): the layer's per-channel coefficients of this lane's
+    // four channels, loaded once like the bias
+    // (BWD is a template parameter: the extra registers and branches slowed EVERY launch by 3 % as a runtime switch)
+    const bool bwd = BWD && a.bwd_y16 != nullptr && a.stats != nullptr && vec_out;
+    f32x4 bsc[BWD ? NTL : 1], bsh[BWD ? NTL : 1], bmu[BWD ? NTL : 1], bis[BWD ? NTL : 1];
+#pragma unroll
+    for (int nt = 0; nt < (BWD ? NTL : 0); ++nt) {
+        bsc[nt] = bsh[nt] = bmu[nt] = bis[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int co = n0 + (wn * NTL + nt) * 32 + (lane & 7) * 4;
+        if (bwd && co < a.Cout) {
+            bsc[nt] = *reinterpret_cast<const f32x4*>(a.bwd_scale + co);
+            bsh[nt] = *reinterpret_cast<const f32x4*>(a.bwd_shift + co);
+            bmu[nt] = *reinterpret_cast<const f32x4*>(a.bwd_mean + co);
+            bis[nt] = *reinterpret_cast<const f32x4*>(a.bwd_invstd + co);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(bsc[nt][e]), "+v"(bsh[nt][e]), "+v"(bmu[nt][e]), "+v"(bis[nt][e]));
+    }
     // ---- epilogue of one tile.  C/D layout of 32x32: col = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2)
     // + 4 * (lane >> 5) (pixel).  Each 32x32 block is transposed through this wave's private LDS scratch and leaves
     // as 4 x 16-byte-per-lane stores of whole 128-byte pixel rows; BatchNorm statistics are folded on the way.
     auto epilogue = [&](const Tile& ct, f32x16 (&ac)[MT][NTL], float* s_ep) {
         const int xs = a.osx * a.y_pstride;
+        // bwd: the layer's raw outputs at this lane's (pixel, 4 channels) positions, fetched before any store of the
+        // tile is issued (the wait at their first use then never has to pass one of this tile's stores)
+        u32x2 ypre[BWD ? MT : 1][BWD ? NTL : 1][2][2];
+        if constexpr (BWD) if (bwd) {
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps) {
+                            const int pp = half * 16 + ps * 8 + (lane >> 3);
+                            const int oy = ct.oy0 + ((wm * MT + mt) * 32) / TW + pp / TW, ox = ct.ox0 + ((wm * MT + mt) * 32) % TW + pp % TW;
+                            const int co = n0 + (wn * NTL + nt) * 32 + (lane & 7) * 4;
+                            ypre[mt][nt][half][ps] = u32x2{0u, 0u};
+                            if (co < a.Cout && oy < a.H && ox < a.W)
+                                ypre[mt][nt][half][ps] = *reinterpret_cast<const u32x2*>(
+                                    a.bwd_y16 + (size_t)((ct.n * a.H + oy) * a.W + ox) * a.bwd_yps + co);
+                        }
+        }
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             const int co0 = n0 + (wn * NTL + nt) * 32;
@@ -274,8 +313,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                                 }
                                 if (!a.y16) *reinterpret_cast<f32x4*>(a.y + off) = v;
                                 if (st_out) {
-                                    p1 += v;
-                                    p2 += v * v;
+                                    if (BWD && bwd) {
+                                        const u32x2 t = ypre[BWD ? mt : 0][BWD ? nt : 0][half][ps];
+                                        const f32x4 yv = {__builtin_bit_cast(float, t[0] << 16), __builtin_bit_cast(float, t[0] & 0xffff0000u),
+                                                          __builtin_bit_cast(float, t[1] << 16), __builtin_bit_cast(float, t[1] & 0xffff0000u)};
+                                        const f32x4 z = yv * bsc[BWD ? nt : 0] + bsh[BWD ? nt : 0], xh = (yv - bmu[BWD ? nt : 0]) * bis[BWD ? nt : 0];
+                                        f32x4 dz;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.0f ? v[e] : v[e] * a.bwd_slope;
+                                        p1 += dz;
+                                        p2 += dz * xh;
+                                    } else {
+                                        p1 += v;
+                                        p2 += v * v;
+                                    }
                                 }
                             }
                         }
@@ -430,8 +481,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     }
 }
 
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1>
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1, bool BWD = false>
 void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
+    if constexpr (!BWD && P == 1)                     // the BatchNorm-backward epilogue: its own instantiation (bf16 flow only)
+        if (d.a.bwd_y16) return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, true>(ctx, d);
     using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>;
     PConvArgs& a = d.a;
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
@@ -451,9 +504,13 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
     RFI_REQUIRE(vec_out || !(a.y16 || a.round_y), "pconv: bf16 output needs Cout % 4 == 0 and an aligned tensor");
     if (a.stats && vec_out && GX <= a.stats_max_records) a.stats_records = GX;
     else { a.stats = nullptr; a.stats_records = 0; }
+    RFI_REQUIRE(!a.bwd_y16 || P == 1, "pconv: the BatchNorm-backward epilogue exists for the bfloat16 flow only");
+    RFI_REQUIRE(!a.bwd_y16 || (a.Hout == a.H && a.Wout == a.W && a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 &&
+                               (a.bwd_yps & 3) == 0 && (reinterpret_cast<uintptr_t>(a.bwd_y16) & 7) == 0),
+                "pconv: BatchNorm-backward sums need a dense output grid and an aligned bfloat16 Y");
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
 #ifdef RFI_DIAG_STAMPS
@@ -461,7 +518,7 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
         const size_t nw = (size_t)GX * ychunks * C::NW;
         RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d.stamps), nw * 64));
         RFI_CHECK_HIP(hipMemsetAsync(d.stamps, 0, nw * 64, ctx->stream));
-        hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+        hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
         std::vector<unsigned long long> hs(nw * 8);
         RFI_CHECK_HIP(hipMemcpyAsync(hs.data(), d.stamps, nw * 64, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -475,7 +532,7 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
         return;
     }
 #endif
-    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
     check_launch("pconv");
 }
 

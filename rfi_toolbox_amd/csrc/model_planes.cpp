@@ -311,8 +311,11 @@ struct GT {
     YRef ref() const { return h ? YRef(h->p, h->pstride) : YRef(f); }
 };
 
-void backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg* in, int nseg, Shape s,
-                       GT dx, PlaneBuf& dYp, int have_records = 0) {
+// `next` (with its raw bfloat16 output next_Y): the layer whose activated output dx is the gradient of -- its BatchNorm-
+// backward sums are then folded into the input-gradient conv's epilogue; returns the number of records left for it in
+// the workspace (0: none, the caller's next call runs bn_bwd_reduce).
+int backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg* in, int nseg, Shape s,
+                      GT dx, PlaneBuf& dYp, int have_records = 0, ConvBN* next = nullptr, YRef next_Y = YRef((const float*)nullptr)) {
     rfi_ctx* ctx = m->ctx;
     const int64_t M = (int64_t)s.N * s.H * s.W;
     float* ws = m->buf(m->ws_red);
@@ -358,8 +361,20 @@ void backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg*
         else { a.y = dx.f; a.y_pstride = c.cin; }
         a.Hout = s.H; a.Wout = s.W;
         a.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
+        static const bool no_fuse = getenv("RFI_NO_BN_FUSE") != nullptr;     // A/B runs: separate bn_bwd_reduce
+        if (next && next_Y.bf16 && !no_fuse) {
+            a.stats = reinterpret_cast<double*>(ws);          // (this layer's dy sums have been finished out of it)
+            a.stats_max_records = (int)(bn_stats_ws_floats(next->cout) / ((size_t)next->cout * 4));
+            a.bwd_y16 = static_cast<const bf16_t*>(next_Y.p);
+            a.bwd_yps = next_Y.stride(next->cout);
+            a.bwd_scale = next->scale(); a.bwd_shift = next->shift();
+            a.bwd_mean = next->mean(); a.bwd_invstd = next->invstd();
+            a.bwd_slope = m->act_slope;
+        }
         launch_pconv(ctx, a);
+        return a.stats_records;
     }
+    return 0;
 }
 
 }  // namespace
@@ -396,10 +411,12 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         const PlaneSeg a1 = seg_of(pl[pA1d[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), yr(decY2[l], y16_flow && l == 1 ? yD2top : -1), &a1, 1, s, gt(gB[l], g16_flow ? g16B[l] : -1), pl[pdYa[l]],
-                          l == 1 ? head_records : 0);
+        const int rec1 = backward_pconv_bn(this, c2, buf(gA[l]), yr(decY2[l], y16_flow && l == 1 ? yD2top : -1), &a1, 1, s,
+                                           gt(gB[l], g16_flow ? g16B[l] : -1), pl[pdYa[l]], l == 1 ? head_records : 0, &c1,
+                                           yr(decY1[l], y16_flow ? yD1[l] : -1));
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};
-        backward_pconv_bn(this, c1, gt(gB[l], g16_flow ? g16B[l] : -1).ref(), yr(decY1[l], y16_flow ? yD1[l] : -1), in2, 2, s, buf(dconcat[l]), pl[pdYb[l]]);
+        backward_pconv_bn(this, c1, gt(gB[l], g16_flow ? g16B[l] : -1).ref(), yr(decY1[l], y16_flow ? yD1[l] : -1), in2, 2, s, buf(dconcat[l]), pl[pdYb[l]],
+                          rec1);
         // ConvTranspose: dUp = dconcat[..., 0:C]; the round-1 kernels on float32 tensors
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
         ConvBN& prevBN = (l == D) ? convs[2 * D + 1] : convs[2 * D + 2 + 2 * (k - 1) + 1];
@@ -442,9 +459,10 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     {                                             // bottleneck
         Shape s{n, h >> D, w >> D};
         const PlaneSeg a1 = seg_of(pl[pA1b]), p4 = seg_of(pl[pPool[D]]);
-        backward_pconv_bn(this, convs[2 * D + 1], buf(gBottA), buf(bottY2), &a1, 1, s, gt(gBottB, g16_flow ? g16BottB : -1), pl[pdYbottA]);
+        const int rec1 = backward_pconv_bn(this, convs[2 * D + 1], buf(gBottA), buf(bottY2), &a1, 1, s, gt(gBottB, g16_flow ? g16BottB : -1),
+                                           pl[pdYbottA], 0, &convs[2 * D], yr(bottY1, y16_flow ? yB1 : -1));
         backward_pconv_bn(this, convs[2 * D], gt(gBottB, g16_flow ? g16BottB : -1).ref(), yr(bottY1, y16_flow ? yB1 : -1), &p4, 1, s,
-                          gt(dpool[D], g16_flow ? g16pool[D] : -1), pl[pdYbottB]);
+                          gt(dpool[D], g16_flow ? g16pool[D] : -1), pl[pdYbottB], rec1);
         bucket_ready(convs[2 * D].w_off, ups[0].w_off);
     }
     for (int l = D; l >= 1; --l) {                // encoders, deep to shallow
@@ -458,11 +476,12 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
             launch_pool_bwd_merge(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
                                   View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(), buf(gA[l]), act_slope);
         const PlaneSeg a1 = seg_of(pl[pA1e[l]]);
-        backward_pconv_bn(this, c2, buf(gA[l]), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, gt(gB[l], g16_flow ? g16B[l] : -1), pl[pdYaE[l]], have);
+        const int rec1 = backward_pconv_bn(this, c2, buf(gA[l]), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, gt(gB[l], g16_flow ? g16B[l] : -1),
+                                           pl[pdYaE[l]], have, &c1, yr(encY1[l], y16_flow ? yE1[l] : -1));
         const PlaneSeg in = seg_of(l == 1 ? pl[pXin] : pl[pPool[l - 1]]);
         backward_pconv_bn(this, c1, gt(gB[l], g16_flow ? g16B[l] : -1).ref(), yr(encY1[l], y16_flow ? yE1[l] : -1), &in, 1, s,
                           (l == 1) ? GT(nullptr) : gt(dpool[l - 1], g16_flow ? g16pool[l - 1] : -1),
-                          pl[pdYbE[l]]);
+                          pl[pdYbE[l]], rec1);
         bucket_ready(c1.w_off, convs[2 * l].w_off);
     }
     side_join();

@@ -83,6 +83,17 @@ struct PConvArgs {
     double* stats = nullptr;          // as ConvArgs::stats
     int stats_max_records = 0;
     int stats_records = 0;
+    // bwd_y16 != null (with stats; input-gradient convs): the output is the gradient dA w.r.t. the ACTIVATED output of a
+    // conv + BatchNorm + (Leaky)ReLU layer whose raw bfloat16 conv output is bwd_y16 (same pixels, bwd_yps elements per
+    // pixel).  The records then hold that layer's BatchNorm-BACKWARD sums (sum dz, sum dz * xhat with dz = dA * act'(z),
+    // of the values as stored) instead of the output statistics: bn_bwd_reduce's pass over dA and Y disappears.
+    const bf16_t* bwd_y16 = nullptr;
+    int64_t bwd_yps = 0;
+    const float* bwd_scale = nullptr;
+    const float* bwd_shift = nullptr;
+    const float* bwd_mean = nullptr;
+    const float* bwd_invstd = nullptr;
+    float bwd_slope = 0.0f;
     double algo_flops = -1;
 };
 void launch_pconv(rfi_ctx* ctx, PConvArgs& a);
