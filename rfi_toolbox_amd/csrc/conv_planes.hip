@@ -22,6 +22,7 @@
 // The epilogue transposes the accumulators through LDS into 16-byte stores of whole pixel rows, adds the bias and
 // folds the BatchNorm statistics of the output (sum y, sum y^2 per channel; fp64 per workgroup record).
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "planes.hpp"
@@ -91,7 +92,10 @@ __device__ __forceinline__ f32x16 mma(const bf16x8 (&a)[P], const bf16x8 (&b)[P]
 // other workgroup's MFMAs, LDS reads and output stores fill the wait).  A workgroup walks its tiles in GROUPS of
 // G: for each K chunk the filter tile is staged ONCE and used by the G tiles of the group (G sets of
 // accumulators), so the filter traffic per MFMA drops G-fold.
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD, bool BWD>
+// OM: what the output tensor holds -- 0 float32, 1 float32 holding bf16-rounded values (round_y), 2 bfloat16 (y16).
+// BWD / OM are template parameters: the epilogue is instruction-issue bound on the shallow layers (a runtime switch for
+// BWD alone cost every launch 3 %).
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD, bool BWD, int OM>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>;
     const PConvArgs& a = d.a;
@@ -158,8 +162,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
         r.n = t / (tiles_x * tiles_y);
         return r;
     };
-    auto issue_A = [&](int k, int kc) {              // halo tile of chunk kc of this workgroup's k-th tile
-        const Tile t = tile_of(k);
+    auto issue_A = [&](const Tile& t, int kc) {      // halo tile of chunk kc of one of this workgroup's tiles
         const int seg = kc >= a.x[0].nchunks ? 1 : 0;
         const unsigned coff = (unsigned)(seg ? kc - a.x[0].nchunks : kc) * (P * 32);
         const unsigned ps = (unsigned)a.x[seg].pstride * 2u;
@@ -247,8 +250,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     // ---- epilogue of one tile.  C/D layout of 32x32: col = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2)
     // + 4 * (lane >> 5) (pixel).  Each 32x32 block is transposed through this wave's private LDS scratch and leaves
     // as 4 x 16-byte-per-lane stores of whole 128-byte pixel rows; BatchNorm statistics are folded on the way.
-    auto epilogue = [&](const Tile& ct, f32x16 (&ac)[MT][NTL], float* s_ep) {
+    // store offsets (elements): a wave-uniform part per (tile, 8-pixel row group) + this lane's part -- pixel (lane >> 3)
+    // of the group, channels 4 (lane & 7) .. + 3 of the n-tile
+    static_assert(TW % 8 == 0, "an 8-pixel row group must not wrap");
+    const unsigned col_st = (unsigned)(a.osx * a.y_pstride), row_st = (unsigned)(a.osy * a.Wout * a.y_pstride);
+    unsigned lane_off[NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) lane_off[nt] = (unsigned)(lane >> 3) * col_st + (unsigned)(n0 + (wn * NTL + nt) * 32 + (lane & 7) * 4);
+    auto epilogue = [&](const Tile& ct, f32x16 (&ac)[MT][NTL], float* s_ep, auto vec_tag) {
+        constexpr bool VEC = decltype(vec_tag)::value;   // 16-byte row stores (vec_out) or the scalar fallback: one branch per tile
         const int xs = a.osx * a.y_pstride;
+        // tiles that lie inside the image with all their channels (every tile of the U-Net shapes): no bounds tests
+        const bool full = ct.oy0 + TH <= a.H && ct.ox0 + TW <= a.W && n0 + C::BN <= a.Cout;
+        const unsigned tbase = (unsigned)(((ct.n * a.Hout + ct.oy0 * a.osy + a.ooy) * a.Wout + ct.ox0 * a.osx + a.oox) * a.y_pstride);
         // bwd: the layer's raw outputs at this lane's (pixel, 4 channels) positions, fetched before any store of the
         // tile is issued (the wait at their first use then never has to pass one of this tile's stores)
         u32x2 ypre[BWD ? MT : 1][BWD ? NTL : 1][2][2];
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
             for (int mt = 0; mt < MT; ++mt) {
                 const int oyb = ct.oy0 + ((wm * MT + mt) * 32) / TW;
                 const int oxb = ct.ox0 + ((wm * MT + mt) * 32) % TW;
-                if (vec_out) {
+                if constexpr (VEC) {
                     const int g4 = (lane & 7) * 4;
                     const int co = co0 + g4;
                     const f32x4 b4 = bias4[nt];
@@ -292,11 +306,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                             const int pl = ps * 8 + (lane >> 3);
                             const int pp = half * 16 + pl;
                             f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pl * 36 + g4) + b4;
+                            const int p0 = (wm * MT + mt) * 32 + half * 16 + ps * 8;         // first pixel of the row group (wave-uniform)
+                            const unsigned off = tbase + (unsigned)(p0 / TW) * row_st + (unsigned)(p0 % TW) * col_st + lane_off[nt];
                             const int oy = oyb + pp / TW, ox = oxb + pp % TW;
-                            if (co < a.Cout && oy < a.H && ox < a.W) {
-                                const unsigned off = (unsigned)(((ct.n * a.Hout + oy * a.osy + a.ooy) * a.Wout + ox * a.osx + a.oox) *
-                                                                a.y_pstride + co);
-                                if (a.y16 || a.round_y) {               // the tensor holds bf16 values (RNE; NaN stays NaN)
+                            if (full || (co < a.Cout && oy < a.H && ox < a.W)) {
+                                if constexpr (OM >= 1) {                // the tensor holds bf16 values (RNE; NaN stays NaN)
                                     unsigned short q[4];
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
@@ -304,14 +318,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                                         q[e] = __builtin_bit_cast(unsigned short, h);
                                         v[e] = (float)h;
                                     }
-                                    if (a.y16) {
+                                    if constexpr (OM == 2) {
                                         u32x2 pk;
                                         pk[0] = (unsigned)q[0] | ((unsigned)q[1] << 16);
                                         pk[1] = (unsigned)q[2] | ((unsigned)q[3] << 16);
                                         *reinterpret_cast<u32x2*>(a.y16 + off) = pk;
                                     }
                                 }
-                                if (!a.y16) *reinterpret_cast<f32x4*>(a.y + off) = v;
+                                if constexpr (OM != 2) *reinterpret_cast<f32x4*>(a.y + off) = v;
                                 if (st_out) {
                                     if (BWD && bwd) {
                                         const u32x2 t = ypre[BWD ? mt : 0][BWD ? nt : 0][half][ps];
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ac[mt][nt][r] = 0.0f;
             }
-            if (st_out && vec_out) {
+            if (VEC && st_out) {
                 // lanes l, l^8, l^16, l^32 hold the same 4 channels of different pixels: fold them
                 // (<= 128 fp32 terms per channel), then continue in fp64 in this wave's LDS slots
 #pragma unroll
@@ -369,11 +383,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
             }
         }
     };
-    auto epilogue_group = [&](int g0) {
+    auto epilogue_group = [&](int g0, const Tile (&tl)[G]) {
         float* s_ep = reinterpret_cast<float*>(smem + wave * C::EPI_WAVE_BYTES);
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (g0 + g < my_tiles && !(d.diag & 4)) epilogue(tile_of(g0 + g), acc[g], s_ep);
+            if (g0 + g < my_tiles && !(d.diag & 4)) {
+                if (vec_out) epilogue(tl[g], acc[g], s_ep, std::true_type{});
+                else if constexpr (OM == 0) epilogue(tl[g], acc[g], s_ep, std::false_type{});
+            }
     };
 
     const unsigned char* const sA = smem;
@@ -389,13 +406,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
 #endif
     for (int g0 = 0; g0 < my_tiles; g0 += G) {
         const int gcount = my_tiles - g0 < G ? my_tiles - g0 : G;
+        Tile tl[G];                                  // (the three scalar divisions of tile_of: once per tile, not per chunk)
+#pragma unroll
+        for (int g = 0; g < G; ++g) tl[g] = tile_of(g0 + (g < gcount ? g : 0));
         for (int kc = 0; kc < d.nkc; ++kc) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (g < gcount) {
                     RFI_T(t0);
                     if (!(d.diag & 2) || (g0 == 0 && kc == 0 && g == 0)) {
-                        issue_A(g0 + g, kc);
+                        issue_A(tl[g], kc);
                         if (g == 0) issue_B(kc);     // the filter tile of the chunk serves every tile of the group
                     }
                     RFI_T(t1);
@@ -446,7 +466,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
             }
         }
         RFI_T(te0);
-        epilogue_group(g0);
+        epilogue_group(g0, tl);
         // the staging area (aliased by the scratch) is about to be overwritten: every wave must be done with its
         // scratch READS (lgkmcnt), but nobody has to wait for the output stores to retire (a __syncthreads() would
         // add s_waitcnt vmcnt(0): one exposed HBM write latency per group)
@@ -481,10 +501,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     }
 }
 
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1, bool BWD = false>
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1, bool BWD = false, int OM = -1>
 void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
-    if constexpr (!BWD && P == 1)                     // the BatchNorm-backward epilogue: its own instantiation (bf16 flow only)
-        if (d.a.bwd_y16) return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, true>(ctx, d);
+    if constexpr (OM < 0) {                           // pick the epilogue variant of this launch
+        const int om = d.a.y16 ? 2 : d.a.round_y ? 1 : 0;
+        const bool b = d.a.bwd_y16 != nullptr;
+        if constexpr (P == 1) {
+            RFI_REQUIRE(!(b && om == 1), "pconv: the BatchNorm-backward epilogue writes float32 or bfloat16 tensors");
+            if (om == 2) return b ? launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, true, 2>(ctx, d)
+                                  : launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, false, 2>(ctx, d);
+            if (om == 1) return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, false, 1>(ctx, d);
+            return b ? launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, true, 0>(ctx, d)
+                     : launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, false, 0>(ctx, d);
+        } else {
+            RFI_REQUIRE(om == 0 && !b, "pconv: bfloat16 outputs and the BatchNorm-backward epilogue exist for the bfloat16 flow only");
+            return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, false, 0>(ctx, d);
+        }
+    } else {
     using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>;
     PConvArgs& a = d.a;
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
@@ -510,7 +543,7 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
                 "pconv: BatchNorm-backward sums need a dense output grid and an aligned bfloat16 Y");
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
 #ifdef RFI_DIAG_STAMPS
@@ -518,7 +551,7 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
         const size_t nw = (size_t)GX * ychunks * C::NW;
         RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d.stamps), nw * 64));
         RFI_CHECK_HIP(hipMemsetAsync(d.stamps, 0, nw * 64, ctx->stream));
-        hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+        hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
         std::vector<unsigned long long> hs(nw * 8);
         RFI_CHECK_HIP(hipMemcpyAsync(hs.data(), d.stamps, nw * 64, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -532,8 +565,9 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
         return;
     }
 #endif
-    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
     check_launch("pconv");
+    }
 }
 
 // Tile choice by output width.  Measured and NOT kept (round 2, gpurun_out/r2k-r2m): groups of 4 tiles, 64-channel
