@@ -619,7 +619,7 @@ void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
                 std::to_string(d.nkc * 16) + "->" + std::to_string(a.Cout) + (a.P == 3 ? " 3xbf16" : " bf16");
     // algorithmic HBM bytes: the plane input (2 P bytes per value), the float32 output, the filters
     const double bytes = (double)a.N * a.Hin * a.Win * d.nkc * 16.0 * 2 * a.P + (a.y16 ? 2.0 : 4.0) * a.N * a.H * a.W * a.Cout +
-                         (double)wbytes;
+                         (a.bwd_y16 ? 2.0 * a.N * a.H * a.W * a.Cout : 0.0) + (double)wbytes;     // (+ the bf16 Y of the BatchNorm-backward epilogue)
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, bytes, label);
     if (a.P == 3) dispatch<3>(ctx, d);
     else dispatch<1>(ctx, d);
