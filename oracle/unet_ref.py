@@ -250,8 +250,9 @@ class bf16_operands:
     ``round_grads`` (default: as ``round_outputs``; needs widths that are multiples of 16, as the library does): the
     input gradients of the 3x3 convs that feed a BatchNorm backward or the max-pool backward -- every second conv of
     a DoubleConv, and the first conv of the bottleneck and of encoders 2.. -- are rounded to bfloat16 as well (under
-    torch.autocast they ARE bf16 tensors; the library stores them as bf16).  The decoder's first conv, whose input
-    gradient feeds the transposed conv and the skip, keeps float32."""
+    torch.autocast they ARE bf16 tensors; the library stores them as bf16), and so are the gradients that reach a
+    DoubleConv's output from the max-pool backward + skip (encoders) and from a one-channel 1x1 head.  The decoder's
+    first conv, whose input gradient feeds the transposed conv and the skip, keeps float32."""
 
     def __init__(self, round_outputs=False, round_grads=None):
         self.round_outputs = bool(round_outputs)
@@ -304,6 +305,8 @@ def forward(state, x_nchw, training=False, buffer_updates=None, tape=None, negat
     ns = negative_slope
     for lvl in range(1, depth + 1):
         a = _double_conv(h, state, f"encoder{lvl}.conv.conv", training, 2, buffer_updates, tape, ns)
+        if _BF16_OPERANDS and _BF16_ROUND_GRADS and _WIDTHS_16 and a.requires_grad:
+            a.register_hook(_bf)          # the merged gradient (max-pool backward + skip) is stored as bfloat16
         skips.append(a)
         h = F.max_pool2d(a, kernel_size=2, stride=2)
     h = _double_conv(h, state, "bottleneck.conv", training, 1, buffer_updates, tape, ns)
@@ -313,6 +316,8 @@ def forward(state, x_nchw, training=False, buffer_updates=None, tape=None, negat
             tape[f"decoder{lvl}.up.out"] = up
         h = torch.cat([up, skips[lvl - 1]], dim=1)
         h = _double_conv(h, state, f"decoder{lvl}.conv.conv", training, 1, buffer_updates, tape, ns)
+    if _BF16_OPERANDS and _BF16_ROUND_GRADS and _WIDTHS_16 and h.requires_grad and state["final_conv.weight"].shape[0] == 1:
+        h.register_hook(_bf)              # ... and the gradient the 1x1 head sends into the last DoubleConv
     out = F.conv2d(h, state["final_conv.weight"], state["final_conv.bias"])
     return torch.sigmoid(out) if head_sigmoid else out
 

@@ -978,7 +978,7 @@ int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t h
         RFI_REQUIRE(!(m->y16_flow && m->planesP == 1 && (base == "encY1" || base == "encY2" || base == "decY1" || base == "bottY1" ||
                                                         (base == "decY2" && idx == 1))),
                     "debug_tensor: this conv output is stored as bfloat16 in the bfloat16 compute mode");
-        RFI_REQUIRE(!(m->g16_flow && m->planesP == 1 && (base == "gB" || base == "dpool" || base == "gBottB")),
+        RFI_REQUIRE(!(m->g16_flow && m->planesP == 1 && (base == "gB" || base == "dpool" || base == "gBottB" || base == "gA")),
                     "debug_tensor: this gradient tensor is stored as bfloat16 in the bfloat16 compute mode");
         auto level = [&](const std::vector<int>& v, size_t chmul) {
             RFI_REQUIRE(idx >= 1 && idx <= D, "debug_tensor: level out of range");

@@ -102,6 +102,17 @@ __device__ __forceinline__ float ldy1(const void* y, int y16, int64_t idx) {
     ldy<1>(y, y16, idx, v);
     return v[0];
 }
+// four values -> bfloat16 (RNE; NaN stays NaN), stored as 8 bytes; v is left holding the rounded values
+__device__ __forceinline__ void round_store_bf16x4(unsigned short* p, float (&v)[4]) {
+    unsigned short q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        q[e] = __builtin_bit_cast(unsigned short, h);
+        v[e] = (float)h;
+    }
+    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16));
+}
 // block-level sum over the RL row lanes of NQ per-lane quantities of V channels each;
 // lane rl == 0 ends up with the totals in acc.  red: NQ * V * 256 doubles of LDS.
 template <int V, int NQ>
@@ -481,7 +492,8 @@ __global__ __launch_bounds__(256) void pool_bwd_merge_vec_kernel(
     const void* __restrict__ y, int y16, int64_t yps, int N, int H, int W, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ dskip, int dskip_ps, const void* __restrict__ dpool, int dp16, float* __restrict__ da, float slope,
-    double* __restrict__ records) {
+    double* __restrict__ records, unsigned short* __restrict__ da16) {
+    // da16 != null: the merged gradient is stored as bfloat16 there (da unused) and the sums are those of the stored values
     __shared__ double red[SUMS ? 8 * kBlock : 1];
     const int Hp = H >> 1, Wp = W >> 1, C4 = C >> 2;
     const int64_t total = (int64_t)N * Hp * Wp * C4;
@@ -521,16 +533,18 @@ __global__ __launch_bounds__(256) void pool_bwd_merge_vec_kernel(
             float d[4];
             ldv<4>(dskip + pixk[k] * dskip_ps + c, d);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                d[v] += (k == arg[v] ? g[v] : 0.0f);
-                if (SUMS) {
+            for (int v = 0; v < 4; ++v) d[v] += (k == arg[v] ? g[v] : 0.0f);
+            if (da16) round_store_bf16x4(da16 + pixk[k] * C + c, d);
+            else stv<4>(da + pixk[k] * C + c, d);
+            if (SUMS) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
                     const float dz = dact_f(zv[k][v], d[v], slope);
                     const float xh = (yv[k][v] - mu[v]) * is[v];
                     s1[v] += (double)dz;
                     s2[v] += (double)dz * (double)xh;
                 }
             }
-            stv<4>(da + pixk[k] * C + c, d);
         }
     }
     if constexpr (SUMS) {
@@ -836,7 +850,8 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const void* __restric
                                                            const float* __restrict__ dl, float* __restrict__ da,
                                                            double* __restrict__ partial, float slope,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           double* __restrict__ bn_records) {
+                                                           double* __restrict__ bn_records, unsigned short* __restrict__ da16) {
+    // da16 != null (Cout == 1): da is stored as bfloat16 there and the BatchNorm-backward sums are those of the stored values
     // bn_records != null (Cout == 1): also the BatchNorm-backward sums of the layer below (sum dz, sum dz * xhat with
     // dz = da * act'), one fp64 record per row block -- bn_bwd_reduce's pass over da and y disappears
     __shared__ double red[4 * kBlock];
@@ -865,15 +880,19 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const void* __restric
                     const float a = act_f(z, slope);
                     sw[v] += (double)d * (double)a;
                     g[v] = o == 0 ? d * wv[v] : g[v] + d * wv[v];
-                    if (bn_records) {
-                        const float dz = dact_f(z, g[v], slope);
+                }
+                if (da16) round_store_bf16x4(da16 + r * C + c, g);
+                else stv<4>(da + r * C + c, g);
+                if (bn_records) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float dz = dact_f(yv[v] * sc[v] + sh[v], g[v], slope);
                         const float xh = (yv[v] - mu[v]) * is[v];
                         q1[v] += (double)dz;
                         q2[v] += (double)dz * (double)xh;
                     }
                 }
                 sb += (double)d;
-                stv<4>(da + r * C + c, g);
             }
         }
 #pragma unroll
@@ -1272,8 +1291,9 @@ static bool pool_vec_ok(YRef y, int C, const float* scale, const float* shift, V
 }
 int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C, const float* scale,
                                const float* shift, const float* mean, const float* invstd, View dskip, YRef dpool,
-                               float* da, float slope, float* partial_ws) {
-    if (!pool_vec_ok(y, C, scale, shift, dskip, dpool, da) || dpool.stride(C) != C ||
+                               float* da, float slope, float* partial_ws, unsigned short* da16) {
+    if (!pool_vec_ok(y, C, scale, shift, dskip, dpool, da16 ? reinterpret_cast<const float*>(da16) : da) || dpool.stride(C) != C ||
+        (reinterpret_cast<uintptr_t>(da16) & 7) ||
         ((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(invstd)) & 15))
         return 0;
     const int C4 = C / 4;
@@ -1290,22 +1310,24 @@ int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
     if ((int64_t)grid * kBlock > total) return 0;   // (every thread must own at least one element)
     ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * (dpool.bf16 ? 8 : 16));
     hipLaunchKernelGGL(pool_bwd_merge_vec_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, y.p, y.bf16, y.stride(C), N, H, W,
-                       C, scale, shift, mean, invstd, dskip.p, dskip.pstride, dpool.p, dpool.bf16, da, slope, reinterpret_cast<double*>(partial_ws));
+                       C, scale, shift, mean, invstd, dskip.p, dskip.pstride, dpool.p, dpool.bf16, da, slope, reinterpret_cast<double*>(partial_ws), da16);
     check_launch("pool_bwd_merge_sums");
     return records;
 }
 
 void launch_pool_bwd_merge(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
                            const float* scale, const float* shift, View dskip, YRef dpool,
-                           float* da, float slope) {
-    const bool vec = pool_vec_ok(y, C, scale, shift, dskip, dpool, da) && dpool.stride(C) == C;
-    RFI_REQUIRE(vec || !dpool.bf16, "pool_bwd_merge: a bfloat16 pooled gradient needs C % 4 == 0 and aligned tensors");
+                           float* da, float slope, unsigned short* da16) {
+    const bool vec = pool_vec_ok(y, C, scale, shift, dskip, dpool, da16 ? reinterpret_cast<const float*>(da16) : da) && dpool.stride(C) == C &&
+                     !(reinterpret_cast<uintptr_t>(da16) & 7);
+    RFI_REQUIRE(vec || !(dpool.bf16 || da16), "pool_bwd_merge: bfloat16 gradient tensors need C % 4 == 0 and aligned tensors");
+    RFI_REQUIRE(!da16 || !((H & 1) || (W & 1)), "pool_bwd_merge: a bfloat16 output needs even H and W");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
     {
         ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * (dpool.bf16 ? 2 : 4));
         if (vec)
             hipLaunchKernelGGL(pool_bwd_merge_vec_kernel<false>, dim3(grid_for(total / 4)), dim3(kBlock), 0, ctx->stream, y.p, y.bf16,
-                               y.stride(C), N, H, W, C, scale, shift, nullptr, nullptr, dskip.p, dskip.pstride, dpool.p, dpool.bf16, da, slope, nullptr);
+                               y.stride(C), N, H, W, C, scale, shift, nullptr, nullptr, dskip.p, dskip.pstride, dpool.p, dpool.bf16, da, slope, nullptr, da16);
         else
             hipLaunchKernelGGL(pool_bwd_merge_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y.p, y.bf16, y.stride(C),
                                N, H, W, C, scale, shift, dskip.p, dskip.pstride, static_cast<const float*>(dpool.p), da, slope);
@@ -1410,12 +1432,13 @@ size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
 int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                     float* partial_ws, float* dw, float* db, float slope, const float* bn_mean, const float* bn_invstd,
-                    float* bn_records_ws) {
+                    float* bn_records_ws, unsigned short* da16) {
     int bn_records = 0;
     const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(yr.p) | reinterpret_cast<uintptr_t>(da) |
                                       reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
                                       reinterpret_cast<uintptr_t>(w)) & 15) && yr.stride(C) % 4 == 0;
     RFI_REQUIRE(vec || !yr.bf16, "head_bwd: a bfloat16 input needs C % 4 == 0");
+    RFI_REQUIRE(!da16 || (vec && Cout == 1 && !(reinterpret_cast<uintptr_t>(da16) & 7)), "head_bwd: a bfloat16 gradient tensor needs C % 4 == 0 and one output channel");
     const float* y = static_cast<const float*>(yr.p);
     ChanGeom g = geom_rows(M, C, vec);     // scalar kernel: one channel per lane; vector kernel: four
     {
@@ -1426,7 +1449,7 @@ int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
             hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, yr.p, yr.bf16,
                                yr.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
                                reinterpret_cast<double*>(partial_ws), slope, bn_mean, bn_invstd,
-                               sums ? reinterpret_cast<double*>(bn_records_ws) : nullptr);
+                               sums ? reinterpret_cast<double*>(bn_records_ws) : nullptr, da16);
             if (sums) bn_records = g.rblocks;
         }
         else

@@ -178,13 +178,15 @@ void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int 
 // da[n,y,x,c] = dskip[n,y,x,c] + (argmax of the 2x2 window of a == (y,x) ? dpool : 0)
 void launch_pool_bwd_merge(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
                            const float* scale, const float* shift, View dskip, YRef dpool,
-                           float* da, float slope = 0.0f);
+                           float* da, float slope = 0.0f, unsigned short* da16 = nullptr);
+// da16 != null (bf16 data flow; C % 4 == 0): the merged gradient is stored as a dense bfloat16 [pixel][C] tensor there
+// instead of da, and the sums of launch_pool_bwd_merge_sums are those of the stored values (the same for launch_head_bwd)
 // the same pass, also writing the BatchNorm-backward sums of that layer (sum dz, sum dz * xhat) as fp64 records into
 // partial_ws (bn_bwd_ws_floats) for launch_bn_bwd_finalize_records; returns the record count, or 0 when the shape does
 // not fit the scheme (nothing launched: call launch_pool_bwd_merge and the separate reduction instead)
 int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C, const float* scale,
                                const float* shift, const float* mean, const float* invstd, View dskip, YRef dpool,
-                               float* da, float slope, float* partial_ws);
+                               float* da, float slope, float* partial_ws, unsigned short* da16 = nullptr);
 // logits[m,o] = b[o] + sum_c relu(y*scale+shift)[m,c] * w[o][c]
 void launch_head_fwd(rfi_ctx* ctx, YRef y, int64_t M, int C, const float* scale,
                      const float* shift, const float* w, const float* b, int Cout, float* logits,
@@ -212,7 +214,7 @@ void launch_focal_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, 
 int launch_head_bwd(rfi_ctx* ctx, YRef y, int64_t M, int C, const float* scale,
                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                     float* partial_ws, float* dw, float* db, float slope = 0.0f, const float* bn_mean = nullptr,
-                    const float* bn_invstd = nullptr, float* bn_records_ws = nullptr);
+                    const float* bn_invstd = nullptr, float* bn_records_ws = nullptr, unsigned short* da16 = nullptr);
 size_t head_bwd_ws_floats(int64_t M, int C, int Cout);
 // per-channel sum over pixels of a view (convT bias grad)
 void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out);

@@ -221,7 +221,7 @@ struct rfi_model {
     // bf16 data flow: the gradient tensors the input-gradient convs write (dA of every first conv, the pooled gradients) are
     // bfloat16 too -- as torch.autocast's are -- when the level widths are multiples of 16
     bool g16_flow = false;
-    std::vector<int> g16B, g16pool;
+    std::vector<int> g16A, g16B, g16pool;       // g16A: dA of the second convs where an elementwise kernel produces it (head, max-pool backward)
     int g16BottB = -1;
     rfi::bf16_t* wb_pool = nullptr;
     void* wb_descs = nullptr;

@@ -85,11 +85,12 @@ void rfi_model::prepare_planes(int n, int h, int w) {
     if (g16_flow) {
         if (g16BottB < 0) {
             auto mk1 = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) { pl.emplace_back(); v[l] = (int)pl.size() - 1; } };
-            mk1(g16B); mk1(g16pool);
+            mk1(g16A); mk1(g16B); mk1(g16pool);
             pl.emplace_back(); g16BottB = (int)pl.size() - 1;
         }
         for (int l = 1; l <= D; ++l) {
             const int64_t M = (int64_t)n * (h >> (l - 1)) * (w >> (l - 1));
+            pl[g16A[l]].ensure(ctx, M, feat << (l - 1), 1);
             pl[g16B[l]].ensure(ctx, M, feat << (l - 1), 1);
             pl[g16pool[l]].ensure(ctx, M / 4, feat << (l - 1), 1);
         }
@@ -401,7 +402,8 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& last = convs[2 * D + 2 + 2 * (D - 1) + 1];
         head_records = launch_head_bwd(ctx, yr(decY2[1], y16_flow ? yD2top : -1), M1, feat, last.scale(), last.shift(), params + head_w_off, out_ch,
                                        buf(dlogits), buf(gA[1]), buf(ws_red) + bn_bwd_ws_floats(M1, feat), grads + head_w_off,
-                                       grads + head_b_off, act_slope, last.mean(), last.invstd(), buf(ws_red));
+                                       grads + head_b_off, act_slope, last.mean(), last.invstd(), buf(ws_red),
+                                       g16_flow && out_ch == 1 ? pl[g16A[1]].p : nullptr);
     }
     for (int l = 1; l <= D; ++l) {                // decoders, shallow to deep
         const int k = D - l;
@@ -411,7 +413,8 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         const PlaneSeg a1 = seg_of(pl[pA1d[l]]);
-        const int rec1 = backward_pconv_bn(this, c2, buf(gA[l]), yr(decY2[l], y16_flow && l == 1 ? yD2top : -1), &a1, 1, s,
+        const int rec1 = backward_pconv_bn(this, c2, gt(gA[l], g16_flow && out_ch == 1 && l == 1 ? g16A[1] : -1).ref(),
+                                           yr(decY2[l], y16_flow && l == 1 ? yD2top : -1), &a1, 1, s,
                                            gt(gB[l], g16_flow ? g16B[l] : -1), pl[pdYa[l]], l == 1 ? head_records : 0, &c1,
                                            yr(decY1[l], y16_flow ? yD1[l] : -1));
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};
@@ -471,12 +474,13 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& c2 = convs[2 * (l - 1) + 1];
         const int have = launch_pool_bwd_merge_sums(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), c2.mean(),
                                                     c2.invstd(), View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(),
-                                                    buf(gA[l]), act_slope, buf(ws_red));
+                                                    buf(gA[l]), act_slope, buf(ws_red), g16_flow ? pl[g16A[l]].p : nullptr);
         if (!have)
             launch_pool_bwd_merge(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
-                                  View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(), buf(gA[l]), act_slope);
+                                  View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(), buf(gA[l]), act_slope,
+                                  g16_flow ? pl[g16A[l]].p : nullptr);
         const PlaneSeg a1 = seg_of(pl[pA1e[l]]);
-        const int rec1 = backward_pconv_bn(this, c2, buf(gA[l]), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, gt(gB[l], g16_flow ? g16B[l] : -1),
+        const int rec1 = backward_pconv_bn(this, c2, gt(gA[l], g16_flow ? g16A[l] : -1).ref(), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, gt(gB[l], g16_flow ? g16B[l] : -1),
                                            pl[pdYaE[l]], have, &c1, yr(encY1[l], y16_flow ? yE1[l] : -1));
         const PlaneSeg in = seg_of(l == 1 ? pl[pXin] : pl[pPool[l - 1]]);
         backward_pconv_bn(this, c1, gt(gB[l], g16_flow ? g16B[l] : -1).ref(), yr(encY1[l], y16_flow ? yE1[l] : -1), &in, 1, s,
