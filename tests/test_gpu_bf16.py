@@ -129,11 +129,13 @@ def test_bf16_inference_iou_at_1024_on_reference_weights(golden_dir):
 
 
 @pytest.mark.parametrize("cls,f,n,h,w", [("UNetBigger", 8, 2, 64, 64), ("UNet", 12, 2, 48, 80), ("UNet", 6, 1, 32, 32),
-                                         ("UNet", 16, 3, 16, 16)])
+                                         ("UNet", 16, 3, 16, 16), ("UNet", 16, 2, 48, 80)])
 def test_bf16_data_flow_other_shapes(cls, f, n, h, w):
     """The bf16 data flow away from the benched shape: depth 5 (1024 channels at the bottleneck), channel counts
     that are not powers of two (partial 16-channel chunks, the scalar fallbacks of the fused reductions), a width
-    that is not a multiple of 4 (conv outputs stay float32 there: the oracle then rounds operands only), tiny maps."""
+    that is not a multiple of 4 (conv outputs stay float32 there: the oracle then rounds operands only), tiny maps, and
+    widths of 16 (bfloat16 gradient tensors, BatchNorm-backward sums in the conv epilogue) on maps that end in partial
+    tiles."""
     from rfi_toolbox_amd.models import UNetBigger
     depth = 5 if cls == "UNetBigger" else 4
     st = unet_ref.init_state(3, 1, f, depth=depth, seed=7)
@@ -150,8 +152,13 @@ def test_bf16_data_flow_other_shapes(cls, f, n, h, w):
     want = lgb.permute(0, 2, 3, 1).reshape(-1).numpy()
     w32 = lg32.permute(0, 2, 3, 1).reshape(-1).numpy()
     span = float(np.abs(want).max())
-    d_same, d_arith = np.abs(m.debug_tensor("logits") - want).max(), np.abs(w32 - want).max()
-    assert d_same <= max(0.6 * d_arith, 5e-3 * span), (d_same, d_arith, span)
+    e_same, e_arith = np.abs(m.debug_tensor("logits") - want), np.abs(w32 - want)
+    d_same, d_arith = e_same.max(), e_arith.max()
+    # closer to the oracle in the SAME arithmetic than that oracle is to float32: the typical logit by a factor 0.6, the
+    # worst one by 0.75 (a single bf16 rounding flip of a conv output moves a logit by about half of d_arith; measured
+    # max 0.38-0.61 of d_arith over seeds at 48 x 80, median 0.33-0.49)
+    assert d_same <= max(0.75 * d_arith, 5e-3 * span), (d_same, d_arith, span)
+    assert np.median(e_same) <= max(0.6 * np.median(e_arith), 1e-3 * span), (np.median(e_same), np.median(e_arith))
     rels = []
     for k, gk in gb.items():
         if k.endswith((".0.bias", ".3.bias")) and "conv" in k:
