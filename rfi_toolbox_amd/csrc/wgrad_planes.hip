@@ -127,6 +127,12 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
 
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntiles = a.N * tiles_y * tiles_x;
+    // per-segment operand constants in registers: indexing the kernel argument by the (per-lane) segment number made
+    // every Xop DMA wait for a vector load of its own base / stride / zero offset -- and with it for every DMA in flight
+    const unsigned char* const xbase0 = reinterpret_cast<const unsigned char*>(a.xop[0].p);
+    const unsigned char* const xbase1 = reinterpret_cast<const unsigned char*>(a.xop[1].p);
+    const unsigned xps0 = (unsigned)a.xop[0].pstride * 2u, xps1 = (unsigned)a.xop[1].pstride * 2u;
+    const unsigned xz0 = d.x_zero[0], xz1 = d.x_zero[1];
     auto issue_tile = [&](int tile) {
         const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int oy0 = ty_i * TH, ox0 = tx_i * TW;
@@ -142,12 +148,12 @@ __global__ __launch_bounds__(256, 2) void pwgrad_kernel(PWgradDev d) {
         }
 #pragma unroll
         for (int it = 0; it < C::X_ITEMS; ++it) {
-            const int seg = (x_seg >> it) & 1;
-            const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.xop[seg].p);
-            const unsigned xps = (unsigned)a.xop[seg].pstride * 2u;
+            const bool seg = (x_seg >> it) & 1;
+            const unsigned char* xb = seg ? xbase1 : xbase0;
+            const unsigned xps = seg ? xps1 : xps0;
             const int iy = iy0 + (int)(x_d[it] >> 20), ix = ix0 + (int)((x_d[it] >> 8) & 0xfff);
             const bool ok = x_d[it] != 0xffffffffu && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
-            const unsigned off = ok ? (unsigned)((n * a.Hx + iy) * a.Wx + ix) * xps + (x_d[it] & 0xff) * 16u : d.x_zero[seg];
+            const unsigned off = ok ? (unsigned)((n * a.Hx + iy) * a.Wx + ix) * xps + (x_d[it] & 0xff) * 16u : (seg ? xz1 : xz0);
             __builtin_amdgcn_global_load_lds((gbl_void*)(xb + off), (lds_void*)(sX + (it * C::NT + wave * 64) * 16), 16, 0, 0);
         }
     };
