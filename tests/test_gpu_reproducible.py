@@ -21,3 +21,9 @@ def test_backward_is_bitwise_reproducible(mode, reps):
 def test_bitwise_reproducible_with_bucketed_exchange():
     from race_probe import probe
     assert not probe("bfloat16", 200, emulate=2)
+
+
+def test_bitwise_reproducible_at_the_benched_shape():
+    """UNet(3,1,32) on 64 x 128 x 128: the kernel configurations and the co-residency of bench.py's step."""
+    from race_probe import probe
+    assert not probe("bfloat16", 40, features=32, batch=64, size=128)
