@@ -992,8 +992,8 @@ int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t h
         else if (base == "encY2") level(m->encY2, 1);
         else if (base == "decY1") level(m->decY1, 1);
         else if (base == "decY2") level(m->decY2, 1);
-        else if (base == "gA") level(m->gA, 1);
-        else if (base == "gB") level(m->gB, 1);
+        else if (base == "gA") level(!m->planesP && m->arch == 0 ? m->gAe : m->gA, 1);     // (as left by the encoder phase)
+        else if (base == "gB") level(!m->planesP && m->arch == 0 ? m->gBe : m->gB, 1);
         else if (base == "concat") level(m->concat, 2);
         else if (base == "dconcat") level(m->dconcat, 2);
         else if (base == "pool") { level(m->pool, 1); n /= 4; }

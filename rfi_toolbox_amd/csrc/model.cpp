@@ -259,7 +259,7 @@ void rfi_model::prepare(int n, int h, int w) {
     if (bufs.empty()) {
         auto mk = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) v[l] = new_buf(); };
         mk(encY1); mk(encY2); mk(concat); mk(pool); mk(decY1); mk(decY2);
-        mk(gA); mk(gB); mk(dconcat); mk(dpool);
+        mk(gA); mk(gB); mk(dconcat); mk(dpool); mk(gAe); mk(gBe);
         bottY1 = new_buf(); bottY2 = new_buf(); gBottA = new_buf(); gBottB = new_buf();
         logits = new_buf(); dlogits = new_buf(); probs = new_buf();
         x_stage = new_buf(); x_stage2 = new_buf(); x_pad = new_buf(); out_stage = new_buf();
@@ -271,6 +271,7 @@ void rfi_model::prepare(int n, int h, int w) {
         const size_t M = (size_t)n * (h >> (l - 1)) * (w >> (l - 1));
         const size_t C = (size_t)feat << (l - 1);
         for (int i : {decY1[l], decY2[l], gA[l], gB[l]}) bufs[i].ensure(ctx, M * C);
+        if (!planesP && arch == 0) for (int i : {gAe[l], gBe[l]}) bufs[i].ensure(ctx, M * C);   // (the encoder phase's own gradient tensors)
         if (arch != 2) for (int i : {encY1[l], encY2[l]}) bufs[i].ensure(ctx, M * C);     // (arch 2: its own tensors, prepare_resnet)
         bufs[concat[l]].ensure(ctx, M * 2 * C);
         bufs[dconcat[l]].ensure(ctx, M * 2 * C);
@@ -613,7 +614,7 @@ namespace {
 struct SideScope {
     rfi_model* m;
     bool ended = false;
-    explicit SideScope(rfi_model* model) : m(model) { m->side_begin(); }
+    explicit SideScope(rfi_model* model, hipEvent_t after = nullptr) : m(model) { m->side_begin_after(after); }
     void end() { m->side_end(); ended = true; }
     ~SideScope() { if (!ended) m->ctx->stream = m->ctx->main_stream; }
 };
@@ -634,8 +635,9 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
     else
         launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(),
                              c.c2(), m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
+    const hipEvent_t dy_done = m->next_fork_event();         // completes with the kernel that writes dY (over dA)
     launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
-                        m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope);
+                        m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope, nullptr, 0, 0, dy_done);
     WgradArgs wa;
     wa.xop = in;
     wa.yop = View{dA, c.cout};
@@ -652,7 +654,7 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
     wa.bf16 = m->compute_bf16;
     wa.bf16x3 = m->compute_x3;
     {
-        SideScope side(m);
+        SideScope side(m, dy_done);
         launch_wgrad(ctx, wa);
         side.end();
     }
@@ -711,6 +713,8 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     const int64_t M1 = (int64_t)n * h * w;
     refresh_dgrad_weights();
     if (planesP) return backward_planes(x_dev, labels_dev, n, h, w);
+    static const int bound_env = getenv("RFI_SIDE_BOUND") ? atoi(getenv("RFI_SIDE_BOUND")) : 0;
+    side_bound = arch == 0 ? bound_env : 2;       // (the ResNet-style encoder double-buffers by block parity: bound 2)
     // loss -> dlogits -> head
     if (loss_kind == 1)
         launch_focal_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, focal_alpha, focal_gamma, buf(dlogits));
@@ -807,11 +811,14 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         side_join();
         return;
     }
-    // encoders, deep to shallow
+    // encoders, deep to shallow.  They write their own gradient tensors (not the decoder's of the same level), so nothing
+    // the weight-gradient kernels read is rewritten before side_join(): no run-ahead bound (RFI_SIDE_BOUND restores one)
     for (int l = D; l >= 1; --l) {
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
+        const std::vector<int>& gA = this->gAe;
+        const std::vector<int>& gB = this->gBe;
         // max-pool routing + skip gradient, with the BatchNorm-backward sums of c2 from the same pass where the
         // shape allows (else the separate reduction inside backward_conv_bn)
         int have = launch_pool_bwd_merge_sums(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), c2.mean(),
@@ -829,6 +836,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         bucket_ready(c1.w_off, convs[l == D ? IB : 2 * l].w_off);       // convs[2 l] = first conv of the next level / the bottleneck
     }
     side_join();
+    side_bound = 2;
 }
 
 // ------------------------------------------------------------------------------------ optimiser

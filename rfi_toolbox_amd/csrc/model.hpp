@@ -132,6 +132,7 @@ struct rfi_model {
     std::vector<rfi::DevBuf> bufs;
     // indices into bufs
     std::vector<int> encY1, encY2, concat, pool, decY1, decY2, gA, gB, dconcat, dpool;
+    std::vector<int> gAe, gBe;        // float32 U-Net path: the encoder phase's gradient tensors (gA / gB are the decoder's)
     int bottY1 = -1, bottY2 = -1, gBottA = -1, gBottB = -1, logits = -1, dlogits = -1;
     int x_stage = -1, x_stage2 = -1, x_pad = -1, out_stage = -1, ws_red = -1, ws_slab = -1, lab_stage = -1;
     double* d_sums = nullptr;         // [0..3] loss sums, [4] grad sumsq
