@@ -18,7 +18,9 @@
 //     order in HBM, planes.hpp) is copied the same way and read back lane-linearly.
 // One workgroup = WM x WN waves, each owning MT x NTL blocks of 32 pixels x 32 channels; workgroups are
 // persistent over an XCD-contiguous range of spatial tiles (neighbouring tiles share halos and filters in one
-// L2).  Staging is single-buffered: two workgroups per CU alternate between their DMA wait and their MFMA phase.
+// L2).  Two workgroups per CU alternate between their DMA wait and their MFMA phase; staging is single-buffered for
+// P = 3 and for the two-chunk layers, double-buffered (the next item's DMA in flight under this item's MFMAs; fragment
+// reads in inline asm, because hipcc drains every outstanding LDS-DMA before a compiler-visible LDS read) elsewhere.
 // The epilogue transposes the accumulators through LDS into 16-byte stores of whole pixel rows, adds the bias and
 // folds the BatchNorm statistics of the output (sum y, sum y^2 per channel; fp64 per workgroup record).
 #include <algorithm>
@@ -70,6 +72,9 @@ struct PCfg {
     static constexpr int STAT_OFF = STAGE_BYTES > NW * EPI_WAVE_BYTES ? STAGE_BYTES : NW * EPI_WAVE_BYTES;
     static constexpr int STAT_DOUBLES = NW * NTL * 32 * 2;  // [wave][n-tile][channel][sum, sumsq]
     static constexpr int LDS_BYTES = STAT_OFF + STAT_DOUBLES * 8;
+    // double-buffered staging (DB kernels): [A0 | A1 | B0 | B1 | stats]
+    static constexpr int STAT_OFF_DB = 2 * STAGE_BYTES > NW * EPI_WAVE_BYTES ? 2 * STAGE_BYTES : NW * EPI_WAVE_BYTES;
+    static constexpr int LDS_BYTES_DB = STAT_OFF_DB + STAT_DOUBLES * 8;
     static_assert(BM == WM * MT * 32, "tile pixels must equal the waves' m-tiles");
     static_assert(32 % TW == 0 || TW % 32 == 0, "TW must divide or be a multiple of 32");
     static_assert(HW < 4096 && HH < 4096, "halo coordinates are packed in 12 bits");
@@ -95,7 +100,10 @@ __device__ __forceinline__ f32x16 mma(const bf16x8 (&a)[P], const bf16x8 (&b)[P]
 // OM: what the output tensor holds -- 0 float32, 1 float32 holding bf16-rounded values (round_y), 2 bfloat16 (y16).
 // BWD / OM are template parameters: the epilogue is instruction-issue bound on the shallow layers (a runtime switch for
 // BWD alone cost every launch 3 %).
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD, bool BWD, int OM>
+// DB: two staging buffers per operand -- the DMA of the next (tile, chunk) item is in flight while this one is
+// multiplied.  Fragment reads are inline asm there: hipcc puts s_waitcnt vmcnt(0) in front of every compiler-visible LDS
+// read while an LDS-DMA is outstanding, which would drain the prefetch.
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD, bool BWD, int OM, bool DB>
 __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     using C = PCfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD>;
     const PConvArgs& a = d.a;
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
         if (st_out && tid < C::BN && n0 + tid < a.Cout) st_out[tid * 2] = st_out[tid * 2 + 1] = 0.0;
         return;
     }
-    double* const s_stat = reinterpret_cast<double*>(smem + C::STAT_OFF);
+    double* const s_stat = reinterpret_cast<double*>(smem + (DB ? C::STAT_OFF_DB : C::STAT_OFF));
     if (st_out)
         for (int i = tid; i < C::STAT_DOUBLES; i += C::NT) s_stat[i] = 0.0;   // visible after the first barrier below
 
@@ -162,14 +170,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
         r.n = t / (tiles_x * tiles_y);
         return r;
     };
-    auto issue_A = [&](const Tile& t, int kc) {      // halo tile of chunk kc of one of this workgroup's tiles
+    auto issue_A = [&](const Tile& t, int kc, int abuf = 0) {      // halo tile of chunk kc of one of this workgroup's tiles
         const int seg = kc >= a.x[0].nchunks ? 1 : 0;
         const unsigned coff = (unsigned)(seg ? kc - a.x[0].nchunks : kc) * (P * 32);
         const unsigned ps = (unsigned)a.x[seg].pstride * 2u;
         const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x[seg].p);
         const unsigned xz = d.x_zero[seg];
         const int iy0 = t.oy0 * S - a.pad, ix0 = t.ox0 * S - a.pad, nb = t.n * a.Hin;
-        unsigned char* dst = smem;
+        unsigned char* dst = smem + abuf * C::A_BYTES;
 #pragma unroll
         for (int it = 0; it < C::A_ITEMS; ++it) {
             const int iy = iy0 + (int)(a_rc[it] >> 16), ix = ix0 + (int)(a_rc[it] & 0xfff);
@@ -178,10 +186,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
             __builtin_amdgcn_global_load_lds((gbl_void*)(xb + off), (lds_void*)(dst + (it * C::NT + wave * 64) * 16), 16, 0, 0);
         }
     };
-    auto issue_B = [&](int kc) {
+    auto issue_B = [&](int kc, int bbuf = 0) {
         const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.wB);
         const unsigned koff = (unsigned)kc * wb_chunk;
-        unsigned char* dst = smem + C::A_BYTES;
+        unsigned char* dst = smem + (DB ? 2 * C::A_BYTES + bbuf * C::B_BYTES : C::A_BYTES);
 #pragma unroll
         for (int it = 0; it < C::B_ITEMS; ++it) {
             const unsigned off = b_off[it] != 0xffffffffu ? b_off[it] + koff : d.wb_zero;
@@ -404,6 +412,96 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
 #define RFI_T(v)
 #define RFI_ACC(i, a_, b_)
 #endif
+    if constexpr (DB) {
+        static_assert(P == 1, "double-buffered staging: bf16 flow");
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NRD = MT + NTL;                       // fragment reads per tap
+        const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem);      // (low half of a flat LDS address = LDS offset)
+        unsigned a_addr[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_addr[mt] = lds0 + (unsigned)a_base[mt];
+        const unsigned b_addr = lds0 + 2 * C::A_BYTES + (unsigned)b_base;
+        for (int g0 = 0; g0 < my_tiles; g0 += G) {
+            const int gcount = my_tiles - g0 < G ? my_tiles - g0 : G;
+            Tile tl[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) tl[g] = tile_of(g0 + (g < gcount ? g : 0));
+            issue_A(tl[0], 0, 0);                           // item 0 of the group
+            issue_B(0, 0);
+            int item = 0;
+            for (int kc = 0; kc < d.nkc; ++kc) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (g < gcount) {
+                        const bool last = kc == d.nkc - 1 && g == gcount - 1;
+                        const bool wrap = g + 1 >= gcount;                  // the next item starts a new chunk (needs its filters)
+                        if (!last) {
+                            issue_A(wrap ? tl[0] : tl[G > 1 ? g + 1 < G ? g + 1 : 0 : 0], wrap ? kc + 1 : kc, (item + 1) & 1);
+                            if (wrap) issue_B(kc + 1, (kc + 1) & 1);
+                        }
+                        if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else if (wrap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::A_ITEMS + C::B_ITEMS) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::A_ITEMS) : "memory");
+                        __builtin_amdgcn_s_barrier();                       // every wave's pieces of THIS item have landed
+                        {
+                            const unsigned aoff = (unsigned)(item & 1) * C::A_BYTES, boff = (unsigned)(kc & 1) * C::B_BYTES;
+                            u32x4 afr[2][MT], bfr[2][NTL];
+                            auto load_frags = [&](auto tap_c, u32x4 (&af)[MT], u32x4 (&bf)[NTL]) {
+                                constexpr int tap = decltype(tap_c)::value;
+                                constexpr int tr = tap / R, ts = tap % R;
+#pragma unroll
+                                for (int nt = 0; nt < NTL; ++nt) {
+                                    const unsigned ad = b_addr + boff + (unsigned)(nt * 1024);       // (a named local: asm operands alone do not capture)
+                                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[nt]) : "v"(ad), "n"(tap * C::NCBL * 1024));
+                                }
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) {
+                                    const unsigned ad = a_addr[mt] + aoff;
+                                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt]) : "v"(ad), "n"((tr * C::HW + ts) * C::ROWB));
+                                }
+                            };
+                            auto wait_frags = [&](auto n_c, u32x4 (&af)[MT], u32x4 (&bf)[NTL]) {     // frags usable once <= n newer reads are pending
+                                constexpr int n = decltype(n_c)::value;
+                                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory");
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(af[mt]));
+#pragma unroll
+                                for (int nt = 0; nt < NTL; ++nt) asm volatile("" : "+v"(bf[nt]));
+                            };
+                            auto tap_step = [&](auto tap_c) {
+                                constexpr int tap = decltype(tap_c)::value;
+                                if constexpr (tap + 1 < C::NTAP) {
+                                    load_frags(std::integral_constant<int, tap + 1>{}, afr[(tap + 1) & 1], bfr[(tap + 1) & 1]);
+                                    wait_frags(std::integral_constant<int, NRD>{}, afr[tap & 1], bfr[tap & 1]);
+                                } else {
+                                    wait_frags(std::integral_constant<int, 0>{}, afr[tap & 1], bfr[tap & 1]);
+                                }
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                    for (int nt = 0; nt < NTL; ++nt)
+                                        acc[g][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                            __builtin_bit_cast(bf16x8, afr[tap & 1][mt]), __builtin_bit_cast(bf16x8, bfr[tap & 1][nt]), acc[g][mt][nt], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            };
+                            load_frags(std::integral_constant<int, 0>{}, afr[0], bfr[0]);
+                            static_assert(C::NTAP == 9, "3 x 3 taps");
+                            tap_step(std::integral_constant<int, 0>{}); tap_step(std::integral_constant<int, 1>{});
+                            tap_step(std::integral_constant<int, 2>{}); tap_step(std::integral_constant<int, 3>{});
+                            tap_step(std::integral_constant<int, 4>{}); tap_step(std::integral_constant<int, 5>{});
+                            tap_step(std::integral_constant<int, 6>{}); tap_step(std::integral_constant<int, 7>{});
+                            tap_step(std::integral_constant<int, 8>{});
+                        }
+                        __builtin_amdgcn_s_barrier();       // every wave is done reading this item's buffers (all reads were waited for)
+                        ++item;
+                    }
+                }
+            }
+            epilogue_group(g0, tl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else
     for (int g0 = 0; g0 < my_tiles; g0 += G) {
         const int gcount = my_tiles - g0 < G ? my_tiles - g0 : G;
         Tile tl[G];                                  // (the three scalar divisions of tile_of: once per tile, not per chunk)
@@ -501,8 +599,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     }
 }
 
-template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1, bool BWD = false, int OM = -1>
+template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1, bool BWD = false, int OM = -1, bool DB = false>
 void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
+    if constexpr (OM >= 0 && !DB && P == 1 && R == 3) {      // double-buffered staging from 3 K chunks (bf16 flow; RFI_PCONV_DB=0: off)
+        static const int db = getenv("RFI_PCONV_DB") ? atoi(getenv("RFI_PCONV_DB")) : 3;
+        if (db > 0 && d.nkc >= db) return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM, true>(ctx, d);
+    }
     if constexpr (OM < 0) {                           // pick the epilogue variant of this launch
         const int om = d.a.y16 ? 2 : d.a.round_y ? 1 : 0;
         const bool b = d.a.bwd_y16 != nullptr;
@@ -522,7 +624,7 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
     PConvArgs& a = d.a;
     const int ntiles = a.N * (int)cdiv(a.H, TH) * (int)cdiv(a.W, TW);
     const int ychunks = (int)cdiv(d.ncb, C::NCBL);
-    const size_t lds = C::LDS_BYTES;
+    const size_t lds = DB ? C::LDS_BYTES_DB : C::LDS_BYTES;
     // persistent grid: about (256 CUs x resident workgroups) workgroups in total, a multiple of 8 along x, tiles
     // spread evenly over the workgroups of each XCD label
     int occ = (int)((160 * 1024) / lds);
@@ -543,7 +645,7 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
                 "pconv: BatchNorm-backward sums need a dense output grid and an aligned bfloat16 Y");
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM, DB>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
 #ifdef RFI_DIAG_STAMPS
@@ -551,7 +653,7 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
         const size_t nw = (size_t)GX * ychunks * C::NW;
         RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d.stamps), nw * 64));
         RFI_CHECK_HIP(hipMemsetAsync(d.stamps, 0, nw * 64, ctx->stream));
-        hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+        hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM, DB>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
         std::vector<unsigned long long> hs(nw * 8);
         RFI_CHECK_HIP(hipMemcpyAsync(hs.data(), d.stamps, nw * 64, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -565,7 +667,7 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
         return;
     }
 #endif
-    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
+    hipLaunchKernelGGL((pconv_kernel<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM, DB>), dim3(GX, ychunks), dim3(C::NT), lds, ctx->stream, d);
     check_launch("pconv");
     }
 }
