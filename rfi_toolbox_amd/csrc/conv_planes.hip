@@ -685,6 +685,16 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
 template <int P>
 void dispatch(rfi_ctx* ctx, PConvDev& d) {
     const PConvArgs& a = d.a;
+    // bf16 flow, 64 output channels and more: 2 x 2 blocks per wave on ONE tile per group (a third fewer LDS bytes per MFMA
+    // than 2 x 1 blocks on two tiles; pays only together with the double-buffered staging: -0.9 % step time;
+    // RFI_PCONV_NT2=0 for A/B runs)
+    static const int wide = getenv("RFI_PCONV_NT2") ? atoi(getenv("RFI_PCONV_NT2")) : 1;
+    if constexpr (P == 1) {
+        if (wide && a.Cout >= 64 * wide) {
+            if (a.W >= 32) return launch_cfg<3, 1, 8, 32, 4, 1, 2, 2, P, 1, 1>(ctx, d);
+            if (a.W >= 16) return launch_cfg<3, 1, 16, 16, 4, 1, 2, 2, P, 1, 1>(ctx, d);
+        }
+    }
     if (a.W >= 32) launch_cfg<3, 1, 8, 32, 4, 1, 2, 1, P, 2, 1>(ctx, d);
     else if (a.W >= 16) launch_cfg<3, 1, 16, 16, 4, 1, 2, 1, P, 2, 1>(ctx, d);
     else launch_cfg<3, 1, 8, 8, 2, 2, 1, 1, P, 2, 1>(ctx, d);
