@@ -763,7 +763,26 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     }
     if (impl == IMPL_MFMA_BF16X3) {
         a.bf16x3 = true;
+        a.wB3 = nullptr;                // (this implementation was asked for by name)
         impl = IMPL_MFMA;
+    }
+    if (impl == IMPL_WS_X3) {           // kernel-level API / tests: a temporary B-operand-order copy of the filters
+        RFI_REQUIRE(conv_ws_eligible(a), "conv: shape not eligible for the wave-specialised kernel");
+        a.bf16x3 = true;
+        const size_t we = wb_elems(9, a.Cout, a.Cin, 0, 3);
+        bf16_t* wb = static_cast<bf16_t*>(ctx->alloc(we * 2 + 64));
+        struct Free {
+            rfi_ctx* c; void* p;
+            ~Free() { (void)hipStreamSynchronize(c->stream); try { c->release(p); } catch (...) {} }
+        } fr{ctx, wb};
+        launch_weights_to_wb_one(ctx, WBDesc{a.w, wb, 9, a.Cout, a.Cin, {a.Cin, 0}, 3});
+        launch_conv_ws(ctx, a, wb);
+        return;
+    }
+    static const bool no_ws = getenv("RFI_NO_WS") != nullptr;                    // A/B runs: round 2's kernel
+    if (impl == IMPL_AUTO && a.bf16x3 && a.wB3 && !no_ws && conv_ws_eligible(a)) {
+        launch_conv_ws(ctx, a, a.wB3);
+        return;
     }
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "conv: empty shape");
     RFI_REQUIRE(a.x.pstride >= a.Cin && a.y.pstride >= a.Cout, "conv: pixel stride smaller than channels");

@@ -44,6 +44,9 @@ struct ConvArgs {
     int Cin = 0, Cout = 0;
     const float* w = nullptr;         // [taps][Cout][Cin]
     const float* w3 = nullptr;        // 3 x bf16 mode: the same filters pre-split (launch_weights_to_x3); null: split on the fly
+    const unsigned short* wB3 = nullptr;   // 3 x bf16 mode, 3x3 stride-1 convs: the same filters in MFMA B-operand order with three
+                                      // planes (planes.hpp, launch_weights_to_wb, one K segment): the wave-specialised
+                                      // kernel (conv_ws.hip) runs where this is set and the shape is eligible
     const float* bias = nullptr;      // [Cout] or null
     MutView y;
     int Hout = 0, Wout = 0;           // spatial size of the tensor y points into
@@ -80,8 +83,11 @@ struct ConvArgs {
 
 // 5 / 6: the plane kernels (planes.hpp) in the 3 x bf16 / bf16 arithmetic; callers holding float32 tensors get
 // temporary plane copies (kernel-level ABI, tests)
+// 7: the wave-specialised 3 x bf16 kernel (conv_ws.hip); callers without ConvArgs::wB3 get a temporary filter copy
 enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 3, IMPL_MFMA_BF16X3 = 4,
-                IMPL_PLANES_X3 = 5, IMPL_PLANES_BF16 = 6 };
+                IMPL_PLANES_X3 = 5, IMPL_PLANES_BF16 = 6, IMPL_WS_X3 = 7 };
+bool conv_ws_eligible(const ConvArgs& a);
+void launch_conv_ws(rfi_ctx* ctx, ConvArgs& a, const unsigned short* wB3);
 
 bool conv_mfma_eligible(const ConvArgs& a);
 bool bf16_k16();           // RFI_BF16_K16=1: the float32-tensor bf16 mode runs the K = 16 MFMA on the split path's data flow (conv_mfma.hip)

@@ -48,6 +48,8 @@ rfi_model::~rfi_model() {
     for (auto& b : pl) b.free();
     if (wb_pool) ctx->release(wb_pool);
     if (wb_descs) ctx->release(wb_descs);
+    if (ws_pool) ctx->release(ws_pool);
+    if (ws_descs) ctx->release(ws_descs);
     for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool, grad_acc})   // (rs_wpool: arch 2 and 5)
         if (p) ctx->release(p);
     if (relayout_descs) ctx->release(relayout_descs);
@@ -396,10 +398,55 @@ void rfi_model::refresh_dgrad_weights() {
         }
         launch_weights_to_x3_batched(ctx, static_cast<const X3Desc*>(x3_descs), x3_n, x3_bytes);
         x3_fresh = true;
+        if (compute_x3 && !planesP) refresh_ws_weights();
     }
     if (arch == 2) refresh_resnet_weights();               // 2x2 forms of the stride-2 filters
     if (planesP && arch == 0) refresh_plane_weights();     // B-operand-order filters of the plane kernels
     wd_dirty = false;
+}
+
+// filters of every 3x3 stride-1 layer in MFMA B-operand order with three planes (conv_ws.hip), both directions, rebuilt
+// with the other derived copies after each optimiser step by ONE batched launch.  Callers find them by the layer's
+// pre-split record pointer (ws_of(ConvArgs::w3)), which every model's conv helper already passes around
+void rfi_model::refresh_ws_weights() {
+    if (!ws_pool) {
+        size_t need = 0;
+        for (const ConvBN& c : convs) {
+            if (c.R != 3 || c.stride != 1) continue;
+            if (c.cin_p % 16 == 0) need += wb_elems(9, c.cout, c.cin_p, 0, 3) + 32;
+            if (c.cout % 16 == 0) need += wb_elems(9, c.cin_p, c.cout, 0, 3) + 32;
+        }
+        if (need == 0) return;
+        ws_pool = static_cast<bf16_t*>(ctx->alloc(need * 2));
+        RFI_CHECK_HIP(hipMemsetAsync(ws_pool, 0, need * 2, ctx->stream));
+        std::vector<WBDesc> hd;
+        size_t o = 0;
+        ws_bytes = 0;
+        for (ConvBN& c : convs) {
+            if (c.R != 3 || c.stride != 1) continue;
+            if (c.cin_p % 16 == 0) {
+                c.ws3f = ws_pool + o;
+                const size_t e = wb_elems(9, c.cout, c.cin_p, 0, 3);
+                o += e + 32;
+                hd.push_back(WBDesc{params + c.w_off, c.ws3f, 9, c.cout, c.cin_p, {c.cin_p, 0}, 3});
+                ws_by_w3[c.w3] = c.ws3f;
+                ws_bytes += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
+            }
+            if (c.cout % 16 == 0) {
+                c.ws3d = ws_pool + o;
+                const size_t e = wb_elems(9, c.cin_p, c.cout, 0, 3);
+                o += e + 32;
+                hd.push_back(WBDesc{c.wd, c.ws3d, 9, c.cin_p, c.cout, {c.cout, 0}, 3});
+                ws_by_w3[c.wd3] = c.ws3d;
+                ws_bytes += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
+            }
+        }
+        ws_n = (int)hd.size();
+        ws_descs = ctx->alloc(hd.size() * sizeof(WBDesc));
+        RFI_CHECK_HIP(hipMemcpyAsync(ws_descs, hd.data(), hd.size() * sizeof(WBDesc), hipMemcpyHostToDevice, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // hd goes out of scope
+    }
+    if (ws_n) launch_weights_to_wb(ctx, static_cast<const WBDesc*>(ws_descs), ws_n, ws_bytes);
 }
 
 // ------------------------------------------------------------------------------------ forward
@@ -414,6 +461,7 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
     a.Cin = c.cin_p; a.Cout = c.cout;
     a.w = m->params + c.w_off;
     a.w3 = m->use_w3() ? c.w3 : nullptr;
+    a.wB3 = m->ws_of(a.w3);
     a.bias = m->params + c.b_off;
     a.y = MutView{Y, c.cout};
     a.Hout = s.H; a.Wout = s.W;
@@ -666,6 +714,7 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
         a.Cin = c.cout; a.Cout = c.cin;     // dx exists only for layers whose cin == cin_p
         a.w = c.wd;
         a.w3 = m->use_w3() ? c.wd3 : nullptr;
+        a.wB3 = m->ws_of(a.w3);
         a.bias = nullptr;
         a.y = MutView{dx, c.cin};
         a.Hout = s.H; a.Wout = s.W;

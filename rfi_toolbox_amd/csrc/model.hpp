@@ -52,6 +52,8 @@ struct ConvBN {
     float* wd3 = nullptr;               // ... and of the dgrad layout
     bf16_t* wBf = nullptr;              // plane kernels: filters in MFMA B-operand order, forward ...
     bf16_t* wBd = nullptr;              // ... and input-gradient direction (planes.hpp)
+    bf16_t* ws3f = nullptr;             // wave-specialised float32 kernel (conv_ws.hip): B-operand order with three planes, one K
+    bf16_t* ws3d = nullptr;             // segment; forward and input-gradient direction (3x3 stride-1 layers, channels % 16 == 0)
 };
 
 // ConvTranspose2d(k2,s2)+bias
@@ -116,6 +118,16 @@ struct rfi_model {
     float* chan_pool = nullptr;
     float* wd_pool = nullptr;
     float* w3_pool = nullptr;         // pre-split (3 x bf16) filter records, rebuilt with the dgrad layouts
+    rfi::bf16_t* ws_pool = nullptr;   // B-operand-order filters of the wave-specialised conv kernel (ConvBN::ws3f / ws3d)
+    void* ws_descs = nullptr;
+    int ws_n = 0;
+    double ws_bytes = 0;
+    std::unordered_map<const float*, const rfi::bf16_t*> ws_by_w3;   // pre-split record pointer (ConvArgs::w3) -> the same filters for conv_ws
+    const rfi::bf16_t* ws_of(const float* w3) const {
+        auto it = ws_by_w3.find(w3);
+        return it == ws_by_w3.end() ? nullptr : it->second;
+    }
+    void refresh_ws_weights();
     void* x3_descs = nullptr;         // device table of the batched rebuild
     int x3_n = 0;
     double x3_bytes = 0;

@@ -188,6 +188,7 @@ ConvArgs conv3x3_args(rfi_model* m, View in, InXform xf, const float* w, const f
     a.Cin = C; a.Cout = C;
     a.w = w;
     a.w3 = m->use_w3() ? w3 : nullptr;
+    a.wB3 = m->ws_of(a.w3);
     a.bias = bias;
     a.y = MutView{y, C};
     a.Hout = h; a.Wout = wd;

@@ -22,10 +22,12 @@ CONV_SHAPES = [
 
 IMPL_X3 = 4       # MFMA kernel, float32 by 3 x bf16 splitting (the default arithmetic of the models)
 IMPL_PX3 = 5      # plane kernels (LDS-DMA staged bf16 pieces), 3 x bf16 arithmetic; any channel count
+IMPL_WS = 7       # wave-specialised kernel (producer waves split, consumer waves multiply), 3 x bf16; H, W >= 8, Cin % 16 == 0
 
 
-def _impls(cin):
-    return [IMPL_DIRECT, IMPL_MFMA, IMPL_X3, IMPL_PX3] if cin % 4 == 0 else [IMPL_DIRECT, IMPL_PX3]
+def _impls(cin, h=0, w=0):
+    ws = [IMPL_WS] if cin % 16 == 0 and h >= 8 and w >= 8 else []
+    return [IMPL_DIRECT, IMPL_MFMA, IMPL_X3, IMPL_PX3] + ws if cin % 4 == 0 else [IMPL_DIRECT, IMPL_PX3]
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
@@ -43,7 +45,7 @@ def test_conv3x3_forward(shape, xform):
     c = ctx()
     dx, dw, db = c.to_device(nhwc(x)), c.to_device(wt.numpy()), c.to_device(b.numpy())
     dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
-    for impl in _impls(cin):
+    for impl in _impls(cin, h, w):
         dy = c.empty((n, h, w, cout))
         check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout,
                                  P(dsc) if xform else None, P(dsh) if xform else None, 1 if xform else 0, P(dy)))
@@ -67,6 +69,10 @@ def test_conv3x3_dgrad_wgrad(shape):
         gw = c.empty((cout, cin, 3, 3))
         check(lib.rfi_op_conv3x3_wgrad(c.handle, impl, P(dxd), P(ddy), n, h, w, cin, cout, None, None, 0, P(gw)))
         assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, f"wgrad impl={impl}"
+    if cout % 16 == 0 and h >= 8 and w >= 8:      # the input gradient on the wave-specialised kernel (a conv with Cin = cout)
+        out = c.empty((n, h, w, cin))
+        check(lib.rfi_op_conv3x3_dgrad(c.handle, IMPL_WS, P(ddy), n, h, w, cout, P(dwd), cin, P(out)))
+        assert rel_err(out.numpy(), nhwc(x.grad)) <= TOL, "dgrad impl=ws"
 
 
 def test_conv3x3_wgrad_with_load_transform():
