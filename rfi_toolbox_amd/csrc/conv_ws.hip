@@ -20,6 +20,7 @@
 // issue about half as fast beside a wave that keeps the matrix pipe full (measured: 14 vs 7 cycles per instruction of
 // the split), which is why a staged halo element has to feed 64 output channels (NTL = 2) wherever the layer has them.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "planes.hpp"
@@ -58,7 +59,9 @@ struct WsDev {
 
 constexpr int ROWB = 112;             // bytes per halo pixel in LDS
 
-template <int TB, int TH, int TW, int NTL>
+// ADB: two halo buffers (where the LDS has room: 32-channel blocks) -- the producers write item q + 1 while the consumers
+// read item q, one barrier per item; otherwise ONE halo buffer, written between two barriers of an item
+template <int TB, int TH, int TW, int NTL, bool ADB>
 struct WsCfg {
     static constexpr int HH = TH + 2, HW = TW + 2, HPI = HH * HW, HP = TB * HPI;
     static constexpr int A_BYTES = (HP * ROWB + 1023) & ~1023;
@@ -66,7 +69,8 @@ struct WsCfg {
     static constexpr int B_BYTES = NPIECE * 1024;
     static constexpr int B_ITEMS = (NPIECE + 3) / 4;                 // pieces per producer wave
     static constexpr int HALO_ITEMS = (HP * 4 + 255) / 256;          // float4 loads per producer thread and item
-    static constexpr int STAT_OFF = A_BYTES + 2 * B_BYTES;
+    static constexpr int B_OFF = (ADB ? 2 : 1) * A_BYTES;
+    static constexpr int STAT_OFF = B_OFF + 2 * B_BYTES;
     static constexpr int LDS_BYTES = STAT_OFF + 4 * NTL * 64 * 2 * 8;   // + per consumer lane and n-block (sum, sumsq)
     static_assert(TB * TH * TW == 256, "a tile is 256 output pixels");
     static_assert(32 % TW == 0 || TW % 32 == 0, "a 32-pixel block covers whole rows or a part of one");
@@ -117,9 +121,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // XF: the load transform -- 0 none, 1 relu(x * scale + shift), 2 x * scale + shift followed by max(v, v * slope) (LeakyReLU;
 // slope 1: no activation)
-template <int TB, int TH, int TW, int NTL, int XF>
+template <int TB, int TH, int TW, int NTL, int XF, bool ADB>
 __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
-    using C = WsCfg<TB, TH, TW, NTL>;
+    using C = WsCfg<TB, TH, TW, NTL, ADB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef RFI_DIAG_STAMPS
     unsigned long long st_[4] = {0, 0, 0, 0};
@@ -218,8 +222,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                 split_pair(v.z, v.w, pl[it][1], pl[it][3], pl[it][5]);
             }
         };
-        auto write_all = [&]() {
-            unsigned char* const sA = smem + (ptid >> 2) * ROWB + (ptid & 3) * 8;
+        auto write_all = [&](int buf) {
+            unsigned char* const sA = smem + buf * C::A_BYTES + (ptid >> 2) * ROWB + (ptid & 3) * 8;
 #pragma unroll
             for (int it = 0; it < C::HALO_ITEMS; ++it) {
                 if (ptid + it * 256 < C::HP * 4) {
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
         // last valid block: its products land in channels that are never stored
         const unsigned char* const wb = reinterpret_cast<const unsigned char*>(d.wB);
         auto issue_B = [&](int kc, int buf) {
-            unsigned char* const sB = smem + C::A_BYTES + buf * C::B_BYTES;
+            unsigned char* const sB = smem + C::B_OFF + buf * C::B_BYTES;
 #pragma unroll
             for (int i = 0; i < C::B_ITEMS; ++i) {
                 const int p = pw + 4 * i;
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                 split_all();                             // (waits for the loads of item q + 1, issued an iteration ago)
                 WS_T(t1);
                 WS_ACC(2, t0, t1);
+                if constexpr (ADB) write_all((q + 1) & 1);         // the consumers left this buffer an item ago
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(d.diag & 2)) issue_B(lch, (q + 1) & 1);      // its buffer was last read for item q - 1
                 __builtin_amdgcn_sched_barrier(0);
@@ -278,14 +283,17 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                 // piece has landed
                 WS_T(t2);
                 wait_vmcnt<C::HALO_ITEMS>();
+                if constexpr (ADB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 WS_T(t3);
                 WS_ACC(3, t2, t3);
             }
             WS_T(t4);
-            wg_barrier();                                // the consumers are done with the halo tile of item q
-            if (more) write_all();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wg_barrier();                                // item q + 1 is staged
+            wg_barrier();                                // the consumers are done with item q (ADB: and item q + 1 is staged)
+            if constexpr (!ADB) {
+                if (more) write_all(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_barrier();                            // item q + 1 is staged
+            }
             WS_T(t5);
             WS_ACC(0, t0, t4);
             WS_ACC(1, t4, t5);
@@ -303,13 +311,20 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
         }
         const int b_base = lane * 16;
         float bias[NTL];
+        unsigned lane_off[NTL];                          // this lane's part of a store address: 4 lh pixels on + its channel
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             const int co = n0 + nt * 32 + li;
             bias[nt] = (d.bias && co < d.Cout) ? d.bias[co] : 0.0f;
             asm volatile("" : "+v"(bias[nt]));
+            lane_off[nt] = (unsigned)(4 * lh * d.y_ps + co);
         }
-        f32x16 acc[2][NTL];
+        // acc: the tile being multiplied; outr: the finished tile whose epilogue is still owed.  C/D layout of 32x32:
+        // col = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel of the block): one wave
+        // store covers the same 32 channels of two pixels = two 128-byte runs
+        // (DEFER: where the registers allow it -- 32-channel blocks; 64-channel blocks run the epilogue from acc at once)
+        constexpr bool DEFER = NTL == 1;
+        f32x16 acc[2][NTL], outr[2][NTL];          // (outr: never touched, hence no registers, without DEFER)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -317,106 +332,194 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
         double d1[NTL], d2[NTL];                         // this lane's share of sum y, sum y^2 (its channels, its pixels)
+        float s1[NTL], s2[NTL];                          // ... of the tile whose epilogue is running
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) d1[nt] = d2[nt] = 0.0;
+        for (int nt = 0; nt < NTL; ++nt) { d1[nt] = d2[nt] = 0.0; s1[nt] = s2[nt] = 0.0f; }
+        constexpr int E = 32 * NTL;                      // accumulator registers (= stores) per tile and lane
+        // element e of a FULL tile (inside the image, all channels): no bounds tests, address = a wave-uniform pixel row
+        // + the lane's constant part
+        auto epi_elem = [&](const f32x16 (&src)[2][NTL], int e, unsigned tile_off) {
+            const int nt = e / 32, mt = (e >> 4) & 1, r = e & 15;
+            const int p = cw * 64 + mt * 32 + (r & 3) + 8 * (r >> 2);       // (+ 4 lh: the same image row)
+            const int b = p / (TH * TW), rr = p % (TH * TW);
+            const unsigned uoff = tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps);
+            const float v = src[mt][nt][r] + bias[nt];
+            d.y[uoff + lane_off[nt]] = v;
+            s1[nt] += v;
+            s2[nt] += v * v;
+        };
+        auto epi_generic = [&](const f32x16 (&src)[2][NTL], const Tile& t) {         // any tile: every element behind its bounds tests
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                const int co = n0 + nt * 32 + li;
+                const bool cok = co < d.Cout;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = cw * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int b = p / (TH * TW), rr = p % (TH * TW);
+                        const int n = t.n + b, oy = t.oy0 + rr / TW, ox = t.ox0 + rr % TW;
+                        const float v = src[mt][nt][r] + bias[nt];
+                        if (cok && n < d.N && oy < d.H && ox < d.W) {
+                            d.y[(unsigned)(((n * d.H + oy) * d.W + ox) * d.y_ps + co)] = v;
+                            s1[nt] += v;
+                            s2[nt] += v * v;
+                        }
+                    }
+                }
+            }
+        };
+        auto epi_finish = [&]() {
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                d1[nt] += (double)s1[nt];
+                d2[nt] += (double)s2[nt];
+                s1[nt] = s2[nt] = 0.0f;
+            }
+        };
+        bool pend = false;                               // outr holds a finished tile (pt)
+        Tile pt = tile_of(0);
+        // one (tile, chunk) item.  PEND: the epilogue of the previous tile (a FULL one) is spread over the nine tap
+        // steps, its stores and sums issuing between the MFMAs instead of in front of them
+        // FIRST: chunk 0 of a tile -- the first MFMA of every block takes C = 0 (no zeroing of the accumulators)
+        auto run_item = [&](auto pend_c, auto first_c, const unsigned char* sA, const unsigned char* sB) {
+            constexpr bool PEND = decltype(pend_c)::value, FIRST = decltype(first_c)::value;
+            const unsigned tile_off = (unsigned)(((pt.n * d.H + pt.oy0) * d.W + pt.ox0) * d.y_ps);
+            // software pipeline over the taps: the fragments of tap t + 1 are read BEFORE the MFMAs of tap t issue
+            bf16x8 afr[2][2][3], bfr[2][NTL][3];
+            auto load_frags = [&](int tap, bf16x8 (&af)[2][3], bf16x8 (&bf)[NTL][3]) {
+                const int tr = tap / 3, ts = tap % 3;
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[nt][p] = *reinterpret_cast<const bf16x8*>(sB + ((tap * NTL + nt) * 3 + p) * 1024);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        af[mt][p] = *reinterpret_cast<const bf16x8*>(sA + a_base[mt] + (tr * C::HW + ts) * ROWB + p * 32);
+            };
+            load_frags(0, afr[0], bfr[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) load_frags(tap + 1, afr[(tap + 1) & 1], bfr[(tap + 1) & 1]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) {
+                        f32x16 c = acc[mt][nt];
+                        if (FIRST && tap == 0)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+                        acc[mt][nt] = mma3(afr[tap & 1][mt], bfr[tap & 1][nt], c);
+                    }
+                if constexpr (PEND && DEFER) {
+#pragma unroll
+                    for (int k = 0; k < (E + 8) / 9; ++k) {
+                        const int e = tap * E / 9 + k;
+                        if (e < (tap + 1) * E / 9) epi_elem(outr, e, tile_off);
+                    }
+                }
+                // issue order of this step: the LDS reads of tap t + 1 (and the pending epilogue's stores and sums) go BETWEEN
+                // the MFMAs of tap t, one or two per MFMA -- issued as one burst in front of them they leave the matrix pipe
+                // idle for most of the burst (12 reads ~ 100 cycles against one 32-cycle MFMA in flight)
+                constexpr int NM = 12 * NTL, NR = 3 * (2 + NTL);
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+                    if (tap + 1 < 9 && i * NR / NM != (i + 1) * NR / NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+                    if constexpr (PEND && DEFER) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                  // two vector ALU instructions
+                        if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // a store every third MFMA
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         int ck = 0, cch = 0;                             // compute cursor: tile index, chunk
         Tile ct = tile_of(0);
         wg_barrier();
-        wg_barrier();                                    // item 0 is staged
+        if constexpr (!ADB) wg_barrier();                // item 0 is staged
         for (int q = 0; q < nitems; ++q) {
             WS_T(t0);
-            const unsigned char* const sA = smem;
-            const unsigned char* const sB = smem + C::A_BYTES + (q & 1) * C::B_BYTES + b_base;
+            const unsigned char* const sA = smem + (ADB ? (q & 1) * C::A_BYTES : 0);
+            const unsigned char* const sB = smem + C::B_OFF + (q & 1) * C::B_BYTES + b_base;
+            if constexpr (DEFER) {
+                if (pend && !(pt.n + TB <= d.N && pt.oy0 + TH <= d.H && pt.ox0 + TW <= d.W && n0 + 32 * NTL <= d.Cout)) {
+                    epi_generic(outr, pt);               // a ragged tile: its epilogue in one piece, in front of the item
+                    epi_finish();
+                    pend = false;
+                }
+            }
             if (!(d.diag & 4)) {
-                // software pipeline over the taps: the fragments of tap t + 1 are read BEFORE the MFMAs of tap t issue
-                bf16x8 afr[2][2][3], bfr[2][NTL][3];
-                auto load_frags = [&](int tap, bf16x8 (&af)[2][3], bf16x8 (&bf)[NTL][3]) {
-                    const int tr = tap / 3, ts = tap % 3;
-#pragma unroll
-                    for (int nt = 0; nt < NTL; ++nt)
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) bf[nt][p] = *reinterpret_cast<const bf16x8*>(sB + ((tap * NTL + nt) * 3 + p) * 1024);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int p = 0; p < 3; ++p)
-                            af[mt][p] = *reinterpret_cast<const bf16x8*>(sA + a_base[mt] + (tr * C::HW + ts) * ROWB + p * 32);
-                };
-                load_frags(0, afr[0], bfr[0]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    if (tap + 1 < 9) load_frags(tap + 1, afr[(tap + 1) & 1], bfr[(tap + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = mma3(afr[tap & 1][mt], bfr[tap & 1][nt], acc[mt][nt]);
-                    __builtin_amdgcn_sched_barrier(0);
+                if (pend) {                              // (pend implies chunk 0 of the next tile)
+                    run_item(std::true_type{}, std::true_type{}, sA, sB);
+                    epi_finish();
+                    pend = false;
+                } else if (cch == 0) {
+                    run_item(std::false_type{}, std::true_type{}, sA, sB);
+                } else {
+                    run_item(std::false_type{}, std::false_type{}, sA, sB);
                 }
             }
             WS_T(t1);
-            if (++cch == nkc) {
-                // ---- epilogue of tile ct, straight from the accumulators.  C/D layout of 32x32: col = lane & 31 (channel),
-                // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel of the block): one wave store covers the same
-                // 32 channels of two pixels = two 128-byte runs
-                // tiles inside the image with all their channels (every tile of the U-Net shapes): no bounds tests, and the
-                // address of a store = a wave-uniform pixel row + this lane's constant part
-                const bool full = ct.n + TB <= d.N && ct.oy0 + TH <= d.H && ct.ox0 + TW <= d.W && n0 + 32 * NTL <= d.Cout;
+            if (++cch == nkc) {                          // the tile is complete
+                if constexpr (DEFER) {                   // its results move to outr, the epilogue follows under the next item's
+#pragma unroll                                           // MFMAs (after the loop for the last tile)
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) {
-                    const int co = n0 + nt * 32 + li;
-                    float s1 = 0.0f, s2 = 0.0f;
-                    if (full) {
-                        const unsigned lane_off = (unsigned)(4 * lh * d.y_ps + co);
+                        for (int nt = 0; nt < NTL; ++nt) outr[mt][nt] = acc[mt][nt];
+                    pt = ct;
+                    pend = true;
+                } else {
+                    if (ct.n + TB <= d.N && ct.oy0 + TH <= d.H && ct.ox0 + TW <= d.W && n0 + 32 * NTL <= d.Cout) {
+                        // (no MFMA of this wave is in flight here: two elements per packed fp32 instruction)
                         const unsigned tile_off = (unsigned)(((ct.n * d.H + ct.oy0) * d.W + ct.ox0) * d.y_ps);
+                        f32x2 s1v[NTL], s2v[NTL];
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
+                        for (int nt = 0; nt < NTL; ++nt) s1v[nt] = s2v[nt] = f32x2{0.0f, 0.0f};
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int p = cw * 64 + mt * 32 + (r & 3) + 8 * (r >> 2);       // (+ 4 lh: the same image row)
+                        for (int e = 0; e < E; e += 2) {
+                            const int nt = e / 32, mt = (e >> 4) & 1, r = e & 15;
+                            const f32x2 v = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{bias[nt], bias[nt]};
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const int p = cw * 64 + mt * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2);
                                 const int b = p / (TH * TW), rr = p % (TH * TW);
-                                const unsigned uoff = tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps);   // wave-uniform
-                                const float v = acc[mt][nt][r] + bias[nt];
-                                d.y[uoff + lane_off] = v;
-                                s1 += v;
-                                s2 += v * v;
-                                acc[mt][nt][r] = 0.0f;
+                                d.y[tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps) + lane_off[nt]] = v[k];
                             }
+                            s1v[nt] += v;
+                            s2v[nt] = __builtin_elementwise_fma(v, v, s2v[nt]);
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < NTL; ++nt) {
+                            s1[nt] += s1v[nt].x + s1v[nt].y;
+                            s2[nt] += s2v[nt].x + s2v[nt].y;
                         }
                     } else {
-                        const bool cok = co < d.Cout;
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int p = cw * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                                const int b = p / (TH * TW), rr = p % (TH * TW);
-                                const int n = ct.n + b, oy = ct.oy0 + rr / TW, ox = ct.ox0 + rr % TW;
-                                const float v = acc[mt][nt][r] + bias[nt];
-                                if (cok && n < d.N && oy < d.H && ox < d.W) {
-                                    d.y[(unsigned)(((n * d.H + oy) * d.W + ox) * d.y_ps + co)] = v;
-                                    s1 += v;
-                                    s2 += v * v;
-                                }
-                                acc[mt][nt][r] = 0.0f;
-                            }
-                        }
+                        epi_generic(acc, ct);
                     }
-                    d1[nt] += (double)s1;
-                    d2[nt] += (double)s2;
+                    epi_finish();
                 }
                 cch = 0;
                 ++ck;
                 if (ck < my_tiles) ct = tile_of(ck);
             }
             WS_T(t4);
-            wg_barrier();                                // every consumer is done with the halo tile (its reads fed MFMAs that have issued)
-            wg_barrier();                                // item q + 1 is staged
+            wg_barrier();                                // every consumer is done with this item's halo tile (its reads fed MFMAs that have issued)
+            if constexpr (!ADB) wg_barrier();            // item q + 1 is staged
             WS_T(t5);
             WS_ACC(0, t0, t1);
             WS_ACC(2, t1, t4);
             WS_ACC(1, t4, t5);
+        }
+        if constexpr (DEFER) {
+            if (pend) {
+                epi_generic(outr, pt);
+                epi_finish();
+            }
         }
         if (st_out) {
 #pragma unroll
@@ -453,7 +556,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
 
 template <int TB, int TH, int TW, int NTL, int XF>
 void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
-    using C = WsCfg<TB, TH, TW, NTL>;
+    constexpr bool ADB = NTL == 1;
+    using C = WsCfg<TB, TH, TW, NTL, ADB>;
     const int ntiles = (int)(cdiv(a.N, TB) * cdiv(a.H, TH) * cdiv(a.W, TW));
     const int ycols = (int)cdiv(d.ncb, NTL);
     // one workgroup per CU: about 256 in total, a multiple of 8 along x, tiles spread evenly over the workgroups of
@@ -468,7 +572,7 @@ void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
     d.stats = a.stats;
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<TB, TH, TW, NTL, XF>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<TB, TH, TW, NTL, XF, ADB>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     });
 #ifdef RFI_DIAG_STAMPS
@@ -476,7 +580,7 @@ void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
         const size_t nw = (size_t)GX * ycols * 8;
         RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d.stamps), nw * 64));
         RFI_CHECK_HIP(hipMemsetAsync(d.stamps, 0, nw * 64, ctx->stream));
-        hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
+        hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
         std::vector<unsigned long long> hs(nw * 8);
         RFI_CHECK_HIP(hipMemcpyAsync(hs.data(), d.stamps, nw * 64, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -492,7 +596,7 @@ void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
         return;
     }
 #endif
-    hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
+    hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
     check_launch("conv_ws");
 }
 
