@@ -88,6 +88,8 @@ enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 
                 IMPL_PLANES_X3 = 5, IMPL_PLANES_BF16 = 6, IMPL_WS_X3 = 7 };
 bool conv_ws_eligible(const ConvArgs& a);
 void launch_conv_ws(rfi_ctx* ctx, ConvArgs& a, const unsigned short* wB3);
+bool gemm_ws_eligible(const ConvArgs& a);        // gemm_ws.hip: transposed conv (k2, s2) forward / input gradient, 1x1 convs
+void launch_gemm_ws(rfi_ctx* ctx, ConvArgs& a, const unsigned short* wB3);
 
 bool conv_mfma_eligible(const ConvArgs& a);
 bool bf16_k16();           // RFI_BF16_K16=1: the float32-tensor bf16 mode runs the K = 16 MFMA on the split path's data flow (conv_mfma.hip)

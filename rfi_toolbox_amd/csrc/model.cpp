@@ -416,6 +416,8 @@ void rfi_model::refresh_ws_weights() {
             if (c.cin_p % 16 == 0) need += wb_elems(9, c.cout, c.cin_p, 0, 3) + 32;
             if (c.cout % 16 == 0) need += wb_elems(9, c.cin_p, c.cout, 0, 3) + 32;
         }
+        for (const UpConv& u : ups)
+            if (u.cin % 16 == 0 && u.cout % 32 == 0) need += wb_elems(1, 4 * u.cout, u.cin, 0, 3) + wb_elems(4, u.cin, u.cout, 0, 3) + 64;
         if (need == 0) return;
         ws_pool = static_cast<bf16_t*>(ctx->alloc(need * 2));
         RFI_CHECK_HIP(hipMemsetAsync(ws_pool, 0, need * 2, ctx->stream));
@@ -440,6 +442,19 @@ void rfi_model::refresh_ws_weights() {
                 ws_by_w3[c.wd3] = c.ws3d;
                 ws_bytes += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
             }
+        }
+        // transposed convs (gemm_ws.hip): forward = ONE tap of 4 cout channels ([4][cout][cin] IS [4 cout][cin]); input
+        // gradient = four taps of [cin][cout]
+        for (UpConv& u : ups) {
+            if (!(u.cin % 16 == 0 && u.cout % 32 == 0)) continue;
+            const size_t ef = wb_elems(1, 4 * u.cout, u.cin, 0, 3), ed = wb_elems(4, u.cin, u.cout, 0, 3);
+            hd.push_back(WBDesc{params + u.w_off, ws_pool + o, 1, 4 * u.cout, u.cin, {u.cin, 0}, 3});
+            ws_by_w3[u.w3] = ws_pool + o;
+            o += ef + 32;
+            hd.push_back(WBDesc{u.wd, ws_pool + o, 4, u.cin, u.cout, {u.cout, 0}, 3});
+            ws_by_w3[u.wd3] = ws_pool + o;
+            o += ed + 32;
+            ws_bytes += 2.0 * (ef + ed) + 8.0 * 4 * u.cin * u.cout;
         }
         ws_n = (int)hd.size();
         ws_descs = ctx->alloc(hd.size() * sizeof(WBDesc));
@@ -543,6 +558,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         a.Cin = u.cin; a.Cout = u.cout;
         a.w = params + u.w_off;
         a.w3 = use_w3() ? u.w3 : nullptr;
+        a.wB3 = ws_of(a.w3);
         a.bias = params + u.b_off;
         a.y = MutView{buf(concat[l]), 2 * u.cout};
         a.Hout = s.H; a.Wout = s.W;
@@ -701,7 +717,11 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
     wa.slab_floats = m->bufs[m->ws_slab].n;
     wa.bf16 = m->compute_bf16;
     wa.bf16x3 = m->compute_x3;
-    {
+    // RFI_WGRAD_LATE=1 (default): the weight gradient is enqueued BEHIND the input-gradient conv of the same layer (the side
+    // stream waits for it): two matrix-core kernels sharing the chip finish no sooner than one after the other, but a
+    // weight gradient that runs next to the following layer's BatchNorm-backward passes (memory-bound) hides them
+    static const bool late = !(getenv("RFI_WGRAD_LATE") && atoi(getenv("RFI_WGRAD_LATE")) == 0);
+    if (!late || !dx) {
         SideScope side(m, dy_done);
         launch_wgrad(ctx, wa);
         side.end();
@@ -731,6 +751,11 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
         }
         launch_conv(ctx, a);
         records = a.stats_records;
+        if (late) {
+            SideScope side(m);
+            launch_wgrad(ctx, wa);
+            side.end();
+        }
     }
     return records;
 }
@@ -824,6 +849,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         a.Cin = u.cout; a.Cout = u.cin;
         a.w = u.wd;
         a.w3 = use_w3() ? u.wd3 : nullptr;
+        a.wB3 = ws_of(a.w3);
         a.bias = nullptr;
         float* dprev = (l == D) ? buf(gBottA) : buf(gA[l + 1]);
         a.y = MutView{dprev, u.cin};

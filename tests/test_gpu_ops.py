@@ -94,7 +94,7 @@ def test_conv3x3_wgrad_with_load_transform():
 
 
 CONVT_SHAPES = [(2, 8, 8, 64, 32), (1, 4, 4, 16, 8), (2, 16, 16, 128, 64), (1, 32, 32, 64, 32), (2, 2, 2, 8, 4),
-                (1, 6, 10, 12, 20)]
+                (1, 6, 10, 12, 20), (3, 5, 7, 48, 96), (64, 8, 8, 512, 256), (1, 3, 3, 32, 16)]
 
 
 @pytest.mark.parametrize("shape", CONVT_SHAPES)
@@ -120,6 +120,15 @@ def test_convt2x2_all(shape):
         gw = c.empty((cin, cout, 2, 2))
         check(lib.rfi_op_convt2x2_wgrad(c.handle, impl, P(dx), P(ddy), n, h, w, cin, cout, P(gw)))
         assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, f"wgrad impl={impl}"
+    # the wave-specialised GEMM kernel: forward with its four phases folded into the channels, input gradient as four taps
+    if cin % 16 == 0 and cout % 32 == 0:
+        out = c.empty((n, 2 * h, 2 * w, cout))
+        check(lib.rfi_op_convt2x2(c.handle, IMPL_WS, P(dx), n, h, w, cin, P(dw), P(db), cout, P(out)))
+        assert rel_err(out.numpy(), nhwc(y.detach())) <= TOL, "fwd impl=ws"
+    if cout % 16 == 0:
+        gx = c.empty((n, h, w, cin))
+        check(lib.rfi_op_convt2x2_dgrad(c.handle, IMPL_WS, P(ddy), n, h, w, cout, P(dw), cin, P(gx)))
+        assert rel_err(gx.numpy(), nhwc(x.grad)) <= TOL, "dgrad impl=ws"
 
 
 @pytest.mark.parametrize("m,c_", [(1, 4), (37, 6), (4096, 32), (70000, 64), (513, 200)])
