@@ -7,11 +7,13 @@
 
 A step = forward + BCE/dice loss + backward + (RCCL gradient all-reduce when N > 1) + global-norm
 clip + Adam on one batch of 64 synthetic patches per GPU that is already resident in HBM.
-Prints ONE JSON line on rank 0.  --dtype picks the arithmetic of the contractions: bf16 (default for the U-Net
-workloads) = bfloat16 activations in HBM and bf16 MFMA operands with float32 accumulation, BatchNorm, loss and
-optimiser -- the mixed precision the reference itself trains in on a GPU (torch.autocast, train_model.py:131,144);
-f32 = float32 by 3 x bf16 splitting (float32-level accuracy; the reference's CPU arithmetic); f32mfma = native
-float32 MFMA.  At N = 1 the default line also carries the float32 measurement of the same step ("float32").
+Prints ONE JSON line on rank 0.  --dtype picks the arithmetic of the contractions: f32 (the default line) = float32
+by 3 x bf16 splitting, float32-level accuracy -- the arithmetic of the reference's CPU path, which is the parity
+target (on CPU the reference's autocast / GradScaler are off, train_model.py:131,144); f32mfma = native
+float32 MFMA; bf16 = a BUILDER-CHOSEN reduced-precision mode (bfloat16 activations in HBM and bf16 MFMA operands,
+float32 accumulation / BatchNorm / loss / optimiser).  It is NOT the reference's arithmetic: on a GPU the reference
+autocasts to float16 with a GradScaler and clips the still-scaled gradients.  At N = 1 the default U-Net line also
+carries the bf16 measurement of the same step as the companion object "bfloat16".
 """
 import argparse
 import json
@@ -111,26 +113,67 @@ T0 = time.perf_counter()
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher around it: start N fresh child processes (one rank per
     GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this process has touched
-    the GPU or loaded the HIP library, wait for them and relay rank 0's JSON line."""
+    the GPU or loaded the HIP library, watch ALL of them and relay rank 0's JSON line.  If any rank exits
+    non-zero the others are terminated at once and this process exits non-zero with that rank's stderr tail
+    (a rank that died at init would otherwise leave the rest in the rendezvous / the first all-reduce until
+    the caller's time limit); RFI_BENCH_LAUNCH_TIMEOUT (seconds, default 1500) bounds the whole run."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    procs = []
+    limit = float(os.environ.get("RFI_BENCH_LAUNCH_TIMEOUT", "1500"))
+    procs, errs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[r]))
+
+    def tail(f, nbytes=3000):
+        f.seek(0, os.SEEK_END)
+        f.seek(max(0, f.tell() - nbytes))
+        return f.read().decode(errors="replace")
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t_start, failed = time.time(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t_start > limit:
+            failed = f"no result after {limit:.0f} s (RFI_BENCH_LAUNCH_TIMEOUT)"
+            bad = [(r, None) for r, c in enumerate(codes) if c is None][:1]
+            break
+        time.sleep(0.1)
+    if failed:
+        stop_all()
+        r = bad[0][0]
+        sys.stderr.write(f"bench: {failed}; the other ranks were terminated.  stderr tail of rank {r}:\n{tail(errs[r])}\n")
+        raise SystemExit(1)
+    sys.stderr.write(tail(errs[0], 20000))        # rank 0's progress log
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit(f"bench ranks failed (rank, exit code): {bad}")
 
 
 def roofline_of(launches, fam_serial, profile_steps, dtype, workload, peak_tf):
@@ -272,7 +315,8 @@ ARITHMETIC = {"f32": "float32 (contractions by 3 x bf16 splitting, float32-level
               "f32planes": "float32 (3 x bf16 pieces, pre-split plane tensors, LDS-DMA staging)",
               "f32mfma": "float32 (native v_mfma_f32_32x32x2_f32)",
               "bf16": "bfloat16 activations in HBM and bf16 MFMA operands, float32 accumulate, float32 BatchNorm / loss / "
-                      "optimiser state (what torch.autocast gives the reference on a GPU, train_model.py:131,144)",
+                      "optimiser state -- a builder-chosen reduced-precision mode, NOT the reference's arithmetic (its CPU "
+                      "path is float32; on a GPU it autocasts to float16 with a GradScaler, train_model.py:131,144)",
               "bf16regs": "bfloat16 MFMA operands rounded in registers, float32 storage"}
 
 
@@ -291,16 +335,17 @@ def main():
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--features", type=int, default=None)
     ap.add_argument("--dtype", choices=("f32", "f32mfma", "bf16", "f32planes", "bf16regs"), default=None,
-                    help="bf16 (default for unet / unet1024 / resnet1024): bfloat16 activations in HBM and bf16 MFMA "
-                         "operands, float32 accumulate / BatchNorm / loss / optimiser (the reference's autocast mode on a "
-                         "GPU); f32 (default for cnn3 / resnet): float32 contractions by 3 x bf16 splitting "
-                         "(float32-level accuracy, six bf16 MFMAs per product block); f32mfma: native float32 MFMA; "
+                    help="f32 (default for unet / cnn3 / resnet): float32 contractions by 3 x bf16 splitting (float32-level "
+                         "accuracy, six bf16 MFMAs per product block; the arithmetic of the reference's CPU path); bf16 "
+                         "(default for unet1024 / resnet1024, whose BASELINE config names bf16): bfloat16 activations in HBM "
+                         "and bf16 MFMA operands, float32 accumulate / BatchNorm / loss / optimiser -- builder-chosen reduced "
+                         "precision, not the reference's arithmetic; f32mfma: native float32 MFMA; "
                          "f32planes: the f32 arithmetic on pre-split plane tensors; bf16regs: bf16 operands rounded in "
                          "registers, float32 storage (round 1's bf16 mode)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-float32-line", action="store_true",
-                    help="skip the float32 measurement the default N = 1 line carries next to the bf16 one")
+    ap.add_argument("--no-bf16-line", "--no-float32-line", dest="no_companion", action="store_true",
+                    help="skip the bfloat16 measurement the default N = 1 U-Net line carries next to the float32 one")
     ap.add_argument("--launch-csv", default=None, help="write the per-launch HIP-event profile here")
     ap.add_argument("--dry-run", action="store_true",
                     help="control plane only (rendezvous, barrier, max-over-ranks, one JSON line); no GPU work")
@@ -308,6 +353,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
+    if os.environ.get("RFI_BENCH_FAIL_RANK") is not None and os.environ.get("RFI_BENCH_FAIL_RANK") == os.environ.get("RANK"):
+        raise SystemExit("fault injection (RFI_BENCH_FAIL_RANK): this rank exits at init")     # launcher tests
 
     if args.batch is None:
         args.batch = 1 if args.workload.endswith("1024") else 64
@@ -317,7 +364,7 @@ def main():
         args.features = 64 if args.workload in ("cnn3", "resnet", "resnet1024") else 32
     default_dtype = args.dtype is None
     if default_dtype:
-        args.dtype = "bf16" if args.workload in ("unet", "unet1024", "resnet1024") else "f32"
+        args.dtype = "bf16" if args.workload in ("unet1024", "resnet1024") else "f32"    # (configs[2] names bf16)
     if args.workload.startswith("resnet") and args.dtype in ("bf16", "f32planes"):
         # the plane data flow exists for the plain U-Net only: this model's bf16 mode rounds operands in registers
         args.dtype = {"bf16": "bf16regs", "f32planes": "f32"}[args.dtype]
@@ -331,8 +378,9 @@ def main():
         t0 = time.perf_counter()
         D.barrier()
         wall = D.max_over_ranks(time.perf_counter() - t0)
+        seen = D.count_ranks()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            print(json.dumps({"dry_run": True, "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
                               "barrier_ms": round(wall * 1e3, 3)}))
         return
 
@@ -346,6 +394,9 @@ def main():
     log("imports done")
     ctx = Context.get(local_rank)
     D.init_gradient_exchange(ctx, rank, world)
+    n_ranks_seen = D.count_ranks_rccl(ctx, world)      # a sum of ones over the RCCL communicator itself
+    if n_ranks_seen != world:
+        raise SystemExit(f"RCCL communicator sees {n_ranks_seen} ranks, expected {world}")
 
     def build_model():
         torch.manual_seed(1234)                   # identical replicas on every rank
@@ -367,10 +418,10 @@ def main():
 
     res = measure(model, ctx, D, d_x, d_y, hp, args, args.dtype, rank, args.launch_csv)
     second = None
-    if world == 1 and default_dtype and args.dtype == "bf16" and not args.no_float32_line:
+    if world == 1 and default_dtype and args.workload == "unet" and not args.no_companion:
         del model
-        model2 = build_model()                    # the same step from the same initial weights in float32
-        second = measure(model2, ctx, D, d_x, d_y, hp, args, "f32", rank)
+        model2 = build_model()                    # the same step from the same initial weights in the bf16 mode
+        second = measure(model2, ctx, D, d_x, d_y, hp, args, "bf16", rank)
         fwd_flops, step_flops = model2.algorithmic_flops(B, S, S)
         n_params = model2.num_parameters()
     else:
@@ -403,7 +454,7 @@ def main():
     out = {
         "metric": ("training patches/sec (128x128x3)" if S == 128 else f"training samples/sec ({S}x{S}x3)"),
         "value": main_line["value"], "unit": "patches/s" if S < 512 else "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],
+        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_line["dtype"], "data": "synthetic",
         "config": {"workload": {
             "unet": f"UNet(3,1,{args.features}) train step (fwd+BCE/dice+bwd+clip+Adam), "
@@ -427,9 +478,10 @@ def main():
         "families_overlapped": main_line["families_overlapped"],
     }
     if second is not None:
-        out["float32"] = line_of(second, "f32")
-        out["float32"]["note"] = ("the same step, same inputs and initial weights, with --dtype f32 (float32 contractions by "
-                                  "3 x bf16 splitting): the arithmetic of the reference's CPU path")
+        out["bfloat16"] = line_of(second, "bf16")
+        out["bfloat16"]["note"] = ("the same step, same inputs and initial weights, with --dtype bf16: a builder-chosen "
+                                   "reduced-precision mode (bf16 storage and MFMA operands), NOT the reference's arithmetic and "
+                                   "not the parity target; the top-level line is the float32 one")
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline ...")
         out["cpu_baseline"] = cpu_baseline(args.workload, args.features, S, B)

@@ -153,8 +153,9 @@ int rfi_model_set_activation(rfi_model* m, float negative_slope);
  *     2^-24 of the product are dropped).  Error against float64 is that of the native float32 MFMA path
  *     (tests/test_gpu_ops.py runs both against the same tolerances), at 2.7x its matrix-pipe rate.
  *   0 native float32 MFMA (v_mfma_f32_32x32x2_f32, an exact fmaf chain).
- *   1 bfloat16: operands rounded to bfloat16 (RNE), float32 accumulate -- the mixed precision the
- *     reference gets from torch.autocast on a GPU (scripts/train_model.py:131,144). */
+ *   1 bfloat16: operands rounded to bfloat16 (RNE), float32 accumulate -- a builder-chosen reduced-precision mode,
+ *     NOT the reference's arithmetic (float32 on CPU; float16 autocast + GradScaler on a GPU,
+ *     scripts/train_model.py:131,144). */
 int rfi_model_set_compute_dtype(rfi_model* m, int dtype);
 int rfi_model_set_head_sigmoid(rfi_model* m, int enabled);
 /* training loss: 0 = mean BCE-with-logits + dice, the reference's (scripts/train_model.py:120-128,146; default);

@@ -193,8 +193,8 @@ def _bn(x, st, prefix, training, ema_repeats, buffer_updates, tape, tag):
 
 
 # --------------------------------------------------------------------------
-# bf16-operand arithmetic (what torch.autocast gives the reference on a GPU, train_model.py:131,144, and what
-# the HIP library's bf16 compute mode does): every contraction (conv / convT, forward, input gradient, weight
+# bf16-operand arithmetic (what the HIP library's builder-chosen bf16 compute mode does; NOT the reference's arithmetic:
+# its CPU path is float32 and on a GPU it autocasts to float16 with a GradScaler, train_model.py:131,144): every contraction (conv / convT, forward, input gradient, weight
 # gradient) sees its two operands rounded to bfloat16 and accumulates in float32; everything else is float32.
 # --------------------------------------------------------------------------
 def _bf(t):
@@ -245,12 +245,10 @@ _WIDTHS_16 = False          # set by forward(): the model's first width is a mul
 class bf16_operands:
     """``with unet_ref.bf16_operands(): ...`` -- forward/backward of the oracle in the bf16-operand arithmetic.
     ``round_outputs=True``: every 3x3 conv output (conv + bias, before BatchNorm) is additionally rounded to bfloat16,
-    as torch.autocast does (its conv outputs ARE bf16 tensors) and as the HIP library's bf16 data flow does, which
-    stores them as bf16; BatchNorm statistics are then those of the rounded values.
+    as the HIP library's bf16 data flow does, which stores them as bf16; BatchNorm statistics are then those of the rounded values.
     ``round_grads`` (default: as ``round_outputs``; needs widths that are multiples of 16, as the library does): the
     input gradients of the 3x3 convs that feed a BatchNorm backward or the max-pool backward -- every second conv of
-    a DoubleConv, and the first conv of the bottleneck and of encoders 2.. -- are rounded to bfloat16 as well (under
-    torch.autocast they ARE bf16 tensors; the library stores them as bf16), and so are the gradients that reach a
+    a DoubleConv, and the first conv of the bottleneck and of encoders 2.. -- are rounded to bfloat16 as well (the library stores them as bf16), and so are the gradients that reach a
     DoubleConv's output from the max-pool backward + skip (encoders) and from a one-channel 1x1 head.  The decoder's
     first conv, whose input gradient feeds the transposed conv and the skip, keeps float32."""
 

@@ -1132,8 +1132,10 @@ int rfi_comm_destroy(rfi_ctx* ctx) {
     return guarded([&] {
         if (ctx->nccl_comm) {
             ctx->activate();
-            hipStreamSynchronize(ctx->stream);
-            if (ctx->comm_stream) hipStreamSynchronize(ctx->comm_stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->main_stream) (void)hipStreamSynchronize(ctx->main_stream);
+            if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);      // (weight gradients feed the buckets)
+            if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
             nccl_check(g_nccl.CommDestroy(ctx->nccl_comm), "ncclCommDestroy");
             ctx->nccl_comm = nullptr;
             ctx->world = 1;

@@ -246,6 +246,17 @@ void rfi_model::prepare(int n, int h, int w) {
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->side_stream));
         side_seq = 0;
     }
+    if (side_seq != 0 || ctx->fork_ring_used != 0 || ctx->bucket_ev_used != 0 || pend_hi > pend_lo) {
+        // the previous pass did not reach side_join / exchange_join (an exception mid-backward): drain every stream and
+        // start from clean counters and event pools
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->main_stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->side_stream));
+        if (ctx->comm_stream) RFI_CHECK_HIP(hipStreamSynchronize(ctx->comm_stream));
+        side_seq = 0;
+        ctx->fork_ring_used = 0;
+        ctx->bucket_ev_used = 0;
+        pend_lo = pend_hi = 0;
+    }
     if (arch == 1) return prepare_cnn3(n, h, w);
     if (arch == 3 || arch == 4) return prepare_mask(n, h, w);
     if (arch == 5) return prepare_backbone(n, h, w);
@@ -652,8 +663,31 @@ static hipEvent_t bucket_event(rfi_ctx* ctx) {
     }
     return ctx->bucket_ev[ctx->bucket_ev_used++];
 }
+// Buckets arrive in the order the backward pass completes them (decreasing offsets).  Small ones are merged with
+// their successors until RFI_BUCKET_MIN_FLOATS (default 2^20 = 4 MB) have accumulated -- a sub-megabyte all-reduce is
+// bound by latency, not by the links -- and the last call (lo == 0) flushes what is left.  RFI_NO_BUCKETS=1: nothing
+// leaves during the pass; exchange_join sends the whole buffer in one all-reduce (the fallback if the overlapped
+// exchange misbehaves on a new communicator).
 void rfi_model::bucket_ready(size_t lo, size_t hi) {
     if (!exchange_in_backward || !ctx->exchange_active() || hi <= lo) return;
+    static const bool no_buckets = getenv("RFI_NO_BUCKETS") != nullptr;
+    static const size_t min_floats = getenv("RFI_BUCKET_MIN_FLOATS") ? (size_t)atoll(getenv("RFI_BUCKET_MIN_FLOATS")) : (size_t)1 << 20;
+    if (pend_hi > pend_lo) {
+        RFI_REQUIRE(hi == pend_lo || lo == pend_hi, "bucket_ready: buckets must be adjacent");
+        pend_lo = std::min(pend_lo, lo);
+        pend_hi = std::max(pend_hi, hi);
+    } else {
+        pend_lo = lo;
+        pend_hi = hi;
+    }
+    if (no_buckets) return;                       // (exchange_join flushes)
+    if (pend_hi - pend_lo < min_floats && pend_lo != 0) return;
+    flush_bucket();
+}
+void rfi_model::flush_bucket() {
+    if (pend_hi <= pend_lo) return;
+    const size_t lo = pend_lo, hi = pend_hi;
+    pend_lo = pend_hi = 0;
     hipEvent_t em = bucket_event(ctx);
     RFI_CHECK_HIP(hipEventRecord(em, ctx->main_stream));
     RFI_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, em, 0));
@@ -666,6 +700,7 @@ void rfi_model::bucket_ready(size_t lo, size_t hi) {
 }
 void rfi_model::exchange_join() {
     if (!ctx->exchange_active()) return;
+    flush_bucket();                               // (RFI_NO_BUCKETS, or a model whose last bucket does not start at 0)
     hipEvent_t e = bucket_event(ctx);
     RFI_CHECK_HIP(hipEventRecord(e, ctx->comm_stream));
     RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, e, 0));

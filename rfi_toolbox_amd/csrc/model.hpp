@@ -232,7 +232,7 @@ struct rfi_model {
     std::vector<int> yE1, yE2, yD1;
     int yB1 = -1, yD2top = -1;
     // bf16 data flow: the gradient tensors the input-gradient convs write (dA of every first conv, the pooled gradients) are
-    // bfloat16 too -- as torch.autocast's are -- when the level widths are multiples of 16
+    // bfloat16 too when the level widths are multiples of 16
     bool g16_flow = false;
     std::vector<int> g16A, g16B, g16pool;       // g16A: dA of the second convs where an elementwise kernel produces it (head, max-pool backward)
     int g16BottB = -1;
@@ -258,6 +258,8 @@ struct rfi_model {
     // and side streams has run -> all-reduce them on the communication stream; exchange_join: main waits for all
     bool exchange_in_backward = false;   // set by the full-step entry points only (the split API exchanges explicitly)
     void bucket_ready(size_t lo, size_t hi);
+    size_t pend_lo = 0, pend_hi = 0;  // finished but not yet exchanged range (small buckets wait for their neighbours)
+    void flush_bucket();
     void exchange_join();
     // BN-apply + activation of layer c as a load transform for its consumers (slope 0 = ReLU)
     rfi::InXform bn_xf(const rfi::ConvBN& c) const { return rfi::act_xform(c.scale(), c.shift(), act_slope); }

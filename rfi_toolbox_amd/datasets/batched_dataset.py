@@ -90,7 +90,12 @@ class BatchWriter:
 def _shard_files(directory):
     import json
     d = Path(directory)
-    files = sorted(d.glob("batch_*.pt"))
+    # by shard NUMBER: the writer names them batch_{idx:03d}.pt (reference datasets/batched_dataset.py:147), so from the
+    # 1000th shard on the lexicographic order (batch_1000 < batch_101) is not the written order
+    def shard_no(p):
+        digits = "".join(ch for ch in p.stem[len("batch_"):] if ch.isdigit())
+        return (int(digits) if digits else -1, p.name)
+    files = sorted(d.glob("batch_*.pt"), key=shard_no)
     if not files:
         raise FileNotFoundError(f"no batch_*.pt shards under {d}")
     meta = json.load(open(d / "metadata.json")) if (d / "metadata.json").exists() else {}
@@ -112,7 +117,7 @@ def load_batches(directory):
     is a VIEW into the whole flushed block (``torch.save`` of a slice stores the full storage); loading gives the
     slice back."""
     files, meta = _shard_files(directory)
-    parts = [_check_shard(torch.load(f, weights_only=False), f) for f in files]
+    parts = [_check_shard(torch.load(f, weights_only=True), f) for f in files]      # tensors only: no pickle code from the data directory
     return TorchDataset(torch.cat([i for i, _ in parts]).float(),
                         torch.cat([lb for _, lb in parts]).to(torch.uint8), meta)
 

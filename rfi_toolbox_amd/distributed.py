@@ -30,13 +30,18 @@ def shard_range(n_items: int, rank: int, world: int):
 
 
 def init_control_plane(backend="gloo"):
-    """Join the torch.distributed rendezvous described by RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT."""
+    """Join the torch.distributed rendezvous described by RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT.  The rendezvous and
+    every later control-plane collective time out after RFI_RDZV_TIMEOUT seconds (default 180) instead of waiting
+    forever for a rank that never came up."""
+    import datetime
+
     import torch.distributed as dist
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        timeout = datetime.timedelta(seconds=float(os.environ.get("RFI_RDZV_TIMEOUT", "180")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local_rank, world
 
 
@@ -65,6 +70,30 @@ def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def count_ranks() -> int:
+    """Ranks the control plane really connects: a sum of ones (1 without a process group)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t[0])
+    return 1
+
+
+def count_ranks_rccl(ctx, world: int) -> int:
+    """Ranks the RCCL communicator of `ctx` connects: an all-reduce(sum) of one float over it (1 for world == 1)."""
+    if world == 1:
+        return 1
+    import ctypes as C
+
+    from ._lib import check, lib
+    one = ctx.to_device(np.ones(4, np.float32))
+    check(lib.rfi_comm_allreduce_sum_f32(ctx.handle, C.c_void_p(one.ptr), 4))
+    ctx.synchronize()
+    return int(round(float(one.numpy()[0])))
 
 
 def max_over_ranks(value: float) -> float:

@@ -160,9 +160,9 @@ class HipSegmenter:
         bfloat16 pieces, six bf16 MFMAs per product block -- float32-level accuracy (same error against
         float64 as the native path) at 2.7x its matrix rate.  ``"float32_mfma"``: the native float32 MFMA
         (exact fmaf chain).  ``"bfloat16"``: activations stored in HBM as bf16, bf16 MFMA operands, float32
-        accumulate, float32 BatchNorm / loss / optimiser -- the mixed precision the reference gets from
-        ``torch.autocast`` on a GPU (train_model.py:131,144); the 3x3 layers run on the plane kernels (LDS-DMA staged
-        operands).  ``"float32_planes"``: the default arithmetic on pre-split plane tensors (same kernels as
+        accumulate, float32 BatchNorm / loss / optimiser -- a builder-chosen reduced-precision mode, NOT the reference's
+        arithmetic (its CPU path, the parity target, is float32; on a GPU it autocasts to float16 with a GradScaler,
+        train_model.py:131,144); the 3x3 layers run on the plane kernels (LDS-DMA staged operands).  ``"float32_planes"``: the default arithmetic on pre-split plane tensors (same kernels as
         bfloat16, three pieces per value).  ``"bfloat16_regs"``: round 1's bf16 mode (float32 storage, operands
         rounded in registers)."""
         code = {"float32": 2, "fp32": 2, "f32": 2, "float32_3xbf16": 2, "float32_mfma": 0, "f32mfma": 0,

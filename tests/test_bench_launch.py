@@ -25,6 +25,27 @@ def test_bench_self_launches_two_ranks():
     assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
 
 
+def test_bench_self_launches_eight_ranks():
+    """The driver's N = 8 invocation, control plane only: eight children, one JSON line, every rank seen."""
+    out = _run(args=("--gpus", "8"))
+    assert out["n_gpus"] == 8 and out["n_ranks_seen"] == 8
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies_at_init():
+    """Rank 3 exits 1 before the rendezvous: the parent must stop the other ranks and return non-zero within seconds, not
+    sit in the rendezvous until somebody's time limit."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["RFI_BENCH_FAIL_RANK"] = "3"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "8"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 60, "the launcher waited for the dead rank"
+    assert "rank 3" in r.stderr and "fault injection" in r.stderr, r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_single_rank_needs_no_rendezvous():
     out = _run(args=("--gpus", "1"))
     assert out["n_gpus"] == 1

@@ -1,6 +1,6 @@
 """-m gpu: the bfloat16 compute mode (MFMA operands rounded to bf16 in registers, float32 accumulate and
-storage) -- the mixed-precision arithmetic the reference gets from torch.autocast on a GPU
-(scripts/train_model.py:131,144).  Not bit-comparable with the float32 CPU reference: checked against
+storage) -- a builder-chosen reduced-precision mode (the reference's CPU path is float32; on a
+GPU it autocasts to float16 with a GradScaler, scripts/train_model.py:131,144).  Not bit-comparable with the float32 CPU reference: checked against
 an oracle that rounds the same operands (weights, activations, output gradients) to bf16, and by the
 north-star criterion, |dIoU| <= 1e-3 on the reference-trained weights."""
 import os

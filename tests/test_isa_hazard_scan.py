@@ -12,5 +12,10 @@ def test_no_packed_fp32_to_f64_pairs_in_the_isa():
     assert S.count_pairs(["v_pk_mul_f32 v[24:25], v[18:19], v[24:25]", "v_cndmask_b32_e64 v22, v36, v16, s[4:5]",
                           "v_cvt_f64_f32_e32 v[32:33], v24"]) == 1
     assert S.count_pairs(["v_pk_mul_f32 v[24:25], v[18:19], v[24:25]", "v_mov_b32_e32 v24, v1", "v_cvt_f64_f32_e32 v[32:33], v24"]) == 0
+    # a copy of the packed result is followed, and the pair is seen up to WINDOW (>= 16) instructions apart
+    assert S.count_pairs(["v_pk_add_f32 v[2:3], v[4:5], v[6:7]", "v_mov_b32_e32 v9, v3", "v_cvt_f64_f32_e32 v[10:11], v9"]) == 1
+    assert S.WINDOW >= 16
+    far = ["v_pk_add_f32 v[2:3], v[4:5], v[6:7]"] + ["s_nop 0"] * 15 + ["v_cvt_f64_f32_e32 v[10:11], v2"]
+    assert S.count_pairs(far) == 1
     res = S.scan_all()
     assert not any(res.values()), res

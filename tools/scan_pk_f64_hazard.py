@@ -10,7 +10,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 from rfi_toolbox_amd import build as B
 
-WINDOW = 8
+WINDOW = B.HAZARD_WINDOW          # instructions after the packed op (16 s_nop between the pair hid the fault: DESIGN.md)
+count_pairs = B.count_pk_f64_pairs    # (the build itself runs this check on every device source it compiles)
 
 
 def scan_source(src):
@@ -20,26 +21,7 @@ def scan_source(src):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(r.stderr)
-        lines = [l.strip() for l in open(out) if l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;")]
-    return count_pairs(lines)
-
-
-def count_pairs(lines):
-    n = 0
-    for i, l in enumerate(lines):
-        m = re.match(r"v_pk_\w+_f32\s+v\[(\d+):(\d+)\]", l)
-        if not m:
-            continue
-        dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
-        for j in range(i + 1, min(i + 1 + WINDOW, len(lines))):
-            c = re.match(r"v_cvt_f64_f32\w*\s+v\[\d+:\d+\],\s+v(\d+)", lines[j])
-            if c and int(c.group(1)) in dst:
-                n += 1
-                break
-            w = re.match(r"v_\w+\s+v\[?(\d+)(?::(\d+))?\]?", lines[j])      # result overwritten: stop tracking those registers
-            if w:
-                dst -= set(range(int(w.group(1)), int(w.group(2) or w.group(1)) + 1))
-    return n
+        return count_pairs(B.isa_lines(out))
 
 
 def scan_all(workers=8):
