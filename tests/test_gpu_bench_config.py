@@ -82,8 +82,10 @@ def test_bench_configuration_step_bf16_vs_bf16_operand_oracle():
         # cancellation-heavy sums, so their float32 values differ in the low bits between two summation orders
         # and a few percent of them round to the neighbouring bf16 -- hence "no further from the same-arithmetic
         # oracle than float32 is", per tensor, and clearly closer for the typical tensor
-        assert rel_same <= max(1.1 * rel_arith, 1e-2), (k, rel_same, rel_arith)
-    assert np.median([w[0] for w in worst]) <= 0.8, sorted(worst)[-3:]
+        # -- and still EVERY tensor must sit clearly closer to the same-arithmetic oracle than float32 does (measured,
+        # round 3: worst tensor 0.53 of the float32 distance, median 0.43, none of the 64 above 0.55)
+        assert rel_same <= max(0.7 * rel_arith, 5e-3), (k, rel_same, rel_arith)
+    assert np.median([w[0] for w in worst]) <= 0.55, sorted(worst)[-3:]
     norm = m.apply_gradients(lr=1e-4, weight_decay=1e-5)
     assert norm == pytest.approx(b["norm"], rel=2e-2)
 

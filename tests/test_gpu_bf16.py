@@ -52,25 +52,91 @@ def test_bf16_inference_iou_on_reference_weights(golden_dir):
     assert np.abs(logits - want).max() <= 0.05 * np.abs(want).max()
 
 
-def test_bf16_training_tracks_float32():
-    """40 steps from the same init and data in both modes: the loss curves stay within 2 % of the initial
-    loss of each other and end at the same IoU (mixed precision must train, not just run)."""
-    torch.manual_seed(7)
-    a = UNet(3, 1, 8)
-    b = UNet(3, 1, 8).load_state_dict(a.state_dict()).set_compute_dtype("bfloat16")
-    g = torch.Generator().manual_seed(8)
-    x = torch.randn(4, 64, 64, 3, generator=g)
-    y = torch.zeros(4, 64, 64, dtype=torch.uint8)
-    y[:, 20:30, :] = 1
-    y[:, :, 40:44] = 1
-    x[..., 1] += 2.0 * y.float()                       # make the mask learnable from channel 1
-    la = [a.train_step(x, y, lr=1e-3) for _ in range(40)]
-    lb = [b.train_step(x, y, lr=1e-3) for _ in range(40)]
-    assert la[-1] < 0.8 * la[0] and lb[-1] < 0.8 * lb[0]
-    assert max(abs(p - q) for p, q in zip(la, lb)) <= 0.02 * la[0], (la[-1], lb[-1])
-    ia = metrics_ref.evaluate_segmentation(a.eval().forward_nhwc(x)[..., 0] > 0, y.numpy())["iou"]
-    ib = metrics_ref.evaluate_segmentation(b.eval().forward_nhwc(x)[..., 0] > 0, y.numpy())["iou"]
-    assert abs(ia - ib) <= 0.02, (ia, ib)
+def _golden_state(npz, tag):
+    return OrderedDict((k[len(tag) + 1:], torch.from_numpy(npz[k].copy())) for k in npz.files if k.startswith(tag + "/"))
+
+
+def _oracle_bf16_trajectory(g, steps, lr, wd, iou_every=0, **adam_kw):
+    """The oracle in the bf16-operand arithmetic on the golden inputs: what a CORRECT bf16 implementation reaches, i.e.
+    the calibration of how far the arithmetic itself moves the reference's float32 trajectory."""
+    st = _golden_state(g, "state0")
+    adam = unet_ref.new_adam_state(st)
+    x, y = unet_ref.nhwc_to_nchw(torch.from_numpy(g["img"])), torch.from_numpy(g["lab"]).float().unsqueeze(1)
+    losses, ious, states = [], {}, {}
+    for s in range(1, steps + 1):
+        with unet_ref.bf16_operands(round_outputs=True):
+            losses.append(unet_ref.train_step(st, adam, x, y, lr=lr, weight_decay=wd, **adam_kw)["loss"])
+            if iou_every and s % iou_every == 0:
+                with torch.no_grad():
+                    lg = unet_ref.forward(st, x, training=False)
+                ious[s] = metrics_ref.evaluate_segmentation(lg[:, 0].numpy() > 0, g["lab"])["iou"]
+        states[s] = OrderedDict((k, v.clone()) for k, v in st.items())
+    return losses, ious, states, adam
+
+
+def test_bf16_trajectory_against_the_reference_golden_f8(golden_dir):
+    """The REFERENCE's 40-step training trajectory (tests/golden/unet_f8_b4_s64.npz, captured from
+    /root/reference/rfi_toolbox/scripts/train_model.py:139-151 semantics on CPU float32) replayed in the bfloat16 mode.
+    Bounds: training is a chaotic map of its rounding errors, and bf16 operands perturb every contraction by ~2^-9, so
+    the yardstick is the CPU oracle run in the same bf16-operand arithmetic on the same data (it leaves the golden IoU
+    by up to 4e-3 and the golden loss by 7e-4): the HIP trajectory may sit twice as far from the golden values as that
+    oracle does (floors 3e-3 IoU / 1e-3 loss) and must stay within 4e-3 IoU / 2e-3 loss of the oracle itself."""
+    g = np.load(os.path.join(golden_dir, "unet_f8_b4_s64.npz"))
+    o_loss, o_iou, _, _ = _oracle_bf16_trajectory(g, 40, 1e-3, 1e-5, iou_every=10)
+    m = UNet(3, 1, 8).load_state_dict(_golden_state(g, "state0")).set_compute_dtype("bfloat16")
+    gold_loss = [float(v) for v in g["losses"]]
+    o_dev = max(abs(a - b) for a, b in zip(o_loss, gold_loss))
+    ious = {}
+    for s in range(1, 41):
+        loss = m.train_step(g["img"], g["lab"], lr=1e-3, weight_decay=1e-5)
+        assert abs(loss - gold_loss[s - 1]) <= max(2 * o_dev, 1e-3), (s, loss, gold_loss[s - 1], o_dev)
+        assert abs(loss - o_loss[s - 1]) <= 2e-3, (s, loss, o_loss[s - 1])
+        if s % 10 == 0:
+            m.eval()
+            ious[s] = metrics_ref.evaluate_segmentation(m.forward_nhwc(g["img"])[..., 0] > 0, g["lab"])["iou"]
+            m.train()
+    for s, want in zip(g["iou_steps"], g["iou"]):
+        s, want = int(s), float(want)
+        assert abs(ious[s] - want) <= max(2 * abs(o_iou[s] - want), 3e-3), (s, ious[s], want, o_iou[s])
+        assert abs(ious[s] - o_iou[s]) <= 4e-3, (s, ious[s], o_iou[s])
+    assert ious[40] >= float(g["iou"][-1]) - 3e-3          # it trains to the reference's final IoU
+
+
+def test_bf16_three_steps_against_the_reference_golden_f4(golden_dir):
+    """The reference's first three optimisation steps (tests/golden/unet_f4_b4_s32.npz) in the bfloat16 mode: losses,
+    every parameter after steps 1 and 3, Adam moments after step 3.  Adam normalises an update to ~lr whatever the
+    gradient's precision, so a parameter can differ from the float32 golden value by at most ~2 lr per step (a sign
+    flip of a noise-level gradient) and typically by a few per cent of lr; the moments carry the gradient's bf16 error
+    directly and are bounded by twice what the bf16-operand oracle itself shows against the golden values."""
+    g = np.load(os.path.join(golden_dir, "unet_f4_b4_s32.npz"))
+    lr, b1, b2, eps, wd, clip = [float(v) for v in g["hyper"]]
+    o_loss, _, o_states, o_adam = _oracle_bf16_trajectory(g, 3, lr, wd, betas=(b1, b2), eps=eps, clip=clip)
+    m = UNet(3, 1, 4).load_state_dict(_golden_state(g, "state0")).set_compute_dtype("bfloat16")
+    for s in (1, 2, 3):
+        loss = m.train_step(g["img"], g["lab"], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, max_grad_norm=clip)
+        assert abs(loss - float(g["losses"][s - 1])) <= 1e-3 and abs(loss - o_loss[s - 1]) <= 1e-3, (s, loss)
+        if s in (1, 3):
+            sd = m.state_dict()
+            meds = []
+            for k, v in sd.items():
+                want = g[f"state{s}/{k}"]
+                if k.endswith("num_batches_tracked"):
+                    assert int(v) == int(want), k
+                elif "running_" in k:        # BatchNorm buffers follow the bf16 activations: against the same-arithmetic oracle
+                    np.testing.assert_allclose(v.numpy(), o_states[s][k].numpy(), rtol=2e-2, atol=2e-3, err_msg=k)
+                else:
+                    d = np.abs(v.numpy() - want)
+                    assert d.max() <= 2.2 * lr * s, (k, d.max() / (lr * s))
+                    meds.append(np.median(d) / (lr * s))
+            assert np.median(meds) <= 0.25, np.median(meds)        # the typical parameter: a fraction of one update
+    for k in ("encoder1.conv.conv.0.weight", "decoder2.up.weight", "final_conv.weight"):
+        mm, vv, step = m.adam_state(k)
+        assert step == 3
+        wm, wv = g[f"adam_m3/{k}"], g[f"adam_v3/{k}"]
+        om, ov = o_adam["m"][k].numpy(), o_adam["v"][k].numpy()
+        rel = lambda a, b: np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)   # noqa: E731
+        assert rel(mm, wm) <= max(2 * rel(om, wm), 2e-2), (k, rel(mm, wm), rel(om, wm))
+        assert rel(vv, wv) <= max(2 * rel(ov, wv), 4e-2), (k, rel(vv, wv), rel(ov, wv))
 
 
 def test_bf16_unet_1024_vs_bf16_operand_oracle():
@@ -104,8 +170,8 @@ def test_bf16_unet_1024_vs_bf16_operand_oracle():
         nrm = np.linalg.norm(w_bf) + 1e-30
         rel_same = np.linalg.norm(m.grad(k).ravel() - w_bf) / nrm
         rel_arith = np.linalg.norm(w_32 - w_bf) / nrm
-        # no further from the same-arithmetic oracle than the float32 oracle is (see test_gpu_bench_config.py)
-        assert rel_same <= max(1.1 * rel_arith, 1e-2), (k, rel_same, rel_arith)
+        # closer to the same-arithmetic oracle than the float32 oracle is (see test_gpu_bench_config.py)
+        assert rel_same <= max(1.0 * rel_arith, 1e-2), (k, rel_same, rel_arith)
 
 
 def test_bf16_inference_iou_at_1024_on_reference_weights(golden_dir):
