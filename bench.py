@@ -100,6 +100,15 @@ def cpu_baseline(workload, features, size, gpu_batch=64, seconds_cap=25.0):
         out["single_thread"] = {"value": round(batch / med1, 3), "unit": unit, "cores": 1,
                                 "sample": f"same step, torch.set_num_threads(1), {n1} timed steps, "
                                           f"median {med1 * 1e3:.1f} ms/step"}
+    if size < 512 and gpu_batch != batch:
+        # the same step at the GPU line's own batch: a short sample, all threads
+        batch, x_small, y_small = gpu_batch, x, y
+        x = torch.randn(batch, 3, size, size, generator=g)
+        y = (torch.rand(batch, 1, size, size, generator=g) > 0.8).float()
+        medb, nb = timed(threads, 1, 3, 12.0)
+        out["at_gpu_batch"] = {"value": round(batch / medb, 3), "unit": unit, "cores": threads,
+                               "sample": f"same step at batch {batch}, {nb} timed steps after 1 warm-up, median "
+                                         f"{medb * 1e3:.1f} ms/step, torch.set_num_threads({threads})"}
     return out
 
 

@@ -292,7 +292,8 @@ int rfi_preprocess_gather(rfi_ctx* ctx, const void* planes, int planes_mem, int 
 
 /* ---- preprocessing, order-statistic branches (preprocessor.py:646-745) on device, for a stack of
  *      patches (n, ps_h, ps_w) already cut by the host:
- *      rfi_preprocess_real: REAL float64 input: optional median normalise (:646-670), stretch
+ *      rfi_preprocess_real: REAL float64 or float32 input (float32: every result rounded to float32, i.e. NumPy's
+ *      float32 arithmetic on a float32 array): optional median normalise (:646-670), stretch
  *      (0 none, 1 SQRT, 2 LOG10; infinities <- MAD of the patch's finite values, :672-706), optional second
  *      normalise, then the 3-channel extraction of :608-644 + ImageNet normalisation -> out_nhwc; when
  *      flags_out != NULL also the MAD flags of the PROCESSED patches (:708-745, |x - med| > sigma * MAD).

@@ -1302,9 +1302,9 @@ int rfi_preprocess_gather(rfi_ctx* ctx, const void* planes, int planes_mem, int 
 namespace {
 // med / mad of every patch of w (n x per doubles) over its non-NaN values -> d_med, d_mad
 void median_and_mad(rfi_ctx* ctx, const double* w, int n, int per, bool finite_only, double* d_med, double* d_mad,
-                    int* d_cnt) {
-    launch_patch_median(ctx, w, n, per, false, nullptr, finite_only, d_med, d_cnt);
-    launch_patch_median(ctx, w, n, per, true, d_med, finite_only, d_mad, nullptr);
+                    int* d_cnt, bool f32 = false) {
+    launch_patch_median(ctx, w, n, per, false, nullptr, finite_only, d_med, d_cnt, f32);
+    launch_patch_median(ctx, w, n, per, true, d_med, finite_only, d_mad, nullptr, f32);
 }
 }  // namespace
 
@@ -1312,8 +1312,10 @@ int rfi_preprocess_real(rfi_ctx* ctx, const void* patches, int patches_mem, int 
                         int stretch, int normalize_before, int normalize_after, double flag_sigma, float* out_nhwc,
                         int out_mem, uint8_t* flags_out, int flags_mem) {
     return guarded([&] {
-        RFI_REQUIRE(dtype == RFI_F64, "preprocess_real: input must be float64 (NumPy keeps float32 input in float32 "
-                                      "arithmetic; that case stays with the caller)");
+        RFI_REQUIRE(dtype == RFI_F64 || dtype == RFI_F32, "preprocess_real: input must be float64 or float32");
+        // float32 input: NumPy keeps it in float32 arithmetic (preprocessor.py:608-706 on a float32 array); here the values
+        // ride in doubles and every result is rounded to float32 (order_stats.hip)
+        const bool f32 = dtype == RFI_F32;
         RFI_REQUIRE(stretch >= 0 && stretch <= 2, "preprocess_real: stretch must be 0 (none), 1 (SQRT) or 2 (LOG10)");
         RFI_REQUIRE(n >= 0 && ps_h > 0 && ps_w > 0 && (n == 0 || (patches && out_nhwc)), "preprocess_real: bad argument");
         if (n == 0) return;
@@ -1327,13 +1329,13 @@ int rfi_preprocess_real(rfi_ctx* ctx, const void* patches, int patches_mem, int 
         int* d_cnt = reinterpret_cast<int*>(stat + 2 * (size_t)n);
         launch_to_abs_f64(ctx, in.dev, dtype, (int64_t)px, w);            // real dtypes: widening copy
         auto normalise = [&] {
-            launch_patch_median(ctx, w, n, per, false, nullptr, false, d_med, nullptr);
-            launch_scale_by_median(ctx, w, n, per, d_med);
+            launch_patch_median(ctx, w, n, per, false, nullptr, false, d_med, nullptr, f32);
+            launch_scale_by_median(ctx, w, n, per, d_med, f32);
         };
         if (normalize_before) normalise();
         if (stretch) {
-            launch_stretch(ctx, w, (int64_t)px, stretch);
-            median_and_mad(ctx, w, n, per, true, d_med, d_mad, d_cnt);
+            launch_stretch(ctx, w, (int64_t)px, stretch, f32);
+            median_and_mad(ctx, w, n, per, true, d_med, d_mad, d_cnt, f32);
             launch_replace_inf(ctx, w, n, per, d_mad, d_cnt);
         }
         if (normalize_after) normalise();
@@ -1343,16 +1345,24 @@ int rfi_preprocess_real(rfi_ctx* ctx, const void* patches, int patches_mem, int 
         if (out_mem == RFI_HOST) dout = static_cast<float*>(tmp_out = ctx->alloc(px * 3 * sizeof(float)));
         if (flags_out && flags_mem == RFI_HOST) dfl = static_cast<uint8_t*>(tmp_fl = ctx->alloc(px));
         if (flags_out) {
-            median_and_mad(ctx, w, n, per, false, d_med, d_mad, nullptr);
-            launch_mad_flags(ctx, w, n, per, d_med, d_mad, flag_sigma, dfl);
+            median_and_mad(ctx, w, n, per, false, d_med, d_mad, nullptr, f32);
+            launch_mad_flags(ctx, w, n, per, d_med, d_mad, flag_sigma, dfl, f32);
         }
         void* mm = ctx->get_scratch((size_t)n * 4 * sizeof(unsigned long long));
-        launch_preprocess(ctx, w, RFI_F64, n, ps_h, ps_w, static_cast<float*>(mm), dout);
+        float* w32 = nullptr;
+        if (f32) {                                  // the channel kernels' float32 form on the float32 values
+            w32 = static_cast<float*>(ctx->alloc(px * sizeof(float)));
+            launch_narrow_f32(ctx, w, (int64_t)px, w32);
+            launch_preprocess(ctx, w32, RFI_F32, n, ps_h, ps_w, static_cast<float*>(mm), dout);
+        } else {
+            launch_preprocess(ctx, w, RFI_F64, n, ps_h, ps_w, static_cast<float*>(mm), dout);
+        }
         if (tmp_out) RFI_CHECK_HIP(hipMemcpyAsync(out_nhwc, dout, px * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         if (tmp_fl) RFI_CHECK_HIP(hipMemcpyAsync(flags_out, dfl, px, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         ctx->release(w);
         ctx->release(stat);
+        if (w32) ctx->release(w32);
         if (tmp_out) ctx->release(tmp_out);
         if (tmp_fl) ctx->release(tmp_fl);
     });

@@ -270,13 +270,16 @@ void launch_preprocess(rfi_ctx* ctx, const void* patches, int dtype, int n, int 
 // gather form (table_dev != null): `patches` are the n_planes x C x T waterfall planes and patch i is
 // the ph x pw tile table_dev[i] names; the same map serves the labels and the blank-patch test
 // order statistics / real-input branch (order_stats.hip); v: [n][per] doubles on the device
+// f32 (all of these): the doubles hold float32 values and every arithmetic result is rounded to float32 -- NumPy's
+// float32 arithmetic for float32 input
 void launch_patch_median(rfi_ctx* ctx, const double* v, int n, int per, bool absdev, const double* centre,
-                         bool finite_only, double* out, int* cnt_out);
-void launch_scale_by_median(rfi_ctx* ctx, double* v, int n, int per, const double* med);
-void launch_stretch(rfi_ctx* ctx, double* v, int64_t total, int kind);          // 1 SQRT, 2 LOG10 of |v|
+                         bool finite_only, double* out, int* cnt_out, bool f32 = false);
+void launch_scale_by_median(rfi_ctx* ctx, double* v, int n, int per, const double* med, bool f32 = false);
+void launch_stretch(rfi_ctx* ctx, double* v, int64_t total, int kind, bool f32 = false);          // 1 SQRT, 2 LOG10 of |v|
 void launch_replace_inf(rfi_ctx* ctx, double* v, int n, int per, const double* mad, const int* nfinite);
 void launch_mad_flags(rfi_ctx* ctx, const double* v, int n, int per, const double* med, const double* mad,
-                      double sigma, uint8_t* flags);
+                      double sigma, uint8_t* flags, bool f32 = false);
+void launch_narrow_f32(rfi_ctx* ctx, const double* src, int64_t total, float* dst);
 void launch_to_abs_f64(rfi_ctx* ctx, const void* src, int dtype, int64_t total, double* dst);
 void launch_synth(rfi_ctx* ctx, unsigned long long seed, int n_samples, int n_pol, int C, int T, double noise,
                   int bandpass, int order, double corr, const rfi_event* events_dev, const int* offsets_dev,

@@ -255,8 +255,9 @@ class Preprocessor:
         is_real = not np.iscomplexobj(patches)
         need_mad = pflags is None and not inference_mode
         images = None
-        # float32 real input keeps NumPy's float32 arithmetic (host); the device branch computes in float64
-        if on_device_tiling and len(patches) and not (is_real and patches.dtype != np.float64):
+        # float64 real input is processed in float64 on the device, float32 real input in float32 arithmetic (every result
+        # rounded to float32: what NumPy does on a float32 array, preprocessor.py:608-706); other real dtypes: host
+        if on_device_tiling and len(patches) and not (is_real and patches.dtype not in (np.float64, np.float32)):
             # order-statistic branches on the GPU: the real-input pipeline (median normalise, stretch,
             # MAD flags, channels) in one call; for flag-less complex input the MAD flags of |z|
             if is_real:
@@ -301,8 +302,8 @@ class Preprocessor:
     # ---- order-statistic branches on the GPU (librfi_hip.so rfi_preprocess_real / rfi_mad_flags)
     def _real_on_device(self, patches, stretch, before, after, sigma):
         n, ph, pw = patches.shape
-        code = F64
-        patches = np.ascontiguousarray(patches, dtype=np.float64)
+        code = F32 if patches.dtype == np.float32 else F64
+        patches = np.ascontiguousarray(patches, dtype=np.float32 if code == F32 else np.float64)
         images = np.empty((n, ph, pw, 3), dtype=np.float32)
         flags = np.empty((n, ph, pw), dtype=np.uint8) if sigma is not None else None
         ctx = Context.get(self._device)

@@ -92,3 +92,27 @@ def test_cnn3_width64_vs_oracle():
     fwd, step = m.algorithmic_flops(1, 128, 128)
     assert fwd == pytest.approx(2 * 16384 * (27 * 64 + 576 * 64 + 64))          # 1.27 GFLOP, SURVEY 8a A9
     assert step == pytest.approx(3 * fwd - 2 * 16384 * 27 * 64)
+
+
+def test_cnn3_at_the_configs1_shape_vs_oracle():
+    """BASELINE configs[1] as written: the 3-layer CNN (width 64) on batch 64 x 128 x 128 x 3, one training step in the
+    float32 arithmetic against oracle/cnn_ref.py on the same seeded inputs (a float32 CPU step of 3.7 GFLOP per patch:
+    tens of seconds on the host).  Loss, logits, every gradient tensor, the clipped gradient norm."""
+    st = cnn_ref.init_state(3, 1, 64, seed=21)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(64, 128, 128, 3, generator=g)
+    y = (torch.rand(64, 128, 128, generator=g) > 0.85).to(torch.uint8)
+    y[:, :, 60:64] = 1
+    xo, yo = unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1)
+    l32, lg32, g32, _ = cnn_ref.loss_and_grads(st, xo, yo)
+    m = SimpleCNN(3, 1, 64).load_state_dict(st).train()
+    loss = m.forward_backward(x, y)
+    assert loss == pytest.approx(float(l32), abs=5e-6)
+    want = lg32.permute(0, 2, 3, 1).reshape(-1).numpy()
+    np.testing.assert_allclose(m.debug_tensor("logits"), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
+    for k in g32:
+        ref = g32[k].numpy()
+        # two float32 summation orders over 64 x 16384 pixels: relative L2 at the 1e-5 level
+        assert np.linalg.norm(m.grad(k) - ref) <= 5e-5 * np.linalg.norm(ref) + 1e-9, k
+    total, _ = unet_ref.clip_coefficient(g32, 1.0)
+    assert m.apply_gradients(lr=1e-4, weight_decay=1e-5) == pytest.approx(float(total), rel=1e-4)

@@ -160,7 +160,7 @@ def test_real_input_branch_on_device_equals_host(kw, dtype):
     np.random.seed(3)
     a = Preprocessor(x).create_dataset(patch_size=32, flag_sigma=4, on_device_tiling=False, **kw)
     np.random.seed(3)
-    b = Preprocessor(x).create_dataset(patch_size=32, flag_sigma=4, **kw)      # float32: NumPy float32 math, host
+    b = Preprocessor(x).create_dataset(patch_size=32, flag_sigma=4, **kw)      # float32: float32 arithmetic on the device too
     assert len(a) == len(b) > 0
     np.testing.assert_array_equal(a.labels.numpy(), b.labels.numpy())
     np.testing.assert_allclose(a.images.numpy(), b.images.numpy(), rtol=0, atol=2e-6, equal_nan=True)
