@@ -33,11 +33,12 @@ PEAK_HBM_GBS = 8000.0
 # is credited with: the default float32 path issues six v_mfma_f32_32x32x16_bf16 per 32x32x16 block product
 # (3 x bf16 splitting), so its ceiling is 2516 / 6 = 419.3 TFLOP/s of float32 work.
 PEAK_BY_DTYPE = {"f32": PEAK_BF16_MFMA_TFLOPS / 6, "f32planes": PEAK_BF16_MFMA_TFLOPS / 6, "f32mfma": PEAK_F32_MFMA_TFLOPS,
-                 "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16regs": PEAK_BF16_MFMA_TFLOPS / 2}
+                 "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16regs": PEAK_BF16_MFMA_TFLOPS}
 INSTR_BY_DTYPE = {"f32": "6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block product (float32 by 3 x bf16 splitting)",
                   "f32planes": "6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block product (pre-split plane tensors)",
                   "f32mfma": "v_mfma_f32_32x32x2_f32", "bf16": "v_mfma_f32_32x32x16_bf16",
-                  "bf16regs": "v_mfma_f32_32x32x8_bf16 (half the rate of the 32x32x16 form: 1258 TFLOP/s)"}
+                  "bf16regs": "v_mfma_f32_32x32x16_bf16 in the 3x3 stride-1 convs (conv_ws.hip, operands rounded at staging); the "
+                              "stride-2 / 1x1 / weight-gradient kernels of this mode still issue v_mfma_f32_32x32x8_bf16"}
 MODE_BY_DTYPE = {"f32": "float32", "f32mfma": "float32_mfma", "bf16": "bfloat16", "f32planes": "float32_planes",
                  "bf16regs": "bfloat16_regs"}
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RFI_HIP_LIB") or os.path.join(_HERE, "librfi_hip.so")
 HOST, DEVICE = 0, 1
 C128, C64, F64, F32 = 0, 1, 2, 3
 U8, FLOAT32 = 0, 1
-IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_BF16, IMPL_MFMA_BF16X3, IMPL_PLANES_X3, IMPL_PLANES_BF16, IMPL_WS_X3 = 0, 1, 2, 3, 4, 5, 6, 7
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_BF16, IMPL_MFMA_BF16X3, IMPL_PLANES_X3, IMPL_PLANES_BF16, IMPL_WS_X3, IMPL_WS_BF16 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class Hyper(C.Structure):

@@ -766,28 +766,35 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
         a.wB3 = nullptr;                // (this implementation was asked for by name)
         impl = IMPL_MFMA;
     }
-    if (impl == IMPL_WS_X3) {           // kernel-level API / tests: a temporary B-operand-order copy of the filters
+    if (impl == IMPL_WS_X3 || impl == IMPL_WS_BF16) {       // kernel-level API / tests: a temporary B-operand-order copy of the filters
+        const int P = impl == IMPL_WS_X3 ? 3 : 1;
         const bool gw = !conv_ws_eligible(a) && gemm_ws_eligible(a);
         RFI_REQUIRE(gw || conv_ws_eligible(a), "conv: shape not eligible for the wave-specialised kernels");
-        a.bf16x3 = true;
+        RFI_REQUIRE(!gw || P == 3, "conv: the wave-specialised GEMM kernel exists in the 3 x bf16 arithmetic only");
+        a.bf16x3 = P == 3;
+        a.bf16 = P == 1;
         // conv_ws: [9][Cout][Cin]; gemm_ws: the transposed conv forward as ONE tap of 4 Cout channels, its input gradient
         // as four taps, a 1x1 conv as one tap
         const int taps = gw ? (a.R == 2 ? 4 : 1) : 9, cout = gw && a.zgroups == 4 ? 4 * a.Cout : a.Cout;
-        const size_t we = wb_elems(taps, cout, a.Cin, 0, 3);
+        const size_t we = wb_elems(taps, cout, a.Cin, 0, P);
         bf16_t* wb = static_cast<bf16_t*>(ctx->alloc(we * 2 + 64));
         struct Free {
             rfi_ctx* c; void* p;
             ~Free() { (void)hipStreamSynchronize(c->stream); try { c->release(p); } catch (...) {} }
         } fr{ctx, wb};
-        launch_weights_to_wb_one(ctx, WBDesc{a.w, wb, taps, cout, a.Cin, {a.Cin, 0}, 3});
+        launch_weights_to_wb_one(ctx, WBDesc{a.w, wb, taps, cout, a.Cin, {a.Cin, 0}, P});
         if (gw) launch_gemm_ws(ctx, a, wb);
-        else launch_conv_ws(ctx, a, wb);
+        else launch_conv_ws(ctx, a, wb, P);
         return;
     }
     static const bool no_ws = getenv("RFI_NO_WS") != nullptr;                    // A/B runs: round 2's kernels
     static const bool no_gw = getenv("RFI_NO_GW") != nullptr;
     if (impl == IMPL_AUTO && a.bf16x3 && a.wB3 && !no_ws && conv_ws_eligible(a)) {
-        launch_conv_ws(ctx, a, a.wB3);
+        launch_conv_ws(ctx, a, a.wB3, 3);
+        return;
+    }
+    if (impl == IMPL_AUTO && a.bf16 && !bf16_k16() && a.wB1 && !no_ws && conv_ws_eligible(a)) {
+        launch_conv_ws(ctx, a, a.wB1, 1);
         return;
     }
     if (impl == IMPL_AUTO && a.bf16x3 && a.wB3 && !no_ws && !no_gw && gemm_ws_eligible(a)) {

@@ -49,15 +49,17 @@ struct WsDev {
     unsigned long long* stamps;       // RFI_DIAG_STAMPS build: per-wave cycle sums
 };
 
-constexpr int ROWB = 112;             // bytes per halo pixel in LDS
+// bytes per halo pixel in LDS: the P planes of a 16-channel chunk (32 B each) + 16 B of padding (odd 16-byte-slot stride:
+// the ds_read_b128 of 32 consecutive pixels is conflict free)
+template <int P> constexpr int ROWB = 32 * P + 16;
 
 // ADB: two halo buffers (where the LDS has room: 32-channel blocks) -- the producers write item q + 1 while the consumers
 // read item q, one barrier per item; otherwise ONE halo buffer, written between two barriers of an item
-template <int TB, int TH, int TW, int NTL, bool ADB>
+template <int TB, int TH, int TW, int NTL, bool ADB, int P>
 struct WsCfg {
     static constexpr int HH = TH + 2, HW = TW + 2, HPI = HH * HW, HP = TB * HPI;
-    static constexpr int A_BYTES = (HP * ROWB + 1023) & ~1023;
-    static constexpr int NPIECE = 27 * NTL;                          // 1-KiB pieces of a filter chunk: 9 taps x NTL blocks x 3 planes
+    static constexpr int A_BYTES = (HP * ROWB<P> + 1023) & ~1023;
+    static constexpr int NPIECE = 9 * NTL * P;                       // 1-KiB pieces of a filter chunk: 9 taps x NTL blocks x P planes
     static constexpr int B_BYTES = NPIECE * 1024;
     static constexpr int B_ITEMS = (NPIECE + 3) / 4;                 // pieces per producer wave
     static constexpr int HALO_ITEMS = (HP * 4 + 255) / 256;          // float4 loads per producer thread and item
@@ -79,9 +81,12 @@ struct WsCfg {
 
 // XF: the load transform -- 0 none, 1 relu(x * scale + shift), 2 x * scale + shift followed by max(v, v * slope) (LeakyReLU;
 // slope 1: no activation)
-template <int TB, int TH, int TW, int NTL, int XF, bool ADB>
+// P: 3 float32 by three bf16 pieces (six MFMAs per block product); 1 bf16 operands (the float32-tensor bf16 mode: values
+// rounded once, RNE, at staging; one MFMA per block product)
+template <int TB, int TH, int TW, int NTL, int XF, bool ADB, int P>
 __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
-    using C = WsCfg<TB, TH, TW, NTL, ADB>;
+    using C = WsCfg<TB, TH, TW, NTL, ADB, P>;
+    constexpr int RB = ROWB<P>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef RFI_DIAG_STAMPS
     unsigned long long st_[4] = {0, 0, 0, 0};
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
         };
         u32x4 raw[C::HALO_ITEMS];                        // the item being loaded
         f32x4 screg = {1.f, 1.f, 1.f, 1.f}, shreg = {0.f, 0.f, 0.f, 0.f};
-        unsigned pl[C::HALO_ITEMS][6];                   // its three bf16 planes (4 channels each), ready for LDS
+        unsigned pl[C::HALO_ITEMS][2 * P];               // its P bf16 planes (4 channels each), ready for LDS
         // the loads of an item issue back to back, the coefficient loads first: the youngest HALO_ITEMS vector-memory
         // operations of the wave are then the halo loads, which the vmcnt arithmetic below relies on
         auto issue_loads = [&](int c0) {
@@ -170,25 +175,29 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                 if constexpr (XF != 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float t = __builtin_fmaf(v[e], screg[e], shreg[e]);
+                        float t = v[e] * screg[e] + shreg[e];     // (unfused, -ffp-contract=off: the same values every other consumer of this tensor computes)
                         if constexpr (XF == 1) asm("v_max_f32 %0, 0, %1" : "=v"(t) : "v"(t));
                         else t = __builtin_fmaxf(t, t * d.slope);
                         v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & vmsk[it]);
                     }
                 }
-                split_pair(v.x, v.y, pl[it][0], pl[it][2], pl[it][4]);
-                split_pair(v.z, v.w, pl[it][1], pl[it][3], pl[it][5]);
+                if constexpr (P == 3) {
+                    split_pair(v.x, v.y, pl[it][0], pl[it][2], pl[it][4]);
+                    split_pair(v.z, v.w, pl[it][1], pl[it][3], pl[it][5]);
+                } else {
+                    pl[it][0] = cvt_pair(v.x, v.y);
+                    pl[it][1] = cvt_pair(v.z, v.w);
+                }
             }
         };
         auto write_all = [&](int buf) {
-            unsigned char* const sA = smem + buf * C::A_BYTES + (ptid >> 2) * ROWB + (ptid & 3) * 8;
+            unsigned char* const sA = smem + buf * C::A_BYTES + (ptid >> 2) * RB + (ptid & 3) * 8;
 #pragma unroll
             for (int it = 0; it < C::HALO_ITEMS; ++it) {
                 if (ptid + it * 256 < C::HP * 4) {
-                    unsigned char* row = sA + it * 64 * ROWB;
-                    *reinterpret_cast<u32x2*>(row) = u32x2{pl[it][0], pl[it][1]};
-                    *reinterpret_cast<u32x2*>(row + 32) = u32x2{pl[it][2], pl[it][3]};
-                    *reinterpret_cast<u32x2*>(row + 64) = u32x2{pl[it][4], pl[it][5]};
+                    unsigned char* row = sA + it * 64 * RB;
+#pragma unroll
+                    for (int p = 0; p < P; ++p) *reinterpret_cast<u32x2*>(row + 32 * p) = u32x2{pl[it][2 * p], pl[it][2 * p + 1]};
                 }
             }
         };
@@ -202,9 +211,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
             for (int i = 0; i < C::B_ITEMS; ++i) {
                 const int p = pw + 4 * i;
                 if (p < C::NPIECE) {
-                    const int tap = p / (3 * NTL), r = p - tap * (3 * NTL), nt = r / 3, plane = r - nt * 3;
+                    const int tap = p / (P * NTL), r = p - tap * (P * NTL), nt = r / P, plane = r - nt * P;
                     const int cb = cb0 + nt < d.ncb ? cb0 + nt : d.ncb - 1;
-                    const unsigned off = (unsigned)((((tap * nkc + kc) * d.ncb + cb) * 3 + plane) * 1024 + lane * 16);
+                    const unsigned off = (unsigned)((((tap * nkc + kc) * d.ncb + cb) * P + plane) * 1024 + lane * 16);
                     __builtin_amdgcn_global_load_lds((gbl_void*)(wb + off), (lds_void*)(sB + p * 1024), 16, 0, 0);
                 }
             }
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
         for (int mt = 0; mt < 2; ++mt) {
             const int p = cw * 64 + mt * 32 + li;
             const int b = p / (TH * TW), r = p % (TH * TW);
-            a_base[mt] = ((b * C::HH + r / TW) * C::HW + r % TW) * ROWB + lh * 16;
+            a_base[mt] = ((b * C::HH + r / TW) * C::HW + r % TW) * RB + lh * 16;
         }
         const int b_base = lane * 16;
         float bias[NTL];
@@ -345,18 +354,18 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
             constexpr bool PEND = decltype(pend_c)::value, FIRST = decltype(first_c)::value;
             const unsigned tile_off = (unsigned)(((pt.n * d.H + pt.oy0) * d.W + pt.ox0) * d.y_ps);
             // software pipeline over the taps: the fragments of tap t + 1 are read BEFORE the MFMAs of tap t issue
-            bf16x8 afr[2][2][3], bfr[2][NTL][3];
-            auto load_frags = [&](int tap, bf16x8 (&af)[2][3], bf16x8 (&bf)[NTL][3]) {
+            bf16x8 afr[2][2][P], bfr[2][NTL][P];
+            auto load_frags = [&](int tap, bf16x8 (&af)[2][P], bf16x8 (&bf)[NTL][P]) {
                 const int tr = tap / 3, ts = tap % 3;
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[nt][p] = *reinterpret_cast<const bf16x8*>(sB + ((tap * NTL + nt) * 3 + p) * 1024);
+                    for (int p = 0; p < P; ++p) bf[nt][p] = *reinterpret_cast<const bf16x8*>(sB + ((tap * NTL + nt) * P + p) * 1024);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        af[mt][p] = *reinterpret_cast<const bf16x8*>(sA + a_base[mt] + (tr * C::HW + ts) * ROWB + p * 32);
+                    for (int p = 0; p < P; ++p)
+                        af[mt][p] = *reinterpret_cast<const bf16x8*>(sA + a_base[mt] + (tr * C::HW + ts) * RB + p * 32);
             };
             load_frags(0, afr[0], bfr[0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -371,7 +380,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                         if (FIRST && tap == 0)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) c[r] = 0.0f;
-                        acc[mt][nt] = mma3(afr[tap & 1][mt], bfr[tap & 1][nt], c);
+                        if constexpr (P == 3) acc[mt][nt] = mma3(afr[tap & 1][mt], bfr[tap & 1][nt], c);
+                        else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tap & 1][mt][0], bfr[tap & 1][nt][0], c, 0, 0, 0);
                     }
                 if constexpr (PEND && DEFER) {
 #pragma unroll
@@ -383,11 +393,17 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                 // issue order of this step: the LDS reads of tap t + 1 (and the pending epilogue's stores and sums) go BETWEEN
                 // the MFMAs of tap t, one or two per MFMA -- issued as one burst in front of them they leave the matrix pipe
                 // idle for most of the burst (12 reads ~ 100 cycles against one 32-cycle MFMA in flight)
-                constexpr int NM = 12 * NTL, NR = 3 * (2 + NTL);
+                constexpr int NM = 2 * NTL * (P == 3 ? 6 : 1), NR = P * (2 + NTL);
 #pragma unroll
                 for (int i = 0; i < NM; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
-                    if (tap + 1 < 9 && i * NR / NM != (i + 1) * NR / NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+                    if (tap + 1 < 9) {                   // the LDS reads that fall to this MFMA (the builtin wants literals)
+                        const int cnt = (i + 1) * NR / NM - i * NR / NM;
+                        if (cnt == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        else if (cnt == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else if (cnt == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                        else if (cnt >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    }
                     if constexpr (PEND && DEFER) {
                         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                  // two vector ALU instructions
                         if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // a store every third MFMA
@@ -512,10 +528,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
     }
 }
 
-template <int TB, int TH, int TW, int NTL, int XF>
+template <int TB, int TH, int TW, int NTL, int XF, int P>
 void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
-    constexpr bool ADB = NTL == 1;
-    using C = WsCfg<TB, TH, TW, NTL, ADB>;
+    constexpr bool ADB = NTL == 1 || P == 1;     // two halo buffers wherever the LDS has room
+    using C = WsCfg<TB, TH, TW, NTL, ADB, P>;
     const int ntiles = (int)(cdiv(a.N, TB) * cdiv(a.H, TH) * cdiv(a.W, TW));
     const int ycols = (int)cdiv(d.ncb, NTL);
     // one workgroup per CU: about 256 in total, a multiple of 8 along x, tiles spread evenly over the workgroups of
@@ -530,7 +546,7 @@ void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
     d.stats = a.stats;
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<TB, TH, TW, NTL, XF, ADB>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<TB, TH, TW, NTL, XF, ADB, P>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     });
 #ifdef RFI_DIAG_STAMPS
@@ -538,7 +554,7 @@ void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
         const size_t nw = (size_t)GX * ycols * 8;
         RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d.stamps), nw * 64));
         RFI_CHECK_HIP(hipMemsetAsync(d.stamps, 0, nw * 64, ctx->stream));
-        hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
+        hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB, P>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
         std::vector<unsigned long long> hs(nw * 8);
         RFI_CHECK_HIP(hipMemcpyAsync(hs.data(), d.stamps, nw * 64, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -554,15 +570,21 @@ void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
         return;
     }
 #endif
-    hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
+    hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB, P>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
     check_launch("conv_ws");
 }
 
-template <int NTL, int XF>
+template <int NTL, int XF, int P>
 void dispatch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
-    if (a.W >= 32) launch_ws<1, 8, 32, NTL, XF>(ctx, a, d);
-    else if (a.W >= 16) launch_ws<1, 16, 16, NTL, XF>(ctx, a, d);
-    else launch_ws<4, 8, 8, NTL, XF>(ctx, a, d);
+    if (a.W >= 32) launch_ws<1, 8, 32, NTL, XF, P>(ctx, a, d);
+    else if (a.W >= 16) launch_ws<1, 16, 16, NTL, XF, P>(ctx, a, d);
+    else launch_ws<4, 8, 8, NTL, XF, P>(ctx, a, d);
+}
+template <int NTL, int P>
+void dispatch_xf(rfi_ctx* ctx, ConvArgs& a, WsDev& d, int xf) {
+    if (xf == 0) dispatch_ws<NTL, 0, P>(ctx, a, d);
+    else if (xf == 1) dispatch_ws<NTL, 1, P>(ctx, a, d);
+    else dispatch_ws<NTL, 2, P>(ctx, a, d);
 }
 
 }  // namespace
@@ -579,18 +601,20 @@ bool conv_ws_eligible(const ConvArgs& a) {
     return true;
 }
 
-// wB3: the layer's filters in B-operand order with P = 3 (launch_weights_to_wb; one K segment of Cin channels)
-void launch_conv_ws(rfi_ctx* ctx, ConvArgs& a, const bf16_t* wB3) {
+// wB: the layer's filters in B-operand order with P planes (launch_weights_to_wb; one K segment of Cin channels).
+// P = 3: the float32-by-3xbf16 arithmetic; P = 1: bf16 operands (ConvArgs::bf16 on float32 tensors)
+void launch_conv_ws(rfi_ctx* ctx, ConvArgs& a, const bf16_t* wB, int P) {
     RFI_REQUIRE(conv_ws_eligible(a), "conv_ws: shape not eligible");
+    RFI_REQUIRE(P == 1 || P == 3, "conv_ws: planes must be 1 or 3");
     WsDev d;
     d.x = a.x.p; d.x_ps = a.x.pstride;
     d.x_bytes = (unsigned)((int64_t)a.N * a.H * a.W * a.x.pstride * 4);
     d.scale = a.xf.scale; d.shift = a.xf.shift;
     d.slope = a.xf.relu == 0 ? 1.0f : a.xf.slope;
     d.N = a.N; d.H = a.H; d.W = a.W; d.Cin = a.Cin; d.Cout = a.Cout;
-    d.wB = wB3;
+    d.wB = wB;
     d.nkc = plane_chunks(a.Cin); d.ncb = (a.Cout + 31) / 32;
-    RFI_REQUIRE((int64_t)wb_elems(9, a.Cout, a.Cin, 0, 3) * 2 < ((int64_t)1 << 32), "conv_ws: filter tensor too large");
+    RFI_REQUIRE((int64_t)wb_elems(9, a.Cout, a.Cin, 0, P) * 2 < ((int64_t)1 << 32), "conv_ws: filter tensor too large");
     d.bias = a.bias;
     d.y = a.y.p; d.y_ps = a.y.pstride;
     d.stats = nullptr;
@@ -603,23 +627,24 @@ void launch_conv_ws(rfi_ctx* ctx, ConvArgs& a, const bf16_t* wB3) {
     std::string label;
     if (ctx->profiling)
         label = "conv_ws N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" + std::to_string(a.W) + " " +
-                std::to_string(a.Cin) + "->" + std::to_string(a.Cout) + (a.xf.scale ? " xf" : "") + " 3xbf16";
+                std::to_string(a.Cin) + "->" + std::to_string(a.Cout) + (a.xf.scale ? " xf" : "") + (P == 3 ? " 3xbf16" : " bf16");
     const double bytes = 4.0 * ((double)a.N * a.H * a.W * a.Cin + 9.0 * a.Cin * a.Cout) + 4.0 * a.N * a.H * a.W * a.Cout;
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, bytes, label);
-    static const int ntl_max = getenv("RFI_WS_NTL") ? atoi(getenv("RFI_WS_NTL")) : 2;          // A/B runs
+    static const int ntl_max = getenv("RFI_WS_NTL") ? atoi(getenv("RFI_WS_NTL")) : 4;          // A/B runs
     const int xf = !a.xf.scale ? 0 : (a.xf.relu == 1 || (a.xf.relu == 2 && a.xf.slope == 0.0f)) ? 1 : 2;
-    // 64-channel blocks halve the producers' work per MFMA; they are used where the grid still covers the chip
-    // (tiles x 64-channel blocks >= ~256 workgroups); below that the narrower block doubles the workgroups
+    // wider channel blocks cut the producers' work per MFMA (64 channels for the split arithmetic; 128 where one MFMA
+    // stands for a block product); they are used where the grid still covers the chip (tiles x blocks >= ~256 workgroups)
     const int64_t tiles = (a.W >= 16 ? (int64_t)a.N : cdiv(a.N, 4)) * cdiv(a.H, a.W >= 32 ? 8 : a.W >= 16 ? 16 : 8) * cdiv(a.W, a.W >= 32 ? 32 : a.W >= 16 ? 16 : 8);
-    const bool wide = a.Cout > 32 && ntl_max >= 2 && tiles * cdiv(d.ncb, 2) >= 224;
-    if (wide) {
-        if (xf == 0) dispatch_ws<2, 0>(ctx, a, d);
-        else if (xf == 1) dispatch_ws<2, 1>(ctx, a, d);
-        else dispatch_ws<2, 2>(ctx, a, d);
+    int ntl = 1;
+    if (a.Cout > 32 && ntl_max >= 2 && tiles * cdiv(d.ncb, 2) >= 224) ntl = 2;
+    if (P == 1 && a.Cout > 64 && ntl_max >= 4 && tiles * cdiv(d.ncb, 4) >= 224) ntl = 4;
+    if (P == 3) {
+        if (ntl == 2) dispatch_xf<2, 3>(ctx, a, d, xf);
+        else dispatch_xf<1, 3>(ctx, a, d, xf);
     } else {
-        if (xf == 0) dispatch_ws<1, 0>(ctx, a, d);
-        else if (xf == 1) dispatch_ws<1, 1>(ctx, a, d);
-        else dispatch_ws<1, 2>(ctx, a, d);
+        if (ntl == 4) dispatch_xf<4, 1>(ctx, a, d, xf);
+        else if (ntl == 2) dispatch_xf<2, 1>(ctx, a, d, xf);
+        else dispatch_xf<1, 1>(ctx, a, d, xf);
     }
 }
 

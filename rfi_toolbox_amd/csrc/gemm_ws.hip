@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GwDev d) {
                 if constexpr (XF != 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float t = __builtin_fmaf(v[e], screg[e], shreg[e]);
+                        float t = v[e] * screg[e] + shreg[e];     // (unfused, -ffp-contract=off: the same values every other consumer of this tensor computes)
                         if constexpr (XF == 1) asm("v_max_f32 %0, 0, %1" : "=v"(t) : "v"(t));
                         else t = __builtin_fmaxf(t, t * d.slope);
                         v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & vmsk[it]);
@@ -379,12 +379,16 @@ void launch_gemm_ws(rfi_ctx* ctx, ConvArgs& a, const bf16_t* wB3) {
     const double bytes = 4.0 * ((double)a.N * a.Hin * a.Win * a.Cin + (double)d.ntap * a.Cin * d.Ngemm) + 4.0 * d.M * (double)d.Ngemm;
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, bytes, label);
     const int xf = !a.xf.scale ? 0 : (a.xf.relu == 1 || (a.xf.relu == 2 && a.xf.slope == 0.0f)) ? 1 : 2;
-    // 8 blocks per workgroup where the grid still covers the chip, else 4
+    // 8 blocks per workgroup where the grid still covers the chip, else 4 (2 for a 64-channel output)
     const bool wide = d.ncb > 4 && cdiv(d.M, TM) * cdiv(d.ncb, 8) >= 192;
     if (wide) {
         if (xf == 0) launch_gw<8, 0>(ctx, d);
         else if (xf == 1) launch_gw<8, 1>(ctx, d);
         else launch_gw<8, 2>(ctx, d);
+    } else if (d.ncb <= 2) {
+        if (xf == 0) launch_gw<2, 0>(ctx, d);
+        else if (xf == 1) launch_gw<2, 1>(ctx, d);
+        else launch_gw<2, 2>(ctx, d);
     } else {
         if (xf == 0) launch_gw<4, 0>(ctx, d);
         else if (xf == 1) launch_gw<4, 1>(ctx, d);

@@ -47,6 +47,7 @@ struct ConvArgs {
     const unsigned short* wB3 = nullptr;   // 3 x bf16 mode, 3x3 stride-1 convs: the same filters in MFMA B-operand order with three
                                       // planes (planes.hpp, launch_weights_to_wb, one K segment): the wave-specialised
                                       // kernel (conv_ws.hip) runs where this is set and the shape is eligible
+    const unsigned short* wB1 = nullptr;   // bf16 mode on float32 tensors (`bf16`): the same with ONE plane (bf16-rounded filters)
     const float* bias = nullptr;      // [Cout] or null
     MutView y;
     int Hout = 0, Wout = 0;           // spatial size of the tensor y points into
@@ -83,11 +84,12 @@ struct ConvArgs {
 
 // 5 / 6: the plane kernels (planes.hpp) in the 3 x bf16 / bf16 arithmetic; callers holding float32 tensors get
 // temporary plane copies (kernel-level ABI, tests)
-// 7: the wave-specialised 3 x bf16 kernel (conv_ws.hip); callers without ConvArgs::wB3 get a temporary filter copy
+// 7 / 8: the wave-specialised kernels (conv_ws.hip, gemm_ws.hip) in the 3 x bf16 / the bf16 arithmetic; callers without
+// ConvArgs::wB3 / wB1 get a temporary filter copy
 enum ConvImpl { IMPL_AUTO = 0, IMPL_DIRECT = 1, IMPL_MFMA = 2, IMPL_MFMA_BF16 = 3, IMPL_MFMA_BF16X3 = 4,
-                IMPL_PLANES_X3 = 5, IMPL_PLANES_BF16 = 6, IMPL_WS_X3 = 7 };
+                IMPL_PLANES_X3 = 5, IMPL_PLANES_BF16 = 6, IMPL_WS_X3 = 7, IMPL_WS_BF16 = 8 };
 bool conv_ws_eligible(const ConvArgs& a);
-void launch_conv_ws(rfi_ctx* ctx, ConvArgs& a, const unsigned short* wB3);
+void launch_conv_ws(rfi_ctx* ctx, ConvArgs& a, const unsigned short* wB, int P);
 bool gemm_ws_eligible(const ConvArgs& a);        // gemm_ws.hip: transposed conv (k2, s2) forward / input gradient, 1x1 convs
 void launch_gemm_ws(rfi_ctx* ctx, ConvArgs& a, const unsigned short* wB3);
 

@@ -351,7 +351,7 @@ void rfi_model::prepare(int n, int h, int w) {
 }
 
 void rfi_model::refresh_dgrad_weights() {
-    if (!wd_dirty && (!use_w3() || x3_fresh)) return;
+    if (!wd_dirty && (!use_w3() || x3_fresh) && ws_P == ws_need()) return;
     if (!relayout_descs) {          // one descriptor per conv-like layer, built once
         std::vector<RelayoutDesc> h;
         relayout_bytes = 0;
@@ -409,8 +409,8 @@ void rfi_model::refresh_dgrad_weights() {
         }
         launch_weights_to_x3_batched(ctx, static_cast<const X3Desc*>(x3_descs), x3_n, x3_bytes);
         x3_fresh = true;
-        if (compute_x3 && !planesP) refresh_ws_weights();
     }
+    refresh_ws_weights(ws_need());
     if (arch == 2) refresh_resnet_weights();               // 2x2 forms of the stride-2 filters
     if (planesP && arch == 0) refresh_plane_weights();     // B-operand-order filters of the plane kernels
     wd_dirty = false;
@@ -418,17 +418,28 @@ void rfi_model::refresh_dgrad_weights() {
 
 // filters of every 3x3 stride-1 layer in MFMA B-operand order with three planes (conv_ws.hip), both directions, rebuilt
 // with the other derived copies after each optimiser step by ONE batched launch.  Callers find them by the layer's
-// pre-split record pointer (ws_of(ConvArgs::w3)), which every model's conv helper already passes around
-void rfi_model::refresh_ws_weights() {
+// float32 filter pointer (ws_set(ConvArgs) looks up ConvArgs::w), which every model's conv helper already passes around
+void rfi_model::refresh_ws_weights(int P) {
+    if (P != ws_P) {                  // another arithmetic: its copies have another size
+        if (ws_pool) { ctx->release(ws_pool); ws_pool = nullptr; }
+        if (ws_descs) { ctx->release(ws_descs); ws_descs = nullptr; }
+        ws_by_w.clear();
+        ws_n = 0;
+        ws_P = P;
+    }
+    if (P == 0) return;
     if (!ws_pool) {
+        // conv_ws: 3x3 stride-1 layers with channels % 16 == 0; gemm_ws (P = 3): the transposed convs
+        auto conv_f = [&](const ConvBN& c) { return c.R == 3 && c.stride == 1 && c.cin_p % 16 == 0; };
+        auto conv_d = [&](const ConvBN& c) { return c.R == 3 && c.stride == 1 && c.cout % 16 == 0; };
+        auto up_ok = [&](const UpConv& u) { return P == 3 && u.cin % 16 == 0 && u.cout % 32 == 0; };
         size_t need = 0;
         for (const ConvBN& c : convs) {
-            if (c.R != 3 || c.stride != 1) continue;
-            if (c.cin_p % 16 == 0) need += wb_elems(9, c.cout, c.cin_p, 0, 3) + 32;
-            if (c.cout % 16 == 0) need += wb_elems(9, c.cin_p, c.cout, 0, 3) + 32;
+            if (conv_f(c)) need += wb_elems(9, c.cout, c.cin_p, 0, P) + 32;
+            if (conv_d(c)) need += wb_elems(9, c.cin_p, c.cout, 0, P) + 32;
         }
         for (const UpConv& u : ups)
-            if (u.cin % 16 == 0 && u.cout % 32 == 0) need += wb_elems(1, 4 * u.cout, u.cin, 0, 3) + wb_elems(4, u.cin, u.cout, 0, 3) + 64;
+            if (up_ok(u)) need += wb_elems(1, 4 * u.cout, u.cin, 0, P) + wb_elems(4, u.cin, u.cout, 0, P) + 64;
         if (need == 0) return;
         ws_pool = static_cast<bf16_t*>(ctx->alloc(need * 2));
         RFI_CHECK_HIP(hipMemsetAsync(ws_pool, 0, need * 2, ctx->stream));
@@ -436,34 +447,33 @@ void rfi_model::refresh_ws_weights() {
         size_t o = 0;
         ws_bytes = 0;
         for (ConvBN& c : convs) {
-            if (c.R != 3 || c.stride != 1) continue;
-            if (c.cin_p % 16 == 0) {
+            if (conv_f(c)) {
                 c.ws3f = ws_pool + o;
-                const size_t e = wb_elems(9, c.cout, c.cin_p, 0, 3);
+                const size_t e = wb_elems(9, c.cout, c.cin_p, 0, P);
                 o += e + 32;
-                hd.push_back(WBDesc{params + c.w_off, c.ws3f, 9, c.cout, c.cin_p, {c.cin_p, 0}, 3});
-                ws_by_w3[c.w3] = c.ws3f;
+                hd.push_back(WBDesc{params + c.w_off, c.ws3f, 9, c.cout, c.cin_p, {c.cin_p, 0}, P});
+                ws_by_w[params + c.w_off] = c.ws3f;
                 ws_bytes += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
             }
-            if (c.cout % 16 == 0) {
+            if (conv_d(c)) {
                 c.ws3d = ws_pool + o;
-                const size_t e = wb_elems(9, c.cin_p, c.cout, 0, 3);
+                const size_t e = wb_elems(9, c.cin_p, c.cout, 0, P);
                 o += e + 32;
-                hd.push_back(WBDesc{c.wd, c.ws3d, 9, c.cin_p, c.cout, {c.cout, 0}, 3});
-                ws_by_w3[c.wd3] = c.ws3d;
+                hd.push_back(WBDesc{c.wd, c.ws3d, 9, c.cin_p, c.cout, {c.cout, 0}, P});
+                ws_by_w[c.wd] = c.ws3d;
                 ws_bytes += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
             }
         }
         // transposed convs (gemm_ws.hip): forward = ONE tap of 4 cout channels ([4][cout][cin] IS [4 cout][cin]); input
         // gradient = four taps of [cin][cout]
         for (UpConv& u : ups) {
-            if (!(u.cin % 16 == 0 && u.cout % 32 == 0)) continue;
-            const size_t ef = wb_elems(1, 4 * u.cout, u.cin, 0, 3), ed = wb_elems(4, u.cin, u.cout, 0, 3);
-            hd.push_back(WBDesc{params + u.w_off, ws_pool + o, 1, 4 * u.cout, u.cin, {u.cin, 0}, 3});
-            ws_by_w3[u.w3] = ws_pool + o;
+            if (!up_ok(u)) continue;
+            const size_t ef = wb_elems(1, 4 * u.cout, u.cin, 0, P), ed = wb_elems(4, u.cin, u.cout, 0, P);
+            hd.push_back(WBDesc{params + u.w_off, ws_pool + o, 1, 4 * u.cout, u.cin, {u.cin, 0}, P});
+            ws_by_w[params + u.w_off] = ws_pool + o;
             o += ef + 32;
-            hd.push_back(WBDesc{u.wd, ws_pool + o, 4, u.cin, u.cout, {u.cout, 0}, 3});
-            ws_by_w3[u.wd3] = ws_pool + o;
+            hd.push_back(WBDesc{u.wd, ws_pool + o, 4, u.cin, u.cout, {u.cout, 0}, P});
+            ws_by_w[u.wd] = ws_pool + o;
             o += ed + 32;
             ws_bytes += 2.0 * (ef + ed) + 8.0 * 4 * u.cin * u.cout;
         }
@@ -487,7 +497,7 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
     a.Cin = c.cin_p; a.Cout = c.cout;
     a.w = m->params + c.w_off;
     a.w3 = m->use_w3() ? c.w3 : nullptr;
-    a.wB3 = m->ws_of(a.w3);
+    m->ws_set(a);
     a.bias = m->params + c.b_off;
     a.y = MutView{Y, c.cout};
     a.Hout = s.H; a.Wout = s.W;
@@ -569,7 +579,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         a.Cin = u.cin; a.Cout = u.cout;
         a.w = params + u.w_off;
         a.w3 = use_w3() ? u.w3 : nullptr;
-        a.wB3 = ws_of(a.w3);
+        ws_set(a);
         a.bias = params + u.b_off;
         a.y = MutView{buf(concat[l]), 2 * u.cout};
         a.Hout = s.H; a.Wout = s.W;
@@ -769,7 +779,7 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
         a.Cin = c.cout; a.Cout = c.cin;     // dx exists only for layers whose cin == cin_p
         a.w = c.wd;
         a.w3 = m->use_w3() ? c.wd3 : nullptr;
-        a.wB3 = m->ws_of(a.w3);
+        m->ws_set(a);
         a.bias = nullptr;
         a.y = MutView{dx, c.cin};
         a.Hout = s.H; a.Wout = s.W;
@@ -884,7 +894,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         a.Cin = u.cout; a.Cout = u.cin;
         a.w = u.wd;
         a.w3 = use_w3() ? u.wd3 : nullptr;
-        a.wB3 = ws_of(a.w3);
+        ws_set(a);
         a.bias = nullptr;
         float* dprev = (l == D) ? buf(gBottA) : buf(gA[l + 1]);
         a.y = MutView{dprev, u.cin};

@@ -122,12 +122,17 @@ struct rfi_model {
     void* ws_descs = nullptr;
     int ws_n = 0;
     double ws_bytes = 0;
-    std::unordered_map<const float*, const rfi::bf16_t*> ws_by_w3;   // pre-split record pointer (ConvArgs::w3) -> the same filters for conv_ws
-    const rfi::bf16_t* ws_of(const float* w3) const {
-        auto it = ws_by_w3.find(w3);
-        return it == ws_by_w3.end() ? nullptr : it->second;
+    std::unordered_map<const float*, const rfi::bf16_t*> ws_by_w;    // float32 filter pointer (ConvArgs::w) -> the same filters for conv_ws / gemm_ws
+    int ws_P = 0;                     // planes of the copies in ws_pool: 3 (float32 by 3 x bf16), 1 (bf16 operands), 0 (none built)
+    int ws_need() const { return planesP ? 0 : compute_x3 ? 3 : (compute_bf16 && !rfi::bf16_k16()) ? 1 : 0; }
+    // the copy of filter `w` for the wave-specialised kernels in the current arithmetic (null: none)
+    void ws_set(rfi::ConvArgs& a) const {
+        auto it = ws_by_w.find(a.w);
+        const rfi::bf16_t* p = it == ws_by_w.end() || ws_P != ws_need() ? nullptr : it->second;
+        a.wB3 = ws_P == 3 ? p : nullptr;
+        a.wB1 = ws_P == 1 ? p : nullptr;
     }
-    void refresh_ws_weights();
+    void refresh_ws_weights(int P);
     void* x3_descs = nullptr;         // device table of the batched rebuild
     int x3_n = 0;
     double x3_bytes = 0;

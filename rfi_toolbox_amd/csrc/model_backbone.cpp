@@ -280,7 +280,7 @@ void conv(rfi_model* m, View in, InXform xf, Sh s, int Hin, int Win, const float
     a.Cin = cin; a.Cout = cout;
     a.w = w;
     a.w3 = m->use_w3() ? w3 : nullptr;
-    a.wB3 = m->ws_of(a.w3);
+    m->ws_set(a);
     a.bias = bias;
     a.y = MutView{Y, cout};
     a.Hout = s.H; a.Wout = s.W;

@@ -158,14 +158,14 @@ void rfi_model::forward_cnn3(const float* x_dev, int n, int h, int w) {
     ConvArgs a1 = conv3x3(c1, x, InXform{}, params + c1.w_off, params + c1.b_off, buf(cY1), c1.cin_p, c1.cout,
                           n, h, w);
     a1.w3 = use_w3() ? c1.w3 : nullptr;
-    a1.wB3 = ws_of(a1.w3);
+    ws_set(a1);
     a1.bf16 = compute_bf16;
     a1.bf16x3 = compute_x3;
     launch_conv(ctx, a1);
     ConvArgs a2 = conv3x3(c2, View{buf(cY1), c1.cout}, relu_xf(c1), params + c2.w_off, params + c2.b_off,
                           buf(cY2), c2.cin_p, c2.cout, n, h, w);
     a2.w3 = use_w3() ? c2.w3 : nullptr;
-    a2.wB3 = ws_of(a2.w3);
+    ws_set(a2);
     a2.bf16 = compute_bf16;
     a2.bf16x3 = compute_x3;
     launch_conv(ctx, a2);
@@ -207,7 +207,7 @@ void rfi_model::backward_cnn3(const float* x_dev, const uint8_t* labels_dev, int
         if (dx) {
             ConvArgs a = conv3x3(c, View{dA, c.cout}, InXform{}, c.wd, nullptr, dx, c.cout, c.cin, n, h, w);
             a.w3 = use_w3() ? c.wd3 : nullptr;
-            a.wB3 = ws_of(a.w3);
+            ws_set(a);
             a.bf16 = compute_bf16;
     a.bf16x3 = compute_x3;
             launch_conv(ctx, a);

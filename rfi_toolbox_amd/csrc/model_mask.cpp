@@ -188,7 +188,7 @@ ConvArgs conv3x3_args(rfi_model* m, View in, InXform xf, const float* w, const f
     a.Cin = C; a.Cout = C;
     a.w = w;
     a.w3 = m->use_w3() ? w3 : nullptr;
-    a.wB3 = m->ws_of(a.w3);
+    m->ws_set(a);
     a.bias = bias;
     a.y = MutView{y, C};
     a.Hout = h; a.Wout = wd;
@@ -219,7 +219,7 @@ void rfi_model::forward_mask(const float* x_dev, int n, int h, int w) {
         a.Cin = C; a.Cout = C;
         a.w = params + u.w_off;
         a.w3 = use_w3() ? u.w3 : nullptr;
-        a.wB3 = ws_of(a.w3);
+        ws_set(a);
         a.bias = params + u.b_off;
         a.y = MutView{buf(mkU), C};
         a.Hout = 2 * h; a.Wout = 2 * w;
@@ -276,7 +276,7 @@ void rfi_model::backward_mask(const float* x_dev, const uint8_t* labels_dev, int
         a.Cin = C; a.Cout = C;
         a.w = u.wd;
         a.w3 = use_w3() ? u.wd3 : nullptr;
-        a.wB3 = ws_of(a.w3);
+        ws_set(a);
         a.y = MutView{buf(mkG[L - 1]), C};
         a.Hout = h; a.Wout = w;
         a.R = 2; a.S = 2; a.pad = 0;

@@ -236,7 +236,7 @@ void conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, const float*
     a.Cin = cin; a.Cout = c.cout;
     a.w = w;
     a.w3 = m->use_w3() ? w3 : nullptr;            // null: the kernel launcher splits a temporary copy
-    a.wB3 = m->ws_of(a.w3);
+    m->ws_set(a);
     a.bias = c.has_bias ? m->params + c.b_off : nullptr;
     a.y = MutView{Y, c.cout};
     a.Hout = s.H; a.Wout = s.W;
@@ -302,7 +302,7 @@ void dgrad(rfi_model* m, const float* dY, int cy, const float* wd, const float* 
     a.Cin = cy; a.Cout = cx;
     a.w = wd;
     a.w3 = m->use_w3() ? wd3 : nullptr;
-    a.wB3 = m->ws_of(a.w3);
+    m->ws_set(a);
     a.y = MutView{dx, cx};
     a.Hout = s.H; a.Wout = s.W;
     a.R = R; a.S = 1; a.pad = pad;

@@ -13,6 +13,7 @@ from test_gpu_ops import CONV_SHAPES, CONVT_SHAPES
 pytestmark = pytest.mark.gpu
 BF = 3          # IMPL_MFMA_BF16: operands rounded to bf16 in registers (the transposed-conv kernels of the bf16 mode)
 PBF = 6         # IMPL_PLANES_BF16: the plane kernels (bf16 activations staged by LDS-DMA), the 3x3 kernels of the bf16 mode
+WSBF = 8        # IMPL_WS_BF16: the wave-specialised kernel with one plane (float32 tensors, operands rounded at staging)
 TOL = 2e-5
 SHAPES = [s for s in CONV_SHAPES if s[3] % 4 == 0 and s[4] % 4 == 0]
 TSHAPES = [s for s in CONVT_SHAPES if s[3] % 4 == 0 and s[4] % 4 == 0]
@@ -39,7 +40,7 @@ def test_conv3x3_forward_bf16(shape, xform):
     c = ctx()
     dx, dw, db = c.to_device(nhwc(x)), c.to_device(wt.numpy()), c.to_device(b.numpy())
     dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
-    for impl in (BF, PBF):
+    for impl in (BF, PBF) + ((WSBF,) if cin % 16 == 0 and h >= 8 and w >= 8 else ()):
         dy = c.empty((n, h, w, cout))
         check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout,
                                  P(dsc) if xform else None, P(dsh) if xform else None, 1 if xform else 0, P(dy)))
@@ -63,6 +64,10 @@ def test_conv3x3_dgrad_wgrad_bf16(shape):
         gw = c.empty((cout, cin, 3, 3))
         check(lib.rfi_op_conv3x3_wgrad(c.handle, impl, P(dxd), P(ddy), n, h, w, cin, cout, None, None, 0, P(gw)))
         assert rel_err(gw.numpy(), wt.grad.float().numpy()) <= 5e-5, impl
+    if cout % 16 == 0 and h >= 8 and w >= 8:          # the input gradient on the wave-specialised kernel (Cin = cout)
+        out = c.empty((n, h, w, cin))
+        check(lib.rfi_op_conv3x3_dgrad(c.handle, WSBF, P(ddy), n, h, w, cout, P(dwd), cin, P(out)))
+        assert rel_err(out.numpy(), nhwc(x.grad.float())) <= TOL, "ws bf16"
 
 
 @pytest.mark.parametrize("shape", TSHAPES)
