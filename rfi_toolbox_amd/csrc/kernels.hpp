@@ -125,6 +125,8 @@ struct WgradArgs {
     int planes = 0;                   // 1 / 3: plane kernel through temporary plane copies (IMPL_PLANES_*)
 };
 size_t wgrad_slab_floats(const WgradArgs& a, int impl);
+bool wgrad_ws_eligible(const WgradArgs& a);      // wgrad_ws.hip: the wave-specialised kernel (float32 tensors, 3 x bf16 or bf16 operands)
+void launch_wgrad_ws(rfi_ctx* ctx, const WgradArgs& a);
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);
 
 // The raw output Y of a conv layer as the elementwise kernels read it: float32 [M][C] or, in the bf16 data flow

@@ -478,6 +478,11 @@ void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
         launch_wgrad_direct(ctx, a);
         return;
     }
+    static const bool no_ws = getenv("RFI_NO_WGRAD_WS") != nullptr;       // A/B runs: round 2's kernels
+    if (!no_ws && (a.bf16x3 || a.bf16) && wgrad_ws_eligible(a) && wgrad_split_eligible(a)) {
+        launch_wgrad_ws(ctx, a);      // (its slab plan -- 256 workgroups -- fits inside wgrad_split's, which sized the workspace)
+        return;
+    }
     static const bool old_x3 = getenv("RFI_OLD_WGRAD") != nullptr;       // round 1's split-per-fragment kernel (A/B runs)
     // R = 2 / S = 1 and R = 1 (ResNet-style encoder) exist only in the split-at-staging kernel (P = 1: bf16 mode)
     const bool only_split = (a.R == 2 && a.S == 1) || a.R == 1;
