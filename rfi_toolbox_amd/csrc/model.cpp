@@ -372,7 +372,8 @@ void rfi_model::refresh_dgrad_weights() {
     }
     launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
                                    wd_pool, relayout_bytes, relayout_tiles);
-    if (use_w3()) {       // pre-split records of both layouts of every conv-like layer (the kernels read them as is)
+    refresh_ws_weights(ws_need());
+    if (use_w3()) {       // pre-split records of both layouts of the conv-like layers (the round-2 kernels read them as is)
         if (!w3_pool) {
             size_t need = 0;
             for (auto& c : convs) need += weights_x3_floats(c.R * c.R, c.cout, c.cin_p) + weights_x3_floats(c.R * c.R, c.cin_p, c.cout);
@@ -388,9 +389,19 @@ void rfi_model::refresh_dgrad_weights() {
                 u.wd3 = w3_pool + o; o += weights_x3_floats(4, u.cin, u.cout);
             }
         }
+        // layers whose filters the wave-specialised kernels read (ws_by_w) need no records: launch_conv drops
+        // ConvArgs::w3 for them, and a shape those kernels decline (maps under 8 x 8) gets a temporary split copy
+        static const bool all_x3 = getenv("RFI_NO_WS") != nullptr || getenv("RFI_NO_GW") != nullptr;     // A/B runs
+        if (x3_descs && x3_for_ws_P != ws_P) {
+            ctx->release(x3_descs);
+            x3_descs = nullptr;
+        }
         if (!x3_descs) {
+            x3_for_ws_P = ws_P;
+            x3_bytes = 0;
             std::vector<X3Desc> h;
             auto add = [&](const float* src, float* dst, int taps, int cout, int cin) {
+                if (!all_x3 && ws_P == 3 && ws_by_w.count(src)) return;
                 h.push_back(X3Desc{src, dst, (int64_t)taps * cout, cin, (cin + 15) / 16});
                 x3_bytes += (double)taps * cout * cin * 4 + (double)weights_x3_floats(taps, cout, cin) * 4;
             };
@@ -403,14 +414,13 @@ void rfi_model::refresh_dgrad_weights() {
                 add(u.wd, u.wd3, 4, u.cin, u.cout);
             }
             x3_n = (int)h.size();
-            x3_descs = ctx->alloc(h.size() * sizeof(X3Desc));
-            RFI_CHECK_HIP(hipMemcpyAsync(x3_descs, h.data(), h.size() * sizeof(X3Desc), hipMemcpyHostToDevice, ctx->stream));
+            x3_descs = ctx->alloc((h.size() + 1) * sizeof(X3Desc));
+            if (x3_n) RFI_CHECK_HIP(hipMemcpyAsync(x3_descs, h.data(), h.size() * sizeof(X3Desc), hipMemcpyHostToDevice, ctx->stream));
             RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // h goes out of scope
         }
-        launch_weights_to_x3_batched(ctx, static_cast<const X3Desc*>(x3_descs), x3_n, x3_bytes);
+        if (x3_n) launch_weights_to_x3_batched(ctx, static_cast<const X3Desc*>(x3_descs), x3_n, x3_bytes);
         x3_fresh = true;
     }
-    refresh_ws_weights(ws_need());
     if (arch == 2) refresh_resnet_weights();               // 2x2 forms of the stride-2 filters
     if (planesP && arch == 0) refresh_plane_weights();     // B-operand-order filters of the plane kernels
     wd_dirty = false;

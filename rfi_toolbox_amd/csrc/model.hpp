@@ -135,6 +135,7 @@ struct rfi_model {
     void refresh_ws_weights(int P);
     void* x3_descs = nullptr;         // device table of the batched rebuild
     int x3_n = 0;
+    int x3_for_ws_P = -1;             // the ws_P the record list was built for (layers with ws copies are left out)
     double x3_bytes = 0;
     int64_t adam_step = 0;
     bool wd_dirty = true;
