@@ -27,21 +27,26 @@ for r in csv.DictReader(open(f)):
     disp[k]["name"] = r["Kernel_Name"]
     disp[k]["waves"] = float(r["Grid_Size"]) / 64.0
     disp[k]["ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+import re
+
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for v in disp.values():
     fam = family(v["name"])
     if fam not in ("conv_igemm_mfma", "wgrad_igemm_mfma"):
         continue
     cyc = 4.0 * v["SQ_WAVE_CYCLES"] / v["waves"]
-    a = acc[fam]
-    a["n"] += 1
-    a["ns"] += v["ns"]
-    a["cycles"] += cyc
-    a["mfma"] += v["SQ_VALU_MFMA_BUSY_CYCLES"]
-res = {}
-for fam, a in acc.items():
-    res[fam] = {"launches_seen": int(a["n"]), "avg_launch_us": round(a["ns"] / a["n"] / 1e3, 2),
-                "eff_clock_GHz": round(a["cycles"] / a["ns"], 3),
-                "mfma_util": round(a["mfma"] / (1024.0 * a["cycles"]), 4)}
-json.dump({"families": res, "note": " ".join(__doc__.split("\n\n")[-1].split())}, open(out, "w"), indent=1, sort_keys=True)
+    short = re.sub(r"rfi::\(anonymous namespace\)::|void |\(.*$", "", v["name"])
+    for key in (fam, "kernel:" + short):
+        a = acc[key]
+        a["n"] += 1
+        a["ns"] += v["ns"]
+        a["cycles"] += cyc
+        a["mfma"] += v["SQ_VALU_MFMA_BUSY_CYCLES"]
+res, kern = {}, {}
+for key, a in acc.items():
+    row = {"launches_seen": int(a["n"]), "avg_launch_us": round(a["ns"] / a["n"] / 1e3, 2),
+           "eff_clock_GHz": round(a["cycles"] / a["ns"], 3),
+           "mfma_util": round(a["mfma"] / (1024.0 * a["cycles"]), 4)}
+    (kern if key.startswith("kernel:") else res)[key.replace("kernel:", "")] = row
+json.dump({"families": res, "kernels": kern, "note": " ".join(__doc__.split("\n\n")[-1].split())}, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
