@@ -71,13 +71,6 @@ struct WsCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-#ifdef RFI_DIAG_STAMPS
-#define WS_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define WS_ACC(i, a_, b_) st_[i] += (b_) - (a_)
-#else
-#define WS_T(v)
-#define WS_ACC(i, a_, b_)
-#endif
 
 // XF: the load transform -- 0 none, 1 relu(x * scale + shift), 2 x * scale + shift followed by max(v, v * slope) (LeakyReLU;
 // slope 1: no activation)
@@ -372,6 +365,20 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 if (tap + 1 < 9) load_frags(tap + 1, afr[(tap + 1) & 1], bfr[(tap + 1) & 1]);
+                if constexpr (!ADB) {
+                    if (tap == 8) {
+                        // one halo buffer: the last LDS reads of the item (the fragments of tap 8) were issued under tap 7's
+                        // MFMAs; once they have landed the producers may overwrite the halo tile -- they do so UNDER the
+                        // MFMAs of tap 8 instead of in a window in which the matrix pipe idles
+                        __builtin_amdgcn_sched_barrier(0);
+                        WS_T(tb0);
+                        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+                        wg_barrier();
+                        WS_T(tb1);
+                        WS_ACC(3, tb0, tb1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -427,7 +434,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                     pend = false;
                 }
             }
-            if (!(d.diag & 4)) {
+            if (d.diag & 4) {
+                if constexpr (!ADB) wg_barrier();
+            } else {
                 if (pend) {                              // (pend implies chunk 0 of the next tile)
                     run_item(std::true_type{}, std::true_type{}, sA, sB);
                     epi_finish();
@@ -482,8 +491,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                 if (ck < my_tiles) ct = tile_of(ck);
             }
             WS_T(t4);
-            wg_barrier();                                // every consumer is done with this item's halo tile (its reads fed MFMAs that have issued)
-            if constexpr (!ADB) wg_barrier();            // item q + 1 is staged
+            // ADB: every consumer is done with this item's halo tile and item q + 1 is staged in the other one.  One buffer:
+            // the "done" barrier sits in front of tap 8 (run_item); this one says that item q + 1 is staged
+            wg_barrier();
             WS_T(t5);
             WS_ACC(0, t0, t1);
             WS_ACC(2, t1, t4);
@@ -562,8 +572,8 @@ void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
         for (size_t w = 0; w < nw; ++w)
             for (int i = 0; i < 5; ++i) ((w & 7) < 4 ? c : p)[i] += (double)hs[w * 8 + i];
         std::fprintf(stderr, "[stamps] conv_ws<%d,%d,%d,%d,%d> N%d %dx%d %d->%d grid %dx%d items/wg %.1f | cycles per item: consumer mfma %.0f "
-                     "epilogue %.0f barriers %.0f | producer work %.0f (split %.0f, dma wait %.0f) barriers+write %.0f\n", TB, TH, TW, NTL, XF,
-                     a.N, a.H, a.W, a.Cin, a.Cout, GX, ycols, c[4] / (nw / 2), c[0] / c[4], c[2] / c[4], c[1] / c[4], p[0] / p[4],
+                     "epilogue %.0f barriers %.0f (+ in front of tap 8: %.0f) | producer work %.0f (split %.0f, dma wait %.0f) barriers+write %.0f\n", TB, TH, TW, NTL, XF,
+                     a.N, a.H, a.W, a.Cin, a.Cout, GX, ycols, c[4] / (nw / 2), c[0] / c[4], c[2] / c[4], c[1] / c[4], c[3] / c[4], p[0] / p[4],
                      p[2] / p[4], p[3] / p[4], p[1] / p[4]);
         RFI_CHECK_HIP(hipFree(d.stamps));
         d.stamps = nullptr;

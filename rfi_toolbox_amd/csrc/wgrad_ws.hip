@@ -11,6 +11,8 @@
 // a second workgroup per CU to fill the gaps (matrix pipe busy 0.57).  One workgroup per CU also means HALF the partial
 // slabs (256 workgroups instead of 512), i.e. half the bytes reduce_slabs has to move.
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 #include "ws_common.hpp"
 
@@ -26,6 +28,7 @@ struct WWsDev {
     int nsplit;
     int64_t slab_stride;
     unsigned x_bytes, y_bytes;
+    unsigned long long* stamps;       // RFI_DIAG_STAMPS build: per-wave cycle sums
 };
 
 template <int R, int BYB, int BXB, int TH, int TW, int P>
@@ -66,11 +69,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
 // barrier behind this wave's LDS writes (the producers have left by then: a terminated wave is not waited for)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int R, int BYB, int BXB, int TH, int TW, int P>
+// XM: the load transforms -- 1 Xop = relu(x * scale + shift), Yop plain (the 3x3 layers of the U-Net: compile-time, no
+// tests); 2 whatever the arguments say (either operand, any activation, or none)
+template <int R, int BYB, int BXB, int TH, int TW, int P, int XM>
 __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
     using C = WWCfg<R, BYB, BXB, TH, TW, P>;
     const WgradArgs& a = d.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef RFI_DIAG_STAMPS
+    unsigned long long st_[4] = {0, 0, 0, 0};
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cy0 = blockIdx.y * BYB * 32, cx0 = blockIdx.z * BXB * 32;
@@ -81,8 +89,15 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
 
     if (wave >= 4) {
         // =============================================================== producers
+        // The producers are the bottleneck of this kernel (cycle stamps, round 3: 9.3 k cycles per 8 x 8 tile against
+        // 6.9 k of MFMA issue) and they issue one vector instruction per ~14 cycles beside the MFMA waves, so this code
+        // counts instructions: everything that does not depend on the tile (pixel coordinates inside the tile, byte offsets
+        // relative to its first pixel, LDS addresses) is computed once; a tile costs one scalar base and one add per item
+        // (interior tiles) or the bounds tests (edge tiles); the transforms are written per element, unfused and unpacked.
         const int ptid = tid - 256;
+        constexpr int YSTEP = 256 / C::YQ, XSTEP = 256 / C::XQ;      // pixels between a thread's consecutive items
         const int yq = ptid % C::YQ, xq = ptid % C::XQ;
+        const int ypix0 = ptid / C::YQ, xpix0 = ptid / C::XQ;
         const int cyq = cy0 + yq * 4, cxq = cx0 + xq * 4;
         const bool y_cok = cyq < a.Cy, x_cok = cxq < a.Cx;            // Cx, Cy % 4 == 0 (launch precondition)
         f32x4 ysc = {1.f, 1.f, 1.f, 1.f}, ysh = {0.f, 0.f, 0.f, 0.f}, xsc = ysc, xsh = ysh;
@@ -96,37 +111,66 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
         }
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.yop.p), 0, (int)d.y_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xop.p), 0, (int)d.x_bytes, 0x00020000);
-        // LDS byte offset of this thread's 4 channels inside a pixel row of its 32-channel block image
-        const int y_lds = (yq >> 3) * (C::BM * C::ROW) + (yq & 7) * 8, x_lds = (xq >> 3) * (C::HP * C::ROW) + (xq & 7) * 8;
+        // an item that does not exist (beyond the tile's pixels or the tensor's channels) gets NOWHERE as its relative
+        // offset: base + NOWHERE lies beyond the buffer for every tile base (bases are > -2^24 and < 0x7f000000: the launch
+        // checks both), so the load returns zero
+        constexpr unsigned NOWHERE = 0x81000000u, OUTSIDE = 0x80000000u;
+        unsigned y_rel[C::Y_ITEMS], x_rel[C::X_ITEMS];
+        int y_dyx[C::Y_ITEMS], x_dyx[C::X_ITEMS];        // row << 16 | column of the item's pixel inside the tile / halo tile
+#pragma unroll
+        for (int it = 0; it < C::Y_ITEMS; ++it) {
+            const int pix = ypix0 + it * YSTEP, dy = pix / TW, dx = pix % TW;
+            y_rel[it] = (pix < C::BM && y_cok) ? (unsigned)((dy * a.W + dx) * a.yop.pstride + cyq) * 4u : NOWHERE;
+            y_dyx[it] = pix < C::BM ? (dy << 16) | dx : 0x7fff7fff;
+        }
+#pragma unroll
+        for (int it = 0; it < C::X_ITEMS; ++it) {
+            const int pix = xpix0 + it * XSTEP, dy = pix / C::HW, dx = pix % C::HW;
+            x_rel[it] = (pix < C::HP && x_cok) ? (unsigned)((dy * a.Wx + dx) * a.xop.pstride + cxq) * 4u : NOWHERE;
+            x_dyx[it] = pix < C::HP ? (dy << 16) | dx : 0x7fff7fff;
+        }
+        // LDS byte address of this thread's 4 channels of item 0 (item it: + it * STEP * ROW, an immediate)
+        const int y_lds = (yq >> 3) * (C::BM * C::ROW) + (yq & 7) * 8 + ypix0 * C::ROW;
+        const int x_lds = (xq >> 3) * (C::HP * C::ROW) + (xq & 7) * 8 + xpix0 * C::ROW;
         u32x4 yreg[C::Y_ITEMS], xreg[C::X_ITEMS];
-        unsigned yvalid = 0, xvalid = 0;
-        // buffer loads: an item outside the image (or the channel range) reads offset 2^31, i.e. zero
+        unsigned yvalid = ~0u, xvalid = ~0u;             // per-item "inside the image" bits of the tile in the registers
+        bool yfull = true, xin = true;                   // ... all set (wave-uniform)
         auto load_tile = [&](int tile) {
             const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
             const int oy0 = ty_i * TH, ox0 = tx_i * TW;
             const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
-            yvalid = 0;
-            xvalid = 0;
+            const unsigned ybase = (unsigned)(((n * a.H + oy0) * a.W + ox0) * a.yop.pstride) * 4u;
+            const unsigned xbase = (unsigned)(((n * a.Hx + iy0) * a.Wx + ix0) * a.xop.pstride) * 4u;     // (may be "negative")
+            yfull = oy0 + TH <= a.H && ox0 + TW <= a.W;
+            xin = iy0 >= 0 && ix0 >= 0 && iy0 + C::HH <= a.Hx && ix0 + C::HW <= a.Wx;
+            if (yfull) {
+                yvalid = ~0u;
 #pragma unroll
-            for (int it = 0; it < C::Y_ITEMS; ++it) {
-                const int pix = (ptid + it * 256) / C::YQ;
-                const int y = oy0 + pix / TW, x = ox0 + pix % TW;
-                const bool ok = pix < C::BM && y < a.H && x < a.W && y_cok;
-                const unsigned off = ok ? (unsigned)(((n * a.H + y) * a.W + x) * a.yop.pstride + cyq) * 4u : 0x80000000u;
-                yreg[it] = __builtin_amdgcn_raw_buffer_load_b128(yrs, off, 0, 0);
-                yvalid |= (ok ? 1u : 0u) << it;
+                for (int it = 0; it < C::Y_ITEMS; ++it) yreg[it] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ybase + y_rel[it], 0, 0);
+            } else {
+                yvalid = 0;
+#pragma unroll
+                for (int it = 0; it < C::Y_ITEMS; ++it) {
+                    const bool ok = oy0 + (y_dyx[it] >> 16) < a.H && ox0 + (y_dyx[it] & 0xffff) < a.W;
+                    yreg[it] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ok ? ybase + y_rel[it] : OUTSIDE, 0, 0);
+                    yvalid |= (ok ? 1u : 0u) << it;
+                }
             }
+            if (xin) {
+                xvalid = ~0u;
 #pragma unroll
-            for (int it = 0; it < C::X_ITEMS; ++it) {
-                const int pix = (ptid + it * 256) / C::XQ;
-                const int iy = iy0 + pix / C::HW, ix = ix0 + pix % C::HW;
-                const bool ok = pix < C::HP && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx && x_cok;
-                const unsigned off = ok ? (unsigned)(((n * a.Hx + iy) * a.Wx + ix) * a.xop.pstride + cxq) * 4u : 0x80000000u;
-                xreg[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
-                xvalid |= (ok ? 1u : 0u) << it;
+                for (int it = 0; it < C::X_ITEMS; ++it) xreg[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xbase + x_rel[it], 0, 0);
+            } else {
+                xvalid = 0;
+#pragma unroll
+                for (int it = 0; it < C::X_ITEMS; ++it) {
+                    const bool ok = (unsigned)(iy0 + (x_dyx[it] >> 16)) < (unsigned)a.Hx && (unsigned)(ix0 + (x_dyx[it] & 0xffff)) < (unsigned)a.Wx;
+                    xreg[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xbase + x_rel[it] : OUTSIDE, 0, 0);
+                    xvalid |= (ok ? 1u : 0u) << it;
+                }
             }
         };
-        // transform, split ONCE into (h, m, l) and write the planes of the thread's 4 channels (8 bytes each)
+        // split ONCE into (h, m, l) and write the planes of the thread's 4 channels (8 bytes each)
         auto put = [&](f32x4 v, unsigned char* dst) {
             if constexpr (P == 3) {
                 unsigned h0, m0, l0, h1, m1, l1;
@@ -139,41 +183,73 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
                 *reinterpret_cast<u32x2*>(dst) = u32x2{cvt_pair(v.x, v.y), cvt_pair(v.z, v.w)};
             }
         };
-        auto xform = [&](f32x4 v, const f32x4& sc, const f32x4& sh, const InXform& xf, bool valid) {
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            if (xf.scale) {
-                v = v * sc + sh;
-                if (xf.relu) v = __builtin_elementwise_max(v, v * xf.slope);       // slope 0 = ReLU
-                v = valid ? v : zero;                                              // zero padding AFTER the transform
+        // the load transform of one item.  MASK: the tile touches the image border -- zero padding AFTER the transform
+        // (`valid`: the item's pixel is inside).  Per element, unfused (the values every other consumer of the tensor
+        // computes), no packed fp32 forms (slower beside the MFMA waves)
+        auto xform = [&](f32x4 v, const f32x4& sc, const f32x4& sh, const InXform& xf, auto mask_c, unsigned valid) {
+            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)valid, 0, 1);          // 0 or ~0
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e] * sc[e] + sh[e];
+                if constexpr (XM == 1) {
+                    asm("v_max_f32 %0, 0, %1" : "=v"(t) : "v"(t));                        // ReLU
+                } else {
+                    if (xf.relu) {
+                        const float u = t * xf.slope;                                       // slope 0 = ReLU
+                        asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(u));
+                    }
+                }
+                if constexpr (decltype(mask_c)::value) t = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & m);
+                v[e] = t;
             }
             return v;
         };
         auto store_tile = [&](int buf) {
-            unsigned char* const sY = smem + buf * C::STAGE;
-            unsigned char* const sX = sY + C::Y_BYTES;
+            unsigned char* const sY = smem + buf * C::STAGE + y_lds;
+            unsigned char* const sX = smem + buf * C::STAGE + C::Y_BYTES + x_lds;
+            const bool do_y = XM == 2 && a.xf_y.scale != nullptr, do_x = XM == 1 || (XM == 2 && a.xf_x.scale != nullptr);
 #pragma unroll
             for (int it = 0; it < C::Y_ITEMS; ++it) {
-                const int pix = (ptid + it * 256) / C::YQ;
-                const f32x4 v = xform(__builtin_bit_cast(f32x4, yreg[it]), ysc, ysh, a.xf_y, (yvalid >> it) & 1u);
-                if (pix < C::BM) put(v, sY + y_lds + pix * C::ROW);
+                f32x4 v = __builtin_bit_cast(f32x4, yreg[it]);
+                if (do_y) v = xform(v, ysc, ysh, a.xf_y, std::true_type{}, yvalid >> it);
+                if (it * YSTEP + YSTEP <= C::BM || ypix0 + it * YSTEP < C::BM) put(v, sY + it * YSTEP * C::ROW);
             }
+            if (do_x && !xin) {
 #pragma unroll
-            for (int it = 0; it < C::X_ITEMS; ++it) {
-                const int pix = (ptid + it * 256) / C::XQ;
-                const f32x4 v = xform(__builtin_bit_cast(f32x4, xreg[it]), xsc, xsh, a.xf_x, (xvalid >> it) & 1u);
-                if (pix < C::HP) put(v, sX + x_lds + pix * C::ROW);
+                for (int it = 0; it < C::X_ITEMS; ++it) {
+                    const f32x4 v = xform(__builtin_bit_cast(f32x4, xreg[it]), xsc, xsh, a.xf_x, std::true_type{}, xvalid >> it);
+                    if (it * XSTEP + XSTEP <= C::HP || xpix0 + it * XSTEP < C::HP) put(v, sX + it * XSTEP * C::ROW);
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < C::X_ITEMS; ++it) {
+                    f32x4 v = __builtin_bit_cast(f32x4, xreg[it]);
+                    if (do_x) v = xform(v, xsc, xsh, a.xf_x, std::false_type{}, 0u);
+                    if (it * XSTEP + XSTEP <= C::HP || xpix0 + it * XSTEP < C::HP) put(v, sX + it * XSTEP * C::ROW);
+                }
             }
         };
         load_tile(split);
         // k = -1 is the prologue (tile 0); every later iteration stages tile k + 1 while the consumers multiply tile k
         for (int k = -1; k < my_tiles; ++k) {
+            WS_T(t0);
             if (k + 1 < my_tiles) {
                 store_tile((k + 1) & 1);                 // (waits for the loads of tile k + 1, issued an iteration ago)
                 if (k + 2 < my_tiles) load_tile(split + (k + 2) * d.nsplit);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            WS_T(t1);
             wg_barrier();
+            WS_T(t2);
+            WS_ACC(0, t0, t1);
+            WS_ACC(1, t1, t2);
         }
+#ifdef RFI_DIAG_STAMPS
+        if (d.stamps && lane == 0) {
+            unsigned long long* o = d.stamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+            o[0] = st_[0]; o[1] = st_[1]; o[2] = (unsigned long long)my_tiles;
+        }
+#endif
     } else {
         // =============================================================== consumers
         const int blk = wave % C::BLOCKS, ps = wave / C::BLOCKS;
@@ -190,18 +266,24 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
         for (int t = 0; t < C::NTAP; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        WS_T(tp0);
         wg_barrier();                                    // tile 0 is staged
+        WS_T(tp1);
         for (int k = 0; k < my_tiles; ++k) {
+            WS_T(t0);
             const unsigned char* const sY = smem + (k & 1) * C::STAGE;
             const unsigned char* const yimg = sY + by * (C::BM * C::ROW) + lane_off;
             const unsigned char* const ximg = sY + C::Y_BYTES + bx * (C::HP * C::ROW) + lane_off;
-            // software pipeline over (k-step, tap): the Xop fragment of the NEXT tap is read from LDS before the MFMAs of the
-            // current one are issued; the fences pin "reads of the next tap, then MFMAs of this one"
-            bf16x8 af[P], bfr[2][P];
-            auto load_a = [&](int kk) {
+            // software pipeline over the steps (k-step, tap) of the tile: the Xop fragment of step s + 1 -- and, on the last
+            // but one tap of a k-step, the Yop fragment of the next k-step -- is read from LDS WHILE the MFMAs of step s
+            // issue: one or two transposing reads behind every MFMA (issued as one burst in front of them, the reads leave
+            // the matrix pipe idle for most of the burst; a Yop fragment read at the top of its k-step stalls the first MFMA
+            // for the full LDS latency: 7.7 k cycles per tile against 6.9 k of MFMA issue, cycle stamps of round 3)
+            bf16x8 af[2][P], bfr[2][P];
+            auto load_a = [&](int kk, bf16x8 (&dst)[P]) {
                 const int t0 = (ps * C::KS_W + kk) * 16 + 8 * kh + q, t1 = t0 + 4;
 #pragma unroll
-                for (int p = 0; p < P; ++p) af[p] = tr_frag(yimg + t0 * C::ROW + p * 64, yimg + t1 * C::ROW + p * 64);
+                for (int p = 0; p < P; ++p) dst[p] = tr_frag(yimg + t0 * C::ROW + p * 64, yimg + t1 * C::ROW + p * 64);
             };
             auto load_b = [&](int kk, int tap, bf16x8 (&bf)[P]) {
                 const int t0 = (ps * C::KS_W + kk) * 16 + 8 * kh + q, t1 = t0 + 4;
@@ -211,23 +293,39 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
                 for (int p = 0; p < P; ++p)
                     bf[p] = tr_frag(ximg + x0 * C::ROW + toff + p * 64, ximg + x1 * C::ROW + toff + p * 64);
             };
+            constexpr int NT_ = C::NTAP, NS = C::KS_W * NT_, TA = NT_ > 1 ? NT_ - 2 : 0, NM = P == 3 ? 6 : 1;
             load_b(0, 0, bfr[0]);
+            load_a(0, af[0]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < C::KS_W; ++kk) {
-                load_a(kk);
+            for (int kk = 0; kk < C::KS_W; ++kk)
 #pragma unroll
-                for (int tap = 0; tap < C::NTAP; ++tap) {
-                    constexpr int NT_ = C::NTAP;
-                    const int cur = (kk * NT_ + tap) & 1;
-                    if (tap + 1 < NT_) load_b(kk, tap + 1, bfr[cur ^ 1]);
-                    else if (kk + 1 < C::KS_W) load_b(kk + 1, 0, bfr[cur ^ 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[tap] = mma<P>(af, bfr[cur], acc[tap]);
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int tap = 0; tap < NT_; ++tap) {
+                const int st = kk * NT_ + tap;
+                const bool has_b = st + 1 < NS, has_a = tap == TA && kk + 1 < C::KS_W;
+                if (has_b) load_b((st + 1) / NT_, (st + 1) % NT_, bfr[(st + 1) & 1]);
+                if (has_a) load_a(kk + 1, af[(kk + 1) & 1]);
+                acc[tap] = mma<P>(af[kk & 1], bfr[st & 1], acc[tap]);
+                const int NR = 2 * P * ((has_b ? 1 : 0) + (has_a ? 1 : 0));
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+                    const int cnt = (i + 1) * NR / NM - i * NR / NM;                      // the LDS reads that fall to it (literals)
+                    if (cnt == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else if (cnt == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else if (cnt == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    else if (cnt == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    else if (cnt > 4) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            WS_T(t1);
             wg_barrier();                                // every consumer is done with this tile's buffers; tile k + 1 is staged
+            WS_T(t2);
+            WS_ACC(0, t0, t1);
+            WS_ACC(1, t1, t2);
         }
+        WS_T(tp2);
         // ---- waves that split the tile's k-steps (WP > 1) add their accumulators through LDS, TC taps at a time.  The
         // producers are past their last barrier (they wrote nothing after it): the staging area is free
         if constexpr (C::WP > 1) {
@@ -254,6 +352,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
                 }
             }
         }
+        WS_T(tp3);
         // ---- the workgroup's partial slab: rows (reg) = cy, cols (lane & 31) = cx
         if (ps == 0) {
             float* slab = a.slab + (size_t)split * d.slab_stride;
@@ -269,6 +368,15 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
                 }
             }
         }
+#ifdef RFI_DIAG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_T(tp4);
+        if (d.stamps && lane == 0) {
+            unsigned long long* o = d.stamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+            o[0] = st_[0]; o[1] = st_[1]; o[2] = (unsigned long long)my_tiles;
+            o[3] = tp1 - tp0; o[4] = tp2 - tp1; o[5] = tp3 - tp2; o[6] = tp4 - tp3;
+        }
+#endif
     }
 }
 
@@ -285,18 +393,18 @@ Plan plan_cfg(const WgradArgs& a) {
     return Plan{nsplit, (int64_t)R * R * a.tap_stride};
 }
 
-template <int R, int BYB, int BXB, int TH, int TW, int P>
+template <int R, int BYB, int BXB, int TH, int TW, int P, int XM>
 void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
     using C = WWCfg<R, BYB, BXB, TH, TW, P>;
     const Plan p = plan_cfg<R, BYB, BXB, TH, TW>(a);
     RFI_REQUIRE(a.slab && a.slab_floats >= (size_t)p.nsplit * p.slab_stride, "wgrad_ws: slab workspace too small");
     WWsDev d{a, p.nsplit, p.slab_stride, (unsigned)((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride * 4),
-             (unsigned)((int64_t)a.N * a.H * a.W * a.yop.pstride * 4)};
+             (unsigned)((int64_t)a.N * a.H * a.W * a.yop.pstride * 4), nullptr};
     dim3 grid(p.nsplit, (unsigned)cdiv(a.Cy, 32 * BYB), (unsigned)cdiv(a.Cx, 32 * BXB));
     const size_t lds = C::LDS_BYTES;
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<R, BYB, BXB, TH, TW, P>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<R, BYB, BXB, TH, TW, P, XM>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
     {
@@ -308,8 +416,25 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
                     std::to_string(p.nsplit) + (P == 3 ? " 3xbf16" : " bf16");
         const double bytes = 4.0 * ((double)a.N * a.Hx * a.Wx * a.Cx + (double)a.N * a.H * a.W * a.Cy + (double)R * R * a.Cx * a.Cy);
         ProfScope ps(ctx, FAM_WGRAD_MFMA, flops, bytes, label);
-        hipLaunchKernelGGL((wgrad_ws_kernel<R, BYB, BXB, TH, TW, P>), grid, dim3(512), lds, ctx->stream, d);
+#ifdef RFI_DIAG_STAMPS
+        const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
+        RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d.stamps), nw * 64));
+        RFI_CHECK_HIP(hipMemsetAsync(d.stamps, 0, nw * 64, ctx->stream));
+#endif
+        hipLaunchKernelGGL((wgrad_ws_kernel<R, BYB, BXB, TH, TW, P, XM>), grid, dim3(512), lds, ctx->stream, d);
         check_launch("wgrad_ws");
+#ifdef RFI_DIAG_STAMPS
+        std::vector<unsigned long long> hs(nw * 8);
+        RFI_CHECK_HIP(hipMemcpyAsync(hs.data(), d.stamps, nw * 64, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        double c[7] = {0, 0, 0, 0, 0, 0, 0}, pr[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < nw; ++w)
+            for (int i = 0; i < 7; ++i) ((w & 7) < 4 ? c : pr)[i] += (double)hs[w * 8 + i];
+        std::fprintf(stderr, "[stamps] wgrad_ws<%d,%d,%d,%d,%d> N%d %dx%d cx%d cy%d grid %ux%ux%u tiles/wg %.1f | cycles per tile: consumer mfma %.0f "
+                     "barrier %.0f | producer work %.0f barrier %.0f | per consumer wave: prologue %.0f loop %.0f reduce %.0f slab store %.0f\n", R, BYB, BXB, TH, TW, a.N, a.H, a.W, a.Cx, a.Cy, grid.x, grid.y, grid.z,
+                     c[2] / (nw / 2), c[0] / c[2], c[1] / c[2], pr[0] / pr[2], pr[1] / pr[2], c[3] / (nw / 2), c[4] / (nw / 2), c[5] / (nw / 2), c[6] / (nw / 2));
+        RFI_CHECK_HIP(hipFree(d.stamps));
+#endif
     }
     launch_reduce_slabs(ctx, a.slab, p.nsplit, p.slab_stride, a.dw);
 }
@@ -318,10 +443,19 @@ template <int R>
 void select(rfi_ctx* ctx, const WgradArgs& a) {
     const bool y2 = a.Cy > 32, x2 = a.Cx > 32;
     const bool p1 = a.bf16 && !a.bf16x3;
+    // XM = 1 (compile-time transform) for the case that carries the U-Net: 3x3, Xop behind BatchNorm + ReLU, Yop plain
+    const bool xm1 = R == 3 && a.xf_x.scale && a.xf_x.relu == 1 && a.xf_x.slope == 0.0f && !a.xf_y.scale;
 #define RFI_WW(BYB_, BXB_, TH_, TW_)                                                \
     do {                                                                            \
-        if (p1) launch_cfg<R, BYB_, BXB_, TH_, TW_, 1>(ctx, a);                     \
-        else launch_cfg<R, BYB_, BXB_, TH_, TW_, 3>(ctx, a);                        \
+        if constexpr (R == 3) {                                                     \
+            if (xm1) {                                                              \
+                if (p1) launch_cfg<R, BYB_, BXB_, TH_, TW_, 1, 1>(ctx, a);          \
+                else launch_cfg<R, BYB_, BXB_, TH_, TW_, 3, 1>(ctx, a);             \
+                return;                                                             \
+            }                                                                       \
+        }                                                                           \
+        if (p1) launch_cfg<R, BYB_, BXB_, TH_, TW_, 1, 2>(ctx, a);                  \
+        else launch_cfg<R, BYB_, BXB_, TH_, TW_, 3, 2>(ctx, a);                     \
         return;                                                                     \
     } while (0)
     if (y2 && x2) RFI_WW(2, 2, 8, 8);
@@ -338,7 +472,9 @@ void select(rfi_ctx* ctx, const WgradArgs& a) {
 bool wgrad_ws_eligible(const WgradArgs& a) {
     if (a.Cx % 4 || a.Cy % 4 || a.xop.pstride % 4 || a.yop.pstride % 4) return false;
     if ((reinterpret_cast<uintptr_t>(a.xop.p) & 15) || (reinterpret_cast<uintptr_t>(a.yop.p) & 15)) return false;
-    if ((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride * 4 >= (int64_t)1 << 31 || (int64_t)a.N * a.H * a.W * a.yop.pstride * 4 >= (int64_t)1 << 31) return false;
+    // (tile bases + an item's relative offset are formed in 32 bits; NOWHERE in the kernel needs bases in (-2^24, 0x7f000000))
+    if ((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride * 4 >= 0x7f000000ll || (int64_t)a.N * a.H * a.W * a.yop.pstride * 4 >= 0x7f000000ll) return false;
+    if (((int64_t)a.Wx + 1) * a.xop.pstride * 4 >= (1 << 24)) return false;
     if (a.S != 1) return false;
     return (a.R == 3 && a.pad == 1) || (a.R == 2 && a.pad == 1) || (a.R == 1 && a.pad == 0);
 }

@@ -2,6 +2,15 @@
 #pragma once
 #include "planes.hpp"
 
+// RFI_DIAG_STAMPS builds (tools/build_diag.sh, never shipped): per-wave cycle sums of the phases of a kernel's main loop
+#ifdef RFI_DIAG_STAMPS
+#define WS_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define WS_ACC(i, a_, b_) st_[i] += (b_) - (a_)
+#else
+#define WS_T(v)
+#define WS_ACC(i, a_, b_)
+#endif
+
 namespace rfi {
 namespace ws {
 
@@ -20,6 +29,9 @@ __device__ __forceinline__ unsigned cvt_pair(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 // v = h + m + l, each piece RNE-rounded to bf16 (exact: 3 x 8 significand bits cover float32's 24)
+// (v_dot2c_f32_bf16 forms a residual "a - float(h.lo)" in one instruction, bit-identically (tools/probe_dot2_split.hip), but
+// beside MFMA waves it is SLOWER than shift + subtract -- producer time per item 5.1 k -> 10.1 k cycles, round 3 -- the dot
+// instructions appear to share the matrix pipe)
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
     h = cvt_pair(a, b);
     const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
