@@ -371,6 +371,11 @@ int rfi_op_roi_align(rfi_ctx* ctx, const float* x, int n, int h, int w, int c, c
 int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, const float* rois,
                               int r, float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
                               float* dx);
+/* mask_targets: the training targets of the mask branch -- RoIAlign (rules above, scale 1, not aligned) of one-channel
+ * uint8 instance masks [g][h][w], thresholded at 0.5: rois[r] = (instance index, x1, y1, x2, y2) -> out uint8 [r][ph][pw].
+ * Device pointers. */
+int rfi_op_mask_targets(rfi_ctx* ctx, const uint8_t* masks, int g, int h, int w, const float* rois, int r, int ph, int pw,
+                        int sampling_ratio, uint8_t* out);
 /* Region-proposal pieces (not in the reference: Faster R-CNN's box parameterisation and RPN loss, greedy IoU
  * NMS, oracle/detection_ref.py).  All tensors device pointers unless named *_host.
  * box_decode: boxes[n][4] = decode(anchors[n_anchors][4] repeating, deltas[n][4]) (weights 1, dw/dh <= log(1000/16)),
@@ -388,6 +393,17 @@ int rfi_op_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, con
 int rfi_op_anchor_match(rfi_ctx* ctx, const float* anchors, int64_t n, const float* gt_boxes, int n_gt, float fg_iou, float bg_iou,
                         int allow_low_quality, int8_t* labels, int32_t* matched, float* targets);
 int rfi_op_nms(rfi_ctx* ctx, const float* boxes_sorted, int n, float iou_threshold, int32_t* keep_host, int* n_keep);
+/* Batched forms -- one launch for every image of a batch, all tensors device pointers.
+ * anchor_match_batched: anchors shared by the images (anchor_stride 0: [n][4]) or per image (anchor_stride = n:
+ *   [images][n][4] with anchor_count[b] valid rows -- the proposals of the RoI stage; null: all n); gt_boxes
+ *   [images][gt_max][4] with gt_count[b] valid rows; labels / matched [images][n], targets [images][n][4] (may be null).  A row
+ *   beyond anchor_count[b] gets label -2.
+ * nms_batched: `sets` independent sets of at most k <= 256 boxes, each sorted by descending score ([sets][k][4], count[s]
+ *   valid rows) -> keep uint8 [sets][k] (1 kept, 0 suppressed or beyond count). */
+int rfi_op_anchor_match_batched(rfi_ctx* ctx, const float* anchors, int64_t n, int64_t anchor_stride, const int32_t* anchor_count,
+                                const float* gt_boxes, int images, int gt_max, const int32_t* gt_count, float fg_iou, float bg_iou,
+                                int allow_low_quality, int8_t* labels, int32_t* matched, float* targets);
+int rfi_op_nms_batched(rfi_ctx* ctx, const float* boxes_sorted, const int32_t* count, int sets, int k, float iou_threshold, uint8_t* keep);
 int rfi_op_rpn_loss(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
                     const float* targets, int64_t num_sampled, float beta, float* dhead, float* loss_objectness,
                     float* loss_box);

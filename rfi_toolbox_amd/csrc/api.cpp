@@ -1731,6 +1731,13 @@ int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int
         launch_roi_align_bwd(ctx, dout, n, h, w, c, rois, r, spatial_scale, ph, pw, sampling_ratio, aligned != 0, dx);
     });
 }
+int rfi_op_mask_targets(rfi_ctx* ctx, const uint8_t* masks, int g, int h, int w, const float* rois, int r, int ph, int pw,
+                        int sampling_ratio, uint8_t* out) {
+    return guarded([&] {
+        ctx->activate();
+        launch_mask_targets(ctx, masks, g, h, w, rois, r, ph, pw, sampling_ratio, out);
+    });
+}
 int rfi_op_box_decode(rfi_ctx* ctx, const float* anchors, int64_t n_anchors, const float* deltas, int64_t n, float clip_h,
                       float clip_w, float* boxes) {
     return guarded([&] {
@@ -1789,6 +1796,24 @@ int rfi_op_nms(rfi_ctx* ctx, const float* boxes_sorted, int n, float iou_thresho
             for (int w = i / 64; w < words; ++w) removed[w] |= row[w];
         }
         *n_keep = k;
+    });
+}
+int rfi_op_anchor_match_batched(rfi_ctx* ctx, const float* anchors, int64_t n, int64_t anchor_stride, const int32_t* anchor_count,
+                                const float* gt_boxes, int images, int gt_max, const int32_t* gt_count, float fg_iou, float bg_iou,
+                                int allow_low_quality, int8_t* labels, int32_t* matched, float* targets) {
+    return guarded([&] {
+        ctx->activate();
+        float* best = static_cast<float*>(ctx->alloc((size_t)images * gt_max * 4 + 16));
+        struct Free { rfi_ctx* c; void* p; ~Free() { try { c->release(p); } catch (...) {} } } fr{ctx, best};
+        launch_anchor_match_batched(ctx, anchors, n, anchor_stride, anchor_count, gt_boxes, images, gt_max, gt_count, fg_iou, bg_iou,
+                                    allow_low_quality != 0, best, reinterpret_cast<signed char*>(labels), matched, targets);
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // (the workspace is released on return)
+    });
+}
+int rfi_op_nms_batched(rfi_ctx* ctx, const float* boxes_sorted, const int32_t* count, int sets, int k, float iou_threshold, uint8_t* keep) {
+    return guarded([&] {
+        ctx->activate();
+        launch_nms_batched(ctx, boxes_sorted, count, sets, k, iou_threshold, keep);
     });
 }
 int rfi_op_rpn_loss(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,

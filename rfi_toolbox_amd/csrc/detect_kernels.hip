@@ -79,6 +79,37 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
     }
 }
 
+// mask-branch targets: RoIAlign (same sampling rules, scale 1) of ONE-channel uint8 instance masks, thresholded at 0.5.
+// rois[r] = (instance index into masks[G][H][W], x1, y1, x2, y2); out[r][ph][pw] in {0, 1}.  thread = (roi, ph, pw)
+__global__ __launch_bounds__(256) void mask_targets_kernel(const unsigned char* __restrict__ masks, int G, int H, int W,
+                                                          const float* __restrict__ rois, int R, int PH, int PW, int sr,
+                                                          unsigned char* __restrict__ out) {
+    const int64_t total = (int64_t)R * PH * PW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH);
+        const int r = (int)(t / PH);
+        const RoiGeom g = roi_geom(rois, r, 1.0f, PH, PW, sr, false);
+        float acc = 0.0f;
+        if (g.n >= 0 && g.n < G) {
+            const unsigned char* mb = masks + (int64_t)g.n * H * W;
+            for (int iy = 0; iy < g.gh; ++iy) {
+                const float yy = g.y1 + ph * g.bh + (iy + 0.5f) * g.bh / g.gh;
+                for (int ix = 0; ix < g.gw; ++ix) {
+                    const float xx = g.x1 + pw * g.bw + (ix + 0.5f) * g.bw / g.gw;
+                    const Bilin b = bilin(yy, xx, H, W);
+                    if (!b.ok) continue;
+                    acc += (float)mb[(int64_t)b.y0 * W + b.x0] * b.w00 + (float)mb[(int64_t)b.y0 * W + b.x1] * b.w01 +
+                           (float)mb[(int64_t)b.y1 * W + b.x0] * b.w10 + (float)mb[(int64_t)b.y1 * W + b.x1] * b.w11;
+                }
+            }
+            acc = acc * (1.0f / (float)(g.gh * g.gw > 0 ? g.gh * g.gw : 1));
+        }
+        out[i] = acc >= 0.5f ? 1 : 0;
+    }
+}
+
 // backward: scatter dout / count through the same bilinear weights (float atomics: the sum over overlapping
 // RoIs is order dependent in the last bits, like the published implementations)
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restrict__ dout, int N, int H, int W, int C,
@@ -163,6 +194,15 @@ void launch_roi_align_fwd(rfi_ctx* ctx, const float* x, int N, int H, int W, int
     hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(grid_of((int64_t)R * PH * PW * C / 4)), dim3(256), 0, ctx->stream, x, N, H, W, C,
                        rois, R, scale, PH, PW, sampling_ratio, aligned ? 1 : 0, out);
     check_launch("roi_align_fwd");
+}
+void launch_mask_targets(rfi_ctx* ctx, const unsigned char* masks, int G, int H, int W, const float* rois, int R, int PH, int PW,
+                         int sr, unsigned char* out) {
+    RFI_REQUIRE(G > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 0, "mask_targets: positive sizes");
+    if (R == 0) return;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)R * PH * PW * (1.0 + 4.0 * (sr > 0 ? sr * sr : 4)));
+    hipLaunchKernelGGL(mask_targets_kernel, dim3(grid_of((int64_t)R * PH * PW)), dim3(256), 0, ctx->stream, masks, G, H, W, rois, R,
+                       PH, PW, sr, out);
+    check_launch("mask_targets");
 }
 void launch_roi_align_bwd(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, const float* rois, int R, float scale,
                           int PH, int PW, int sampling_ratio, bool aligned, float* dx) {

@@ -221,7 +221,132 @@ __global__ __launch_bounds__(kB) void box_encode_kernel(const float* __restrict_
     }
 }
 
+// ---- batched forms (one launch for every image of a batch): blockIdx.y = image.  Anchors are shared (stride 0) or per
+// image ([B][n][4], `acount[b]` of them valid: the proposals of the RoI stage); ground truth [B][Gmax][4] with gcount[b]
+__global__ __launch_bounds__(kB) void gt_best_iou_batched_kernel(const float* __restrict__ anchors, int64_t n, int64_t astride,
+                                                                const int* __restrict__ acount, const float* __restrict__ gt, int Gmax,
+                                                                const int* __restrict__ gcount, float* __restrict__ best) {
+    __shared__ float red[kB];
+    const int b = blockIdx.y, g = blockIdx.x;
+    if (g >= gcount[b]) return;                       // (uniform for the block)
+    const float* an = anchors + (int64_t)b * astride * 4;
+    const int64_t na = acount ? acount[b] : n;
+    const float4 gb = *reinterpret_cast<const float4*>(gt + ((int64_t)b * Gmax + g) * 4);
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < na; i += kB) m = fmaxf(m, iou_of(gb, *reinterpret_cast<const float4*>(an + i * 4)));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = kB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) best[(int64_t)b * Gmax + g] = red[0];
+}
+// labels as anchor_match_kernel; an entry beyond acount[b] gets label -2 (not a box), matched -1, zero targets
+__global__ __launch_bounds__(kB) void anchor_match_batched_kernel(const float* __restrict__ anchors, int64_t n, int64_t astride,
+                                                                 const int* __restrict__ acount, const float* __restrict__ gt, int Gmax,
+                                                                 const int* __restrict__ gcount, const float* __restrict__ best, float hi,
+                                                                 float lo, int low_quality, signed char* __restrict__ labels,
+                                                                 int* __restrict__ matched, float* __restrict__ targets) {
+    const int b = blockIdx.y;
+    const float* an = anchors + (int64_t)b * astride * 4;
+    const float* gb = gt + (int64_t)b * Gmax * 4;
+    const int G = gcount[b];
+    const int64_t na = acount ? acount[b] : n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int lab = -2, mi = -1;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < na) {
+            const float4 a = *reinterpret_cast<const float4*>(an + i * 4);
+            float mv = -1.0f;
+            bool lq = false;
+            for (int g = 0; g < G; ++g) {
+                const float v = iou_of(*reinterpret_cast<const float4*>(gb + (int64_t)g * 4), a);
+                if (v > mv) { mv = v; mi = g; }
+                lq = lq || (low_quality && v == best[(int64_t)b * Gmax + g] && v > 0.0f);
+            }
+            lab = G == 0 ? 0 : (mv >= hi ? 1 : (mv < lo ? 0 : -1));
+            if (lq) lab = 1;
+            if (lab != 1) mi = -1;
+            if (mi >= 0 && targets) {
+                const float4 g = *reinterpret_cast<const float4*>(gb + (int64_t)mi * 4);
+                const float aw = a.z - a.x, ah = a.w - a.y, gw = g.z - g.x, gh = g.w - g.y;
+                t = make_float4(((g.x + 0.5f * gw) - (a.x + 0.5f * aw)) / aw, ((g.y + 0.5f * gh) - (a.y + 0.5f * ah)) / ah, logf(gw / aw),
+                                logf(gh / ah));
+            }
+        }
+        labels[(int64_t)b * n + i] = (signed char)lab;
+        matched[(int64_t)b * n + i] = mi;
+        if (targets) *reinterpret_cast<float4*>(targets + ((int64_t)b * n + i) * 4) = t;
+    }
+}
+
+// greedy NMS of B independent sets of at most K <= 256 boxes, each sorted by descending score: one workgroup per set builds
+// the suppression matrix (bit j of row i: j > i and IoU > thr) in LDS, its first thread runs the greedy scan.  keep[b][i] = 1
+// for the boxes kept, 0 for the suppressed ones and for i >= count[b]
+constexpr int kNmsK = 256;
+__global__ __launch_bounds__(kNmsK) void nms_batched_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int K, float thr,
+                                                           unsigned char* __restrict__ keep) {
+    __shared__ float4 bx[kNmsK];
+    __shared__ unsigned long long sup[kNmsK][kNmsK / 64];
+    const int b = blockIdx.x, i = threadIdx.x;
+    const int n = min(count[b], K);
+    if (i < n) bx[i] = *reinterpret_cast<const float4*>(boxes + ((int64_t)b * K + i) * 4);
+    __syncthreads();
+    if (i < n) {
+        const float4 a = bx[i];
+        const float area_a = (a.z - a.x) * (a.w - a.y);
+        for (int w = 0; w < kNmsK / 64; ++w) {
+            unsigned long long bits = 0;
+            for (int k = 0; k < 64; ++k) {
+                const int j = w * 64 + k;
+                if (j <= i || j >= n) continue;
+                const float4 c = bx[j];
+                const float iw = fmaxf(fminf(a.z, c.z) - fmaxf(a.x, c.x), 0.0f), ih = fmaxf(fminf(a.w, c.w) - fmaxf(a.y, c.y), 0.0f);
+                const float inter = iw * ih, uni = area_a + (c.z - c.x) * (c.w - c.y) - inter;
+                if (inter > thr * uni) bits |= 1ull << k;
+            }
+            sup[i][w] = bits;
+        }
+    }
+    __syncthreads();
+    if (i == 0) {
+        unsigned long long removed[kNmsK / 64] = {0ull, 0ull, 0ull, 0ull};
+        for (int r = 0; r < K; ++r) {
+            const bool kept = r < n && !((removed[r / 64] >> (r % 64)) & 1ull);
+            keep[(int64_t)b * K + r] = kept ? 1 : 0;
+            if (kept)
+                for (int w = r / 64; w < kNmsK / 64; ++w) removed[w] |= sup[r][w];
+        }
+    }
+}
+
 }  // namespace
+
+void launch_anchor_match_batched(rfi_ctx* ctx, const float* anchors, int64_t n, int64_t anchor_stride, const int* anchor_count,
+                                 const float* gt, int B, int Gmax, const int* gt_count, float hi, float lo, bool low_quality,
+                                 float* best_ws, signed char* labels, int* matched, float* targets) {
+    RFI_REQUIRE(n > 0 && B > 0 && Gmax > 0, "anchor_match_batched: empty input");
+    RFI_REQUIRE(!((reinterpret_cast<uintptr_t>(anchors) | reinterpret_cast<uintptr_t>(gt) | reinterpret_cast<uintptr_t>(targets)) & 15),
+                "anchor_match_batched: 16-byte aligned boxes");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)B * n * (16.0 * 2 + 21));
+    hipLaunchKernelGGL(gt_best_iou_batched_kernel, dim3(Gmax, B), dim3(kB), 0, ctx->stream, anchors, n, anchor_stride, anchor_count, gt,
+                       Gmax, gt_count, best_ws);
+    check_launch("gt_best_iou_batched");
+    int64_t b = cdiv(n, kB);
+    if (b > 256) b = 256;
+    hipLaunchKernelGGL(anchor_match_batched_kernel, dim3((unsigned)b, B), dim3(kB), 0, ctx->stream, anchors, n, anchor_stride,
+                       anchor_count, gt, Gmax, gt_count, best_ws, hi, lo, low_quality ? 1 : 0, labels, matched, targets);
+    check_launch("anchor_match_batched");
+}
+
+void launch_nms_batched(rfi_ctx* ctx, const float* boxes, const int* count, int B, int K, float thr, unsigned char* keep) {
+    RFI_REQUIRE(B > 0 && K > 0 && K <= kNmsK, "nms_batched: at most 256 boxes per set");
+    RFI_REQUIRE(!(reinterpret_cast<uintptr_t>(boxes) & 15), "nms_batched: 16-byte aligned boxes");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)B * K * 17);
+    hipLaunchKernelGGL(nms_batched_kernel, dim3(B), dim3(kNmsK), 0, ctx->stream, boxes, count, K, thr, keep);
+    check_launch("nms_batched");
+}
 
 void launch_anchor_match(rfi_ctx* ctx, const float* anchors, int64_t n, const float* gt, int G, float hi, float lo, bool low_quality,
                          float* best_ws, signed char* labels, int* matched, float* targets) {

@@ -152,3 +152,54 @@ def fastrcnn_loss(head, labels, targets, beta=1.0 / 9, device=None):
     lc, lb = C.c_float(), C.c_float()
     check(lib.rfi_op_fastrcnn_loss(ctx.handle, _p(dh), r, k1, _p(dl), _p(dt), float(beta), _p(dg), C.byref(lc), C.byref(lb)))
     return lc.value, lb.value, dg.numpy()
+
+
+# ---------------------------------------------------------------- batched forms: one launch for a whole batch of images
+def _gt_pack(gt_list):
+    """list of (g_i, 4) arrays -> padded (B, Gmax, 4) float32 + counts (B,) int32."""
+    gs = [np.asarray(g, np.float32).reshape(-1, 4) for g in gt_list]
+    gmax = max(1, max(len(g) for g in gs))
+    out = np.zeros((len(gs), gmax, 4), np.float32)
+    for i, g in enumerate(gs):
+        out[i, :len(g)] = g
+    return out, np.asarray([len(g) for g in gs], np.int32)
+
+
+def anchor_match_batched(anchors, gt_list, fg_iou=0.7, bg_iou=0.3, allow_low_quality=True, anchor_counts=None, device=None):
+    """``anchor_match`` for every image of a batch in one launch.  ``anchors``: (n, 4) shared by the images, or (B, n, 4) per
+    image with ``anchor_counts`` (B,) valid rows each (rows beyond get label -2).  -> labels int8 (B, n), matched int32
+    (B, n), targets float32 (B, n, 4)."""
+    ctx = Context.get(device)
+    a = np.ascontiguousarray(np.asarray(anchors, np.float32))
+    gt, gc = _gt_pack(gt_list)
+    B = len(gc)
+    shared = a.ndim == 2
+    n = a.shape[-2]
+    if not shared and a.shape[0] != B:
+        raise ValueError("per-image anchors need one block per image")
+    da, dg, dgc = ctx.to_device(a), ctx.to_device(gt), ctx.to_device(gc)
+    dac = None if anchor_counts is None else ctx.to_device(np.ascontiguousarray(np.asarray(anchor_counts, np.int32)))
+    labels, matched, targets = ctx.empty((B, n), np.int8), ctx.empty((B, n), np.int32), ctx.empty((B, n, 4), np.float32)
+    check(lib.rfi_op_anchor_match_batched(ctx.handle, _p(da), n, 0 if shared else n, None if dac is None else _p(dac), _p(dg), B,
+                                          gt.shape[1], _p(dgc), float(fg_iou), float(bg_iou), 1 if allow_low_quality else 0,
+                                          _p(labels), _p(matched), _p(targets)))
+    return labels.numpy(), matched.numpy(), targets.numpy()
+
+
+def nms_batched(boxes_sorted, counts, iou_threshold, device=None):
+    """Greedy NMS of B independent sets: ``boxes_sorted`` (B, K, 4) with K <= 256, every set in descending score order and
+    ``counts[b]`` valid rows.  -> keep bool (B, K)."""
+    ctx = Context.get(device)
+    b = np.ascontiguousarray(np.asarray(boxes_sorted, np.float32))
+    if b.ndim != 3 or b.shape[2] != 4 or b.shape[1] > 256:
+        raise ValueError("boxes_sorted must be (B, K <= 256, 4)")
+    c = np.ascontiguousarray(np.asarray(counts, np.int32).reshape(-1))
+    if len(c) != b.shape[0]:
+        raise ValueError("one count per set")
+    if b.shape[0] == 0 or b.shape[1] == 0:
+        return np.zeros(b.shape[:2], bool)
+    db, dc = ctx.to_device(b), ctx.to_device(c)
+    keep = ctx.empty(b.shape[:2], np.uint8)
+    check(lib.rfi_op_nms_batched(ctx.handle, _p(db), _p(dc), b.shape[0], b.shape[1], float(iou_threshold), _p(keep)))
+    ctx.synchronize()
+    return keep.numpy().astype(bool)

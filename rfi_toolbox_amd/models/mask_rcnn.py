@@ -5,8 +5,9 @@ pipeline (He et al. 2017) from the models and kernels of this package -- ``ResNe
 the five pyramid levels (``accumulate_gradients``), ``anchor_match`` / ``rpn_loss`` / ``decode_boxes`` / ``nms``,
 multi-level ``roi_align``, ``BoxHead`` with ``fastrcnn_loss``, ``MaskHead``.  Every contraction, loss and gather runs on
 the GPU; this class is the host-side bookkeeping between them (anchor grids, the random samplers, level assignment, score
-thresholds, mask pasting), with host round trips between the stages -- it defines the API, it is not the fast path
-(``tools/bench_maskrcnn_lite.py`` times the device-resident chain).  Conventions where implementations differ: box-coder
+thresholds, mask pasting).  ``train_step`` keeps every feature map, RoI feature, activation and gradient in HBM and calls
+the C-ABI on device pointers; what crosses to the host is the box bookkeeping (RPN head outputs for the top-k, labels of the
+batched matcher, the sampled index sets, five loss scalars).  ``predict`` is the plain host-array form.  Conventions where implementations differ: box-coder
 weights 1 in both stages, four anchors per pixel (aspect ratios 0.5, 1, 2 and a 1.5x square), level assignment
 ``k = floor(k0 + log2(sqrt(area) / s0))`` with ``(k0, s0) = (4, image_size / 2)``.
 
@@ -16,10 +17,12 @@ weights 1 in both stages, four anchors per pixel (aspect ratios 0.5, 1, 2 and a 
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import numpy as np
 
+from .._lib import DEVICE, HOST, check, lib
 from . import detection_ops as ops
 from .backbone import ResNet50FPN
 from .box_head import BoxHead
@@ -105,20 +108,28 @@ class MaskRCNN:
 
     def _proposals(self, rpn_out, anchors, n, h, w, extra=None):
         """Per image: top ``pre_nms`` boxes per level by objectness, decoded and clipped, per-level NMS, the ``post_nms``
-        best overall (+ ``extra`` boxes: the ground truth during training)."""
+        best overall (+ ``extra`` boxes: the ground truth during training).  One decode launch per level and ONE NMS
+        launch for all (image, level) sets."""
+        K = self.pre_nms
+        sets_b = np.zeros((n, len(anchors), K, 4), np.float32)
+        sets_s = np.full((n, len(anchors), K), -np.inf, np.float32)
+        counts = np.zeros((n, len(anchors)), np.int32)
+        for lvl, (o, a) in enumerate(zip(rpn_out, anchors)):
+            oi = np.asarray(o).reshape(n, -1, 20)
+            sc, dl = oi[:, :, :4].reshape(n, -1), oi[:, :, 4:].reshape(n, -1, 4)
+            top = np.argsort(-sc, axis=1, kind="stable")[:, :K]                            # (n, k) anchors by descending score
+            k = top.shape[1]
+            rows = np.arange(n)[:, None]
+            bx = ops.decode_boxes(a[top].reshape(-1, 4), dl[rows, top].reshape(-1, 4), image_size=(h, w)).reshape(n, k, 4)
+            ss = sc[rows, top]
+            ok = ((bx[..., 2] - bx[..., 0]) >= 1e-2) & ((bx[..., 3] - bx[..., 1]) >= 1e-2)
+            for i in range(n):                                                               # drop degenerate boxes, keep the order
+                c = int(ok[i].sum())
+                sets_b[i, lvl, :c], sets_s[i, lvl, :c], counts[i, lvl] = bx[i][ok[i]], ss[i][ok[i]], c
+        keep = ops.nms_batched(sets_b.reshape(-1, K, 4), counts.reshape(-1), self.rpn_nms).reshape(n, len(anchors), K)
         props = []
         for i in range(n):
-            boxes, scores = [], []
-            for lvl, (o, a) in enumerate(zip(rpn_out, anchors)):
-                oi = o[i].reshape(-1, 20)
-                sc, dl = oi[:, :4].reshape(-1), oi[:, 4:].reshape(-1, 4)
-                top = np.argsort(-sc, kind="stable")[:self.pre_nms]
-                b = ops.decode_boxes(a[top], dl[top], image_size=(h, w))        # one delta row per selected anchor
-                ok = ((b[:, 2] - b[:, 0]) >= 1e-2) & ((b[:, 3] - b[:, 1]) >= 1e-2)
-                b, s_ = b[ok], sc[top][ok]
-                keep = ops.nms(b, s_, self.rpn_nms) if len(b) else np.zeros(0, np.int64)
-                boxes.append(b[keep]); scores.append(s_[keep])
-            b, s_ = np.concatenate(boxes), np.concatenate(scores)
+            b, s_ = sets_b[i][keep[i]], sets_s[i][keep[i]]                                   # level-major, score order inside a level
             b = b[np.argsort(-s_, kind="stable")[:self.post_nms]]
             if extra is not None and len(extra[i]):
                 b = np.concatenate([b, np.asarray(extra[i], np.float32).reshape(-1, 4)])
@@ -173,49 +184,64 @@ class MaskRCNN:
         return out
 
     # ---- one optimisation step
-    def train_step(self, images, targets, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0):
-        x = np.ascontiguousarray(np.asarray(images, np.float32))
-        n, h, w, _ = x.shape
-        for m in (self.rpn, self.box, self.mask):
-            m.train()
-        feats = self.backbone.forward_features(x)
-        shapes = [f.shape for f in feats]
-        dfe = [np.zeros(s, np.float32) for s in shapes]
-        anchors = self._anchors(h, w)
-        all_anchors = np.concatenate(anchors)
-        # RPN targets: match, then sample rpn_batch anchors per image (at most half positive)
-        labels = np.empty((n, len(all_anchors)), np.int8)
-        tgts = np.empty((n, len(all_anchors), 4), np.float32)
-        for i in range(n):
-            lab, _, tg = ops.anchor_match(all_anchors, targets[i]["boxes"])
+    # Every feature map, RoI feature, head activation and gradient stays in HBM (device buffers cached per input shape,
+    # C-ABI calls on device pointers); what crosses to the host is the small integer / box bookkeeping: RPN head outputs
+    # for top-k + NMS, anchor / RoI labels from the matcher, the sampled index sets, five loss scalars.
+    def _buffers(self, n, h, w):
+        key = (n, h, w)
+        if getattr(self, "_buf_key", None) == key:
+            return self._buf
+        ctx, F = self.backbone.ctx, self.F
+        b = type("Buffers", (), {})()
+        b.x = ctx.empty((n, h, w, self.backbone.in_channels), np.float32)
+        shapes = [(n, h // s, w // s, F) for s in _STRIDES]
+        b.shapes = shapes
+        b.feats = [ctx.empty(sh, np.float32) for sh in shapes]
+        b.dfe = [ctx.empty(sh, np.float32) for sh in shapes]
+        b.tmp = [ctx.empty(sh, np.float32) for sh in shapes[:4]]
+        b.pf = (C.c_void_p * 5)(*[f.ptr for f in b.feats])
+        b.pdf = (C.c_void_p * 5)(*[f.ptr for f in b.dfe])
+        b.rpn_out = [ctx.empty((sh[0], sh[1], sh[2], 20), np.float32) for sh in shapes]
+        b.rpn_dout = [ctx.empty((sh[0], sh[1], sh[2], 20), np.float32) for sh in shapes]
+        b.rpn_lab = [ctx.empty((sh[0] * sh[1] * sh[2] * 4,), np.int8) for sh in shapes]
+        b.rpn_tgt = [ctx.empty((sh[0] * sh[1] * sh[2] * 4, 4), np.float32) for sh in shapes]
+        R, Rm = n * self.roi_batch, n * (self.roi_batch // 4)
+        b.rois, b.rois_m, b.rois_g = ctx.empty((R, 5), np.float32), ctx.empty((Rm, 5), np.float32), ctx.empty((Rm, 5), np.float32)
+        b.roi7, b.roi7_grad = ctx.empty((R, 7, 7, F), np.float32), ctx.empty((R, 7, 7, F), np.float32)
+        k1 = self.num_classes
+        b.box_out, b.box_dout = ctx.empty((R, 5 * k1), np.float32), ctx.empty((R, 5 * k1), np.float32)
+        b.box_lab, b.box_tgt = ctx.empty((R,), np.int32), ctx.empty((R, 4), np.float32)
+        b.roi14, b.roi14_grad = ctx.empty((Rm, 14, 14, F), np.float32), ctx.empty((Rm, 14, 14, F), np.float32)
+        b.mask_t = ctx.empty((Rm, 28, 28), np.uint8)
+        b.masks, b.masks_n = None, 0
+        self._buf_key, self._buf = key, b
+        return b
+
+    def _rpn_targets(self, all_anchors, targets):
+        """Matcher (IoU 0.7 / 0.3, low-quality matches; one launch for the batch) + the random sampler: rpn_batch anchors
+        per image, at most half positive.  -> labels int8 (n, A) in {1, 0, -1 = not sampled}, regression targets (n, A, 4)."""
+        labels, _, tgts = ops.anchor_match_batched(all_anchors, [t["boxes"] for t in targets])
+        for i in range(len(targets)):
+            lab = labels[i]
             pos, neg = np.flatnonzero(lab == 1), np.flatnonzero(lab == 0)
             npos = min(len(pos), self.rpn_batch // 2)
             lab[self.rng.permutation(pos)[npos:]] = -1
             lab[self.rng.permutation(neg)[self.rpn_batch - npos:]] = -1
-            labels[i], tgts[i] = lab, tg
-        n_sampled = max(int((labels >= 0).sum()), 1)
-        losses = {"loss_objectness": 0.0, "loss_rpn_box_reg": 0.0}
-        rpn_out, off = [], 0
-        self.rpn.accumulate_gradients("begin")
-        for lvl, f in enumerate(feats):
-            cnt = len(anchors[lvl])
-            o = self.rpn.forward_nhwc(f)
-            rpn_out.append(o)
-            lo, lb, dout = ops.rpn_loss(o.reshape(-1, 20), labels[:, off:off + cnt].reshape(-1), tgts[:, off:off + cnt].reshape(-1, 4), 4,
-                                        num_sampled=n_sampled)
-            self.rpn.backward(f, dout)
-            self.rpn.accumulate_gradients("add")
-            dfe[lvl] += self.rpn.input_grad(f.shape)
-            losses["loss_objectness"] += lo
-            losses["loss_rpn_box_reg"] += lb
-            off += cnt
-        self.rpn.accumulate_gradients("end")
-        # RoI heads: proposals (+ ground truth) matched at IoU 0.5, roi_batch per image with at most a quarter foreground
-        props = self._proposals(rpn_out, anchors, n, h, w, extra=[t["boxes"] for t in targets])
+        return labels, tgts
+
+    def _sample_rois(self, props, targets):
+        """Proposals (+ ground truth) matched at IoU 0.5 (one launch for the batch); roi_batch per image with at most a
+        quarter foreground.  -> rois (R, 5), class labels (R,), regression targets (R, 4), matched ground-truth index (R,)
+        (-1: background)."""
+        pmax = max(len(p) for p in props)
+        pb = np.zeros((len(props), pmax, 4), np.float32)
+        for i, p in enumerate(props):
+            pb[i, :len(p)] = p
+        labs, midxs, tgs = ops.anchor_match_batched(pb, [t["boxes"] for t in targets], 0.5, 0.5, False,
+                                                    anchor_counts=[len(p) for p in props])
         rois, rlab, rtgt, rgt = [], [], [], []
         for i, p in enumerate(props):
-            g = np.asarray(targets[i]["boxes"], np.float32).reshape(-1, 4)
-            lab, midx, tg = ops.anchor_match(p, g, 0.5, 0.5, False)
+            lab, midx, tg = labs[i, :len(p)], midxs[i, :len(p)], tgs[i, :len(p)]
             pos, neg = np.flatnonzero(lab == 1), np.flatnonzero(lab == 0)
             npos = min(len(pos), self.roi_batch // 4)
             pos, neg = self.rng.permutation(pos)[:npos], self.rng.permutation(neg)[:self.roi_batch - npos]
@@ -224,30 +250,117 @@ class MaskRCNN:
             cls[:npos] = np.asarray(targets[i]["labels"], np.int32).reshape(-1)[midx[pos]]
             rois.append(np.concatenate([np.full((len(keep), 1), i, np.float32), p[keep]], 1))
             rlab.append(cls); rtgt.append(tg[keep]); rgt.append(np.where(np.arange(len(keep)) < npos, midx[keep], -1))
-        rois, rlab, rtgt, rgt = np.concatenate(rois), np.concatenate(rlab), np.concatenate(rtgt), np.concatenate(rgt)
-        rf, lv = self._roi_align(feats, rois, 7, max(h, w))
-        head = self.box.forward_rois(rf)
-        lc, lr_, dout = ops.fastrcnn_loss(head, rlab, rtgt)
-        self.box.backward(rf, dout)
-        self._roi_align_backward(self.box.input_grad(rf.shape), shapes, rois, lv, dfe)
-        losses["loss_classifier"], losses["loss_box_reg"] = lc, lr_
-        # mask branch on the foreground RoIs: targets = the matched ground-truth mask, RoIAligned to 28 x 28
+        return np.concatenate(rois), np.concatenate(rlab), np.concatenate(rtgt).astype(np.float32), np.concatenate(rgt)
+
+    def _roi_align_dev(self, b, rois_dev, lv, out_dev, res, backward=False, grad_dev=None):
+        """Multi-level RoIAlign on device buffers; the RoIs are SORTED by level, so level k is one contiguous slice of the
+        RoI list and of the output.  backward: RoI-feature gradients -> added to the level's feature gradient."""
+        ctx, F = self.backbone.ctx, self.F
+        off = 0
+        for k in range(4):
+            cnt = int((lv == k).sum())
+            if cnt:
+                n, hk, wk, _ = b.shapes[k]
+                rp = C.c_void_p(rois_dev.ptr + off * 20)
+                fp = C.c_void_p((grad_dev if backward else out_dev).ptr + off * res * res * F * 4)
+                if backward:
+                    check(lib.rfi_op_roi_align_backward(ctx.handle, fp, n, hk, wk, F, rp, cnt, 1.0 / _STRIDES[k], res, res, 2, 0,
+                                                        C.c_void_p(b.tmp[k].ptr)))
+                    check(lib.rfi_op_add_inplace(ctx.handle, C.c_void_p(b.dfe[k].ptr), C.c_void_p(b.tmp[k].ptr), n * hk * wk * F))
+                else:
+                    check(lib.rfi_op_roi_align(ctx.handle, C.c_void_p(b.feats[k].ptr), n, hk, wk, F, rp, cnt, 1.0 / _STRIDES[k],
+                                               res, res, 2, 0, fp))
+            off += cnt
+
+    def train_step(self, images, targets, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0):
+        x = np.ascontiguousarray(np.asarray(images, np.float32))
+        n, h, w, _ = x.shape
+        ctx, F, k1 = self.backbone.ctx, self.F, self.num_classes
+        P = lambda d: C.c_void_p(d.ptr)  # noqa: E731
+        for m in (self.rpn, self.box, self.mask):
+            m.train()
+        b = self._buffers(n, h, w)
+        b.x.copy_from(x)
+        check(lib.rfi_backbone_forward(self.backbone._h, P(b.x), DEVICE, n, h, w, b.pf, DEVICE))
+        anchors = self._anchors(h, w)
+        all_anchors = np.concatenate(anchors)
+        labels, tgts = self._rpn_targets(all_anchors, targets)
+        n_sampled = max(int((labels >= 0).sum()), 1)
+        losses = {"loss_objectness": 0.0, "loss_rpn_box_reg": 0.0}
+        rpn_out, off = [], 0
+        lo, lb = C.c_float(), C.c_float()
+        self.rpn.accumulate_gradients("begin")
+        for lvl in range(5):
+            cnt = len(anchors[lvl])
+            _, hl, wl, _ = b.shapes[lvl]
+            b.rpn_lab[lvl].copy_from(labels[:, off:off + cnt].reshape(-1))
+            b.rpn_tgt[lvl].copy_from(tgts[:, off:off + cnt].reshape(-1, 4))
+            check(lib.rfi_model_forward_nhwc(self.rpn._h, P(b.feats[lvl]), DEVICE, n, hl, wl, P(b.rpn_out[lvl]), DEVICE))
+            check(lib.rfi_op_rpn_loss(ctx.handle, P(b.rpn_out[lvl]), n * hl * wl, 4, P(b.rpn_lab[lvl]), P(b.rpn_tgt[lvl]), n_sampled,
+                                      1.0 / 9, P(b.rpn_dout[lvl]), C.byref(lo), C.byref(lb)))
+            check(lib.rfi_model_backward_dlogits(self.rpn._h, P(b.feats[lvl]), DEVICE, P(b.rpn_dout[lvl]), DEVICE, n, hl, wl))
+            self.rpn.accumulate_gradients("add")
+            check(lib.rfi_model_input_grad(self.rpn._h, P(b.dfe[lvl]), DEVICE))          # the first term of d loss / d P_l
+            rpn_out.append(b.rpn_out[lvl].numpy())
+            losses["loss_objectness"] += lo.value
+            losses["loss_rpn_box_reg"] += lb.value
+            off += cnt
+        self.rpn.accumulate_gradients("end")
+        # RoI heads
+        props = self._proposals(rpn_out, anchors, n, h, w, extra=[t["boxes"] for t in targets])
+        rois, rlab, rtgt, rgt = self._sample_rois(props, targets)
+        lv = self._levels(rois[:, 1:], max(h, w))
+        order = np.argsort(lv, kind="stable")                    # level-major: a level is one slice of every RoI tensor
+        rois, rlab, rtgt, rgt, lv = rois[order], rlab[order], rtgt[order], rgt[order], lv[order]
+        R = len(rois)
+        self._upload(b.rois, rois); self._upload(b.box_lab, rlab.astype(np.int32)); self._upload(b.box_tgt, rtgt)
+        self._roi_align_dev(b, b.rois, lv, b.roi7, 7)
+        check(lib.rfi_model_forward_nhwc(self.box._h, P(b.roi7), DEVICE, R, 1, 1, P(b.box_out), DEVICE))
+        lc, lr_ = C.c_float(), C.c_float()
+        check(lib.rfi_op_fastrcnn_loss(ctx.handle, P(b.box_out), R, k1, P(b.box_lab), P(b.box_tgt), 1.0 / 9, P(b.box_dout),
+                                       C.byref(lc), C.byref(lr_)))
+        check(lib.rfi_model_backward_dlogits(self.box._h, P(b.roi7), DEVICE, P(b.box_dout), DEVICE, R, 1, 1))
+        check(lib.rfi_model_input_grad(self.box._h, P(b.roi7_grad), DEVICE))
+        self._roi_align_dev(b, b.rois, lv, None, 7, backward=True, grad_dev=b.roi7_grad)
+        losses["loss_classifier"], losses["loss_box_reg"] = lc.value, lr_.value
+        # mask branch on the foreground RoIs: targets = the matched ground-truth mask, RoIAligned to 28 x 28 at 0.5
         fg = np.flatnonzero(rlab > 0)
         losses["loss_mask"] = 0.0
         if len(fg):
-            mf, mlv = self._roi_align(feats, rois[fg], 14, max(h, w))
-            mt = np.zeros((len(fg), 28, 28), np.uint8)
-            for j, r in enumerate(fg):
-                gm = np.asarray(targets[int(rois[r, 0])]["masks"], np.float32)[rgt[r]]
-                src = np.repeat(gm[None, :, :, None], 4, 3)                   # (1, H, W, 4): the kernels want C % 4 == 0
-                roi = np.concatenate([[0.0], rois[r, 1:]]).astype(np.float32)[None]
-                mt[j] = ops.roi_align(src, roi, 1.0, (28, 28), 2, False)[0, :, :, 0] >= 0.5
-            losses["loss_mask"] = self.mask.forward_backward(mf, mt)
-            self._roi_align_backward(self.mask.input_grad(mf.shape), shapes, rois[fg], mlv, dfe)
-        self.backbone.backward(x, dfe)
-        for m in self.models():
+            gcount = [len(t["boxes"]) for t in targets]
+            gbase = np.concatenate([[0], np.cumsum(gcount)])
+            if b.masks is None or b.masks_n < gbase[-1]:
+                b.masks, b.masks_n = ctx.empty((int(gbase[-1]), h, w), np.uint8), int(gbase[-1])
+            allm = np.concatenate([np.asarray(t["masks"], np.uint8).reshape(-1, h, w) for t in targets])
+            self._upload(b.masks, allm)
+            rm = rois[fg]
+            rg = np.concatenate([(gbase[rm[:, 0].astype(int)] + rgt[fg])[:, None].astype(np.float32), rm[:, 1:]], 1)
+            self._upload(b.rois_m, rm); self._upload(b.rois_g, rg)
+            Rf = len(fg)
+            self._roi_align_dev(b, b.rois_m, lv[fg], b.roi14, 14)
+            check(lib.rfi_op_mask_targets(ctx.handle, P(b.masks), int(gbase[-1]), h, w, P(b.rois_g), Rf, 28, 28, 2, P(b.mask_t)))
+            lm = C.c_float()
+            check(lib.rfi_train_forward_backward(self.mask._h, P(b.roi14), DEVICE, P(b.mask_t), DEVICE, Rf, 14, 14, C.byref(lm)))
+            check(lib.rfi_model_input_grad(self.mask._h, P(b.roi14_grad), DEVICE))
+            self._roi_align_dev(b, b.rois_m, lv[fg], None, 14, backward=True, grad_dev=b.roi14_grad)
+            losses["loss_mask"] = lm.value
+        check(lib.rfi_backbone_backward(self.backbone._h, P(b.x), DEVICE, n, h, w, b.pdf, DEVICE))
+        norms = {}
+        for name, m in zip(("backbone", "rpn", "box", "mask"), self.models()):
             if m is self.mask and not len(fg):
                 continue
-            m.apply_gradients(lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+            norms[name] = m.apply_gradients(lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         losses["loss"] = float(sum(losses.values()))
+        # the discrete decisions and gradient norms of the step (tests replay them through oracle/mask_rcnn_ref.py)
+        self.last_trace = {"rpn_labels": labels, "rpn_targets": tgts, "proposals": props, "rois": rois, "roi_labels": rlab,
+                           "roi_targets": rtgt, "roi_gt": rgt, "roi_levels": lv, "grad_norms": norms}
         return losses
+
+    @staticmethod
+    def _upload(dev, arr):
+        """Host array -> the leading bytes of a (larger) device buffer."""
+        arr = np.ascontiguousarray(arr, dtype=dev.dtype)
+        if arr.nbytes > dev.nbytes:
+            raise ValueError("device buffer too small")
+        if arr.nbytes:
+            check(lib.rfi_memcpy(dev.ctx.handle, C.c_void_p(dev.ptr), DEVICE, arr.ctypes.data_as(C.c_void_p), HOST, arr.nbytes))

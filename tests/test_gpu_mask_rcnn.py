@@ -1,7 +1,9 @@
 """The detector assembly (``MaskRCNN``: SURVEY.md 8a row A11, BASELINE.json configs[3]) end to end on the GPU: a
-builder-defined pipeline (no reference counterpart), so the checks are structural -- every stage is parity-tested on its
-own (test_gpu_backbone / test_gpu_mask_head / test_gpu_detection_ops) -- plus the property that optimisation steps on a
-fixed batch drive the summed loss down."""
+builder-defined pipeline (no reference counterpart).  Every stage is parity-tested on its own (test_gpu_backbone /
+test_gpu_mask_head / test_gpu_detection_ops); here the ASSEMBLED training step is checked against the assembled oracle
+(oracle/mask_rcnn_ref.py) -- five losses, the gradient norms of the four parameter sets, and every discrete decision
+(sampled anchors, proposals, sampled RoIs, mask targets) -- at reduced and at full width (ResNet-50, 256 pyramid channels,
+1024-wide box head), plus the property that optimisation steps on a fixed batch drive the summed loss down."""
 import numpy as np
 import pytest
 
@@ -69,3 +71,98 @@ def test_paste_identity():
     prob[:, 14:] = 1.0
     m = _paste(prob, [10, 20, 38, 48], 64, 64)
     assert m[20:48, 24:38].all() and not m[20:48, 10:24].any() and m.sum() == 28 * 14
+
+
+def _states(det):
+    return {"backbone": det.backbone.state_dict(), "rpn": det.rpn.state_dict(), "box": det.box.state_dict(), "mask": det.mask.state_dict()}
+
+
+@pytest.mark.parametrize("widths", [(16, 64, 128), (64, 256, 1024)], ids=["reduced", "resnet50_fpn256"])
+def test_assembled_step_against_the_oracle(widths):
+    import torch
+    from oracle.mask_rcnn_ref import MaskRCNNRef
+    from rfi_toolbox_amd.models import MaskRCNN
+    torch.manual_seed(3)
+    det = MaskRCNN(2, 3, *widths, seed=7)
+    ref = MaskRCNNRef(2, 3, *widths).load(_states(det))
+    x, targets = _batch(np.random.default_rng(1))
+    got = det.train_step(x, targets, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)        # (lr 0: the weights stay what the oracle holds)
+    tr = det.last_trace
+    # continuous quantities, on the decisions the device step took
+    want, wtr = ref.step(x, targets, decisions=tr)
+    for k in want:
+        assert abs(got[k] - want[k]) <= 5e-4 * max(1.0, abs(want[k])), (k, got[k], want[k])
+    for k, v in wtr["grad_norms"].items():
+        assert abs(tr["grad_norms"][k] - v) <= 3e-3 * v, (k, tr["grad_norms"][k], v)
+    # discrete decisions: a free oracle run from the same seed takes the same ones
+    free, ftr = ref.step(x, targets, rng=np.random.default_rng(7), grads=False)
+    assert np.array_equal(ftr["rpn_labels"], tr["rpn_labels"])
+    np.testing.assert_allclose(ftr["rpn_targets"], tr["rpn_targets"], rtol=1e-5, atol=1e-6)
+    assert [len(p) for p in ftr["proposals"]] == [len(p) for p in tr["proposals"]]
+    for a, b in zip(ftr["proposals"], tr["proposals"]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-3)
+    order = np.argsort(ftr["roi_levels"], kind="stable")                                  # the device step keeps its RoIs level-major
+    np.testing.assert_allclose(ftr["rois"][order], tr["rois"], rtol=0, atol=2e-3)
+    assert np.array_equal(ftr["roi_labels"][order], tr["roi_labels"]) and np.array_equal(ftr["roi_gt"][order], tr["roi_gt"])
+    for k in free:
+        assert abs(got[k] - free[k]) <= 5e-4 * max(1.0, abs(free[k])), (k, got[k], free[k])
+
+
+def test_batched_matcher_and_nms_match_the_per_image_oracle():
+    from oracle import detection_ref
+    from rfi_toolbox_amd.models import detection_ops as ops
+    rng = np.random.default_rng(0)
+    anchors = np.concatenate([rng.uniform(0, 90, (300, 2)), rng.uniform(0, 90, (300, 2))], 1).astype(np.float32)
+    anchors[:, 2:] = anchors[:, :2] + rng.uniform(4, 40, (300, 2)).astype(np.float32)
+    gts = []
+    for g in (3, 0, 1, 5):
+        b = rng.uniform(0, 80, (g, 2)).astype(np.float32)
+        gts.append(np.concatenate([b, b + rng.uniform(8, 40, (g, 2)).astype(np.float32)], 1))
+    lab, mi, tg = ops.anchor_match_batched(anchors, gts)
+    for i, g in enumerate(gts):
+        l0, m0, t0 = detection_ref.anchor_match(anchors, g)
+        assert np.array_equal(lab[i], l0) and np.array_equal(mi[i], m0)
+        np.testing.assert_allclose(tg[i], t0, rtol=1e-5, atol=1e-6)
+    # per-image boxes with counts (the RoI stage), thresholds 0.5 / 0.5 without the low-quality rule
+    per = np.stack([anchors[rng.permutation(300)] for _ in gts])
+    counts = [300, 17, 0, 256]
+    lab, mi, tg = ops.anchor_match_batched(per, gts, 0.5, 0.5, False, anchor_counts=counts)
+    for i, g in enumerate(gts):
+        l0, m0, t0 = detection_ref.anchor_match(per[i, :counts[i]], g, 0.5, 0.5, False)
+        assert np.array_equal(lab[i, :counts[i]], l0) and np.array_equal(mi[i, :counts[i]], m0) and (lab[i, counts[i]:] == -2).all()
+        np.testing.assert_allclose(tg[i, :counts[i]], t0, rtol=1e-5, atol=1e-6)
+    # batched NMS: sets in descending score order
+    K = 200
+    sets = np.zeros((5, K, 4), np.float32)
+    cnt = np.array([200, 1, 0, 77, 130], np.int32)
+    for s in range(5):
+        p = rng.uniform(0, 100, (K, 2)).astype(np.float32)
+        sets[s] = np.concatenate([p, p + rng.uniform(5, 50, (K, 2)).astype(np.float32)], 1)
+    keep = ops.nms_batched(sets, cnt, 0.7)
+    for s in range(5):
+        want = detection_ref.nms(sets[s, :cnt[s]], -np.arange(cnt[s], dtype=np.float32), 0.7) if cnt[s] else np.zeros(0, np.int64)
+        assert np.array_equal(np.flatnonzero(keep[s]), np.sort(want)), s
+
+
+def test_mask_targets_kernel_against_the_roi_align_oracle():
+    import ctypes as C
+    from oracle import detection_ref
+    from rfi_toolbox_amd._lib import check, lib
+    from rfi_toolbox_amd.runtime import Context
+    ctx = Context.get(0)
+    rng = np.random.default_rng(2)
+    masks = (rng.random((3, 40, 48)) > 0.6).astype(np.uint8)
+    masks[1] = 0
+    masks[1, 10:30, 5:25] = 1
+    rois = np.array([[0, 2.5, 3.0, 30.0, 33.0], [1, 5.0, 10.0, 25.0, 30.0], [2, -4.0, -2.0, 20.0, 50.0], [1, 0.0, 0.0, 48.0, 40.0]], np.float32)
+    dm, dr = ctx.to_device(masks), ctx.to_device(rois)
+    out = ctx.empty((len(rois), 28, 28), np.uint8)
+    check(lib.rfi_op_mask_targets(ctx.handle, C.c_void_p(dm.ptr), 3, 40, 48, C.c_void_p(dr.ptr), len(rois), 28, 28, 2, C.c_void_p(out.ptr)))
+    ctx.synchronize()
+    got = out.numpy()
+    for j, r in enumerate(rois):
+        roi = np.concatenate([[0.0], r[1:]]).astype(np.float32)[None]
+        v = detection_ref.roi_align(masks[int(r[0])].astype(np.float32)[None, :, :, None], roi, 1.0, (28, 28), 2, False)[0, :, :, 0]
+        clear = np.abs(v - 0.5) > 1e-4                                   # (a value within rounding of the threshold may fall either way)
+        assert np.array_equal(got[j][clear], (v >= 0.5)[clear].astype(np.uint8)), j
+    assert got[1][:26, :26].all()                                         # the RoI is the rectangle (its far edge interpolates to the outside)
