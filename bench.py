@@ -230,7 +230,8 @@ def roofline_of(launches, fam_serial, profile_steps, dtype, workload, peak_tf):
     # HBM bytes per launch of the dominant family: NOT measured by this run (bench.py cannot sit under the profiler
     # and time itself at once) -- a constant read from the committed rocprofv3 --pmc passes of this same command
     import glob
-    tag = {"unet": "", "cnn3": "_cnn3", "unet1024": "_unet1024", "resnet": "_resnet", "resnet1024": "_resnet1024"}[workload] + \
+    tag = {"unet": "", "cnn3": "_cnn3", "unet1024": "_unet1024", "resnet": "_resnet", "resnet1024": "_resnet1024",
+           "maskrcnn": "_maskrcnn"}[workload] + \
           ("" if dtype == "f32" else "_" + dtype)
     traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic{tag}.json")))
     if traffic_files:
@@ -320,6 +321,136 @@ def measure(model, ctx, D, d_x, d_y, hp, args, dtype, rank, launch_csv=None):
     return {"wall": wall, "ev_ms": ev_ms, "loss": float(loss), "fam": fam, "fam_ov": fam_ov, "launches": launches}
 
 
+def synthetic_instances(batch, size, seed, per_image=3):
+    """Patches with `per_image` bright rectangular "emitters" each, and their instance annotations (boxes, labels, masks)."""
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((batch, size, size, 3)) * 0.1).astype(np.float32)
+    targets = []
+    for i in range(batch):
+        boxes, masks = [], []
+        for _ in range(per_image):
+            w, h = rng.integers(size // 8, size // 2, 2)
+            x1, y1 = rng.integers(0, size - w), rng.integers(0, size - h)
+            m = np.zeros((size, size), np.uint8)
+            m[y1:y1 + h, x1:x1 + w] = 1
+            x[i, y1:y1 + h, x1:x1 + w] += 2.0
+            boxes.append([x1, y1, x1 + w, y1 + h]); masks.append(m)
+        targets.append({"boxes": np.asarray(boxes, np.float32), "labels": np.ones(per_image, np.int64), "masks": np.stack(masks)})
+    return x, targets
+
+
+def cpu_baseline_maskrcnn(size, gpu_batch, seconds_cap=25.0):
+    """The assembled oracle (oracle/mask_rcnn_ref.py: torch-CPU float32, full width) timed on this host: losses + backward
+    of one step (no optimiser update) at batch 2 -- a BOUNDED sample of the GPU line's batch."""
+    import torch
+
+    from oracle.mask_rcnn_ref import MaskRCNNRef
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    ref = MaskRCNNRef(2, 3, 64, 256, 1024)
+    batch = 2
+    x, targets = synthetic_instances(batch, size, 0)
+    rng = np.random.default_rng(0)
+    t_all0, times = time.perf_counter(), []
+    for i in range(1 + 6):
+        t0 = time.perf_counter()
+        ref.step(x, targets, rng=rng)
+        if i >= 1:
+            times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all0 > seconds_cap and len(times) >= 2:
+            break
+    med = float(np.median(times))
+    return {"value": round(batch / med, 3), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/mask_rcnn_ref MaskRCNNRef(2,3,64,256,1024).step (losses + backward of every parameter set, no optimiser "
+                      f"update), batch {batch} (the GPU line is batch {gpu_batch}) x {size}x{size}x3 fp32 with 3 instances per patch, "
+                      f"{len(times)} timed steps after 1 warm-up, median {med * 1e3:.0f} ms/step, torch.set_num_threads({threads})"}
+
+
+def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
+    """BASELINE configs[3]: one training step of the assembled detector per `step` (backbone, RPN on five levels with its
+    losses, proposals, RoI sampling, RoIAlign, box head + Fast R-CNN losses, mask head + mask loss, every backward pass, clip
+    + Adam of the four parameter sets).  Tensors live in HBM; the box bookkeeping between the stages runs on the host and IS
+    inside the timed region."""
+    import torch
+
+    from rfi_toolbox_amd.models import MaskRCNN
+    torch.manual_seed(1234)
+    B, S = args.batch, args.size
+    det = MaskRCNN(2, 3, 64, 256, 1024, device=local_rank, seed=1234 + rank).set_compute_dtype(MODE_BY_DTYPE[args.dtype])
+    det.grad_sync = world
+    x, targets = synthetic_instances(B, S, 1234 + rank)
+    log(f"detector built, batch {B} x {S}x{S}x3 with {len(targets[0]['boxes'])} instances per patch")
+    losses = None
+    for _ in range(args.warmup):
+        losses = det.train_step(x, targets)
+    ctx.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = det.train_step(x, targets)
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    D.barrier()
+    wall = D.max_over_ranks(wall)
+    log(f"[{args.dtype}] timed region done: {wall * 1e3 / args.steps:.1f} ms/step")
+    if not np.isfinite(losses["loss"]):
+        raise SystemExit(f"non-finite loss {losses}")
+    fam, launches, host_ms = {}, [], None
+    if args.profile_steps > 0:
+        import tempfile
+        ctx.set_overlap(False)
+        ctx.profile_reset()
+        ctx.profile(True)
+        for _ in range(args.profile_steps):
+            det.train_step(x, targets)
+        ctx.synchronize()
+        ctx.profile(False)
+        fam = ctx.profile_report()
+        if rank == 0:
+            path = args.launch_csv or os.path.join(tempfile.gettempdir(), f"rfi_bench_launches_{os.getpid()}.csv")
+            ctx.profile_dump(path)
+            launches = read_launch_csv(path)
+            if not args.launch_csv:
+                os.unlink(path)
+        ctx.set_overlap(not os.environ.get("RFI_NO_OVERLAP") == "1")
+    if world > 1:
+        ctx.synchronize()
+        D.barrier()
+        ctx.comm_destroy()
+    if rank != 0:
+        return
+    P = max(args.profile_steps, 1)
+    ms_per_step = wall * 1e3 / args.steps
+    peak = PEAK_BY_DTYPE[args.dtype]
+    roof, _ = roofline_of(launches, fam, P, args.dtype, "maskrcnn", peak)
+    kernel_ms = sum(f["ms"] for f in fam.values()) / P
+    step_flops = sum(f["flops"] for f in fam.values()) / P
+    out = {"metric": "training patches/sec (128x128x3)", "value": round(world * B * args.steps / wall, 2), "unit": "patches/s",
+           "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype.startswith("bf16") else "f32",
+           "data": "synthetic",
+           "config": {"workload": f"MaskRCNN(2 classes; ResNet-50-FPN 64/256, RPN on P2..P6, RoIAlign 7x7 + 14x14, 1024-wide box head, "
+                                  f"4-conv mask head) train step (five losses, every backward pass, clip + Adam of four parameter "
+                                  f"sets), batch {B}/GPU x {S}x{S}x3 NHWC with 3 instances per patch (BASELINE configs[3]; "
+                                  "builder-defined detector, SURVEY 8a A11)",
+                      "arithmetic": ARITHMETIC[args.dtype], "global_batch": B * world, "patch": [S, S, 3], "parallelism": f"dp{world}",
+                      "params": int(sum(m.num_parameters() for m in det.models()))},
+           "roofline": roof,
+           "step": {"algorithmic_gflop_per_patch": round(step_flops / B / 1e9, 3),
+                    "tflops_whole_step": round(step_flops / (ms_per_step * 1e-3) / 1e12, 3),
+                    "kernel_ms_per_step_serial": round(kernel_ms, 3),
+                    "host_bookkeeping_ms_per_step": round(max(ms_per_step - kernel_ms, 0.0), 3),
+                    "note": "the box bookkeeping between the stages (top-k, sampling, level sort; RPN outputs and labels cross "
+                            "PCIe) runs on the host inside the timed region: ms_per_step - kernel_ms_per_step_serial is its share",
+                    "final_losses": {k: round(float(v), 5) for k, v in losses.items()}},
+           "families": per_family(fam, P)}
+    if world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline ...")
+        out["cpu_baseline"] = cpu_baseline_maskrcnn(S, B)
+    print(json.dumps(out))
+
+
 ARITHMETIC = {"f32": "float32 (contractions by 3 x bf16 splitting, float32-level accuracy; --dtype f32mfma selects the "
                      "native float32 MFMA)",
               "f32planes": "float32 (3 x bf16 pieces, pre-split plane tensors, LDS-DMA staging)",
@@ -335,12 +466,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=("unet", "cnn3", "unet1024", "resnet", "resnet1024"), default="unet",
+    ap.add_argument("--workload", choices=("unet", "cnn3", "unet1024", "resnet", "resnet1024", "maskrcnn"), default="unet",
                     help="unet: UNet(3,1,32) batch 64 x 128^2 (headline, BASELINE configs[1]/[4] shape); "
                          "cnn3: the builder-defined 3-layer CNN of configs[1] (SURVEY 8a A9), batch 64 x 128^2; "
                          "unet1024: UNet(3,1,32) on 1 x 1024^2 (configs[2] shape on the reference's U-Net); "
                          "resnet / resnet1024: the builder-defined U-Net with a ResNet-18-style encoder (configs[2], "
-                         "SURVEY 8a A10) at 64 x 128^2 / 1 x 1024^2")
+                         "SURVEY 8a A10) at 64 x 128^2 / 1 x 1024^2; "
+                         "maskrcnn: the builder-defined Mask R-CNN (ResNet-50-FPN, RPN, RoIAlign, box and mask heads; configs[3], "
+                         "SURVEY 8a A11) on 64 x 128^2 patches with synthetic instance annotations")
     ap.add_argument("--batch", type=int, default=None, help="patches per GPU per step")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--features", type=int, default=None)
@@ -375,6 +508,8 @@ def main():
     default_dtype = args.dtype is None
     if default_dtype:
         args.dtype = "bf16" if args.workload in ("unet1024", "resnet1024") else "f32"    # (configs[2] names bf16)
+    if args.workload == "maskrcnn" and args.dtype in ("bf16", "f32planes"):
+        args.dtype = {"bf16": "bf16regs", "f32planes": "f32"}[args.dtype]      # (the detector's models hold float32 tensors)
     if args.workload.startswith("resnet") and args.dtype in ("bf16", "f32planes"):
         # the plane data flow exists for the plain U-Net only: this model's bf16 mode rounds operands in registers
         args.dtype = {"bf16": "bf16regs", "f32planes": "f32"}[args.dtype]
@@ -407,6 +542,9 @@ def main():
     n_ranks_seen = D.count_ranks_rccl(ctx, world)      # a sum of ones over the RCCL communicator itself
     if n_ranks_seen != world:
         raise SystemExit(f"RCCL communicator sees {n_ranks_seen} ranks, expected {world}")
+
+    if args.workload == "maskrcnn":
+        return run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen)
 
     def build_model():
         torch.manual_seed(1234)                   # identical replicas on every rank

@@ -72,6 +72,7 @@ class MaskRCNN:
         self.rng = np.random.default_rng(seed)
         self.pre_nms, self.post_nms, self.rpn_nms, self.rpn_batch, self.roi_batch = 200, 100, 0.7, 256, 128
         self.score_thresh, self.det_nms, self.max_det = 0.05, 0.5, 20
+        self.grad_sync = 0                # data parallel over this many ranks (> 1): all-reduce (mean) of the four gradient sets
 
     def models(self):
         return (self.backbone, self.rpn, self.box, self.mask)
@@ -349,7 +350,10 @@ class MaskRCNN:
         for name, m in zip(("backbone", "rpn", "box", "mask"), self.models()):
             if m is self.mask and not len(fg):
                 continue
-            norms[name] = m.apply_gradients(lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+            if self.grad_sync > 1:
+                m.allreduce_gradients()
+            norms[name] = m.apply_gradients(lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
+                                            grad_scale=1.0 / max(self.grad_sync, 1))
         losses["loss"] = float(sum(losses.values()))
         # the discrete decisions and gradient norms of the step (tests replay them through oracle/mask_rcnn_ref.py)
         self.last_trace = {"rpn_labels": labels, "rpn_targets": tgts, "proposals": props, "rois": rois, "roi_labels": rlab,
