@@ -380,7 +380,8 @@ def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
     det = MaskRCNN(2, 3, 64, 256, 1024, device=local_rank, seed=1234 + rank).set_compute_dtype(MODE_BY_DTYPE[args.dtype])
     det.grad_sync = world
     x, targets = synthetic_instances(B, S, 1234 + rank)
-    log(f"detector built, batch {B} x {S}x{S}x3 with {len(targets[0]['boxes'])} instances per patch")
+    x = ctx.to_device(x)                              # inputs resident in HBM before the timed region (the instance masks go up
+    log(f"detector built, batch {B} x {S}x{S}x3 with {len(targets[0]['boxes'])} instances per patch")     # with the first warm-up step)
     losses = None
     for _ in range(args.warmup):
         losses = det.train_step(x, targets)

@@ -340,6 +340,9 @@ int rfi_threshold_logits(rfi_ctx* ctx, const float* logits_dev, int64_t count, f
 int rfi_op_conv3x3(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
                    const float* w_oihw, const float* bias, int cout,
                    const float* in_scale, const float* in_shift, int in_relu, float* y);
+/* 1x1 stride-1 conv (a GEMM over the pixels): the Bottleneck / pyramid / fully connected layers of the detector (A11). */
+int rfi_op_conv1x1(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin, const float* w_oihw, const float* bias,
+                   int cout, const float* in_scale, const float* in_shift, int in_relu, float* y);
 int rfi_op_conv3x3_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h, int w, int cout,
                          const float* w_oihw, int cin, float* dx);
 int rfi_op_conv3x3_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* dy, int n, int h,

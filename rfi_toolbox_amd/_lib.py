@@ -131,6 +131,7 @@ _PROTOS = {
     "rfi_confusion_counts": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i64, _pi64, _pi64, _pi64]),
     "rfi_threshold_logits": (_i, [_vp, _vp, _i64, _f, _vp]),
     "rfi_op_conv3x3": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "rfi_op_conv1x1": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "rfi_op_conv_s2": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "rfi_op_conv_s2_dgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "rfi_op_conv_s2_wgrad": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -1517,6 +1517,23 @@ int rfi_op_conv3x3(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, 
         launch_conv(ctx, a, impl);
     });
 }
+int rfi_op_conv1x1(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin, const float* w_oihw, const float* bias,
+                   int cout, const float* in_scale, const float* in_shift, int in_relu, float* y) {
+    return guarded([&] {
+        ctx->activate();
+        Scratch s(ctx);
+        ConvArgs a;
+        a.x = View{x, cin};
+        a.N = n; a.H = h; a.W = w; a.Hin = h; a.Win = w; a.Cin = cin; a.Cout = cout;
+        a.w = upload_lib_weight(ctx, s, w_oihw, (size_t)cin * cout, false, cout, cin, 1);
+        a.bias = bias;
+        a.y = MutView{y, cout};
+        a.Hout = h; a.Wout = w;
+        a.R = 1; a.S = 1; a.pad = 0;
+        a.xf = InXform{in_scale, in_shift, in_relu};
+        launch_conv(ctx, a, impl);
+    });
+}
 int rfi_op_conv3x3_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h, int w, int cout,
                          const float* w_oihw, int cin, float* dx) {
     return guarded([&] {

@@ -443,10 +443,13 @@ void rfi_model::refresh_ws_weights(int P) {
         auto conv_f = [&](const ConvBN& c) { return c.R == 3 && c.stride == 1 && c.cin_p % 16 == 0; };
         auto conv_d = [&](const ConvBN& c) { return c.R == 3 && c.stride == 1 && c.cout % 16 == 0; };
         auto up_ok = [&](const UpConv& u) { return P == 3 && u.cin % 16 == 0 && u.cout % 32 == 0; };
+        // gemm_ws also runs the plain 1x1 stride-1 convs (the Bottleneck and pyramid convs of the detection backbone) as GEMMs
+        auto one_ok = [&](const ConvBN& c) { return P == 3 && c.R == 1 && c.stride == 1 && c.cin_p % 32 == 0 && c.cout % 32 == 0; };
         size_t need = 0;
         for (const ConvBN& c : convs) {
             if (conv_f(c)) need += wb_elems(9, c.cout, c.cin_p, 0, P) + 32;
             if (conv_d(c)) need += wb_elems(9, c.cin_p, c.cout, 0, P) + 32;
+            if (one_ok(c)) need += wb_elems(1, c.cout, c.cin_p, 0, P) + wb_elems(1, c.cin_p, c.cout, 0, P) + 64;
         }
         for (const UpConv& u : ups)
             if (up_ok(u)) need += wb_elems(1, 4 * u.cout, u.cin, 0, P) + wb_elems(4, u.cin, u.cout, 0, P) + 64;
@@ -472,6 +475,16 @@ void rfi_model::refresh_ws_weights(int P) {
                 hd.push_back(WBDesc{c.wd, c.ws3d, 9, c.cin_p, c.cout, {c.cout, 0}, P});
                 ws_by_w[c.wd] = c.ws3d;
                 ws_bytes += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
+            }
+            if (one_ok(c)) {
+                const size_t ef = wb_elems(1, c.cout, c.cin_p, 0, P), ed = wb_elems(1, c.cin_p, c.cout, 0, P);
+                hd.push_back(WBDesc{params + c.w_off, ws_pool + o, 1, c.cout, c.cin_p, {c.cin_p, 0}, P});
+                ws_by_w[params + c.w_off] = ws_pool + o;
+                o += ef + 32;
+                hd.push_back(WBDesc{c.wd, ws_pool + o, 1, c.cin_p, c.cout, {c.cout, 0}, P});
+                ws_by_w[c.wd] = ws_pool + o;
+                o += ed + 32;
+                ws_bytes += 2.0 * (ef + ed) + 8.0 * c.cin_p * c.cout;
             }
         }
         // transposed convs (gemm_ws.hip): forward = ONE tap of 4 cout channels ([4][cout][cin] IS [4 cout][cin]); input

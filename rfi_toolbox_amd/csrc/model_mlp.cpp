@@ -153,6 +153,7 @@ void rfi_model::forward_mlp(const float* x_dev, int n) {
         a.Cin = c.cin; a.Cout = c.cout;
         a.w = params + c.w_off;
         a.w3 = use_w3() ? c.w3 : nullptr;
+        ws_set(a);
         a.bias = params + c.b_off;
         a.y = MutView{buf(mkY[i]), c.cout};
         a.Hout = s.H; a.Wout = s.W;
@@ -202,6 +203,7 @@ void rfi_model::backward_mlp(const float* x_dev, int n) {
         a.Cin = c.cout; a.Cout = c.cin;
         a.w = c.wd;
         a.w3 = use_w3() ? c.wd3 : nullptr;
+        ws_set(a);
         a.y = MutView{i == 0 ? buf(mkGx) : buf(mkG[i - 1]), c.cin};
         a.Hout = s.H; a.Wout = s.W;
         a.R = 1; a.S = 1; a.pad = 0;

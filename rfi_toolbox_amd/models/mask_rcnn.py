@@ -43,6 +43,22 @@ def _level_anchors(h, w, stride, size):
     return out.reshape(-1, 4)
 
 
+def _topk_desc_stable(scores, k):
+    """Row-wise indices of the k largest float32 scores in descending order, ties by ascending index -- what
+    ``np.argsort(-scores, kind="stable")[:, :k]`` returns, through a partial selection on exact 64-bit integer keys
+    (order-preserving image of the float32 in the high word, the index in the low word) instead of a full sort."""
+    sc = np.ascontiguousarray(scores, np.float32)
+    n, m = sc.shape
+    bits = ((-sc) + np.float32(0.0)).view(np.uint32)                   # ascending -score = descending score (+ 0: -0.0 and 0.0 tie)
+    key = np.where(bits & 0x80000000, ~bits, bits | 0x80000000).astype(np.uint64)          # monotone map float32 -> uint32
+    key = (key << np.uint64(32)) | np.arange(m, dtype=np.uint64)[None, :]
+    if k >= m:
+        return np.argsort(key, axis=1)
+    part = np.argpartition(key, k - 1, axis=1)[:, :k]
+    rows = np.arange(n)[:, None]
+    return part[rows, np.argsort(key[rows, part], axis=1)]
+
+
 def _paste(prob, box, h, w):
     """28 x 28 mask probabilities -> boolean mask of the (h, w) image inside ``box`` (bilinear, threshold 0.5)."""
     x1, y1, x2, y2 = [float(v) for v in box]
@@ -118,7 +134,7 @@ class MaskRCNN:
         for lvl, (o, a) in enumerate(zip(rpn_out, anchors)):
             oi = np.asarray(o).reshape(n, -1, 20)
             sc, dl = oi[:, :, :4].reshape(n, -1), oi[:, :, 4:].reshape(n, -1, 4)
-            top = np.argsort(-sc, axis=1, kind="stable")[:, :K]                            # (n, k) anchors by descending score
+            top = _topk_desc_stable(sc, K)                                                  # (n, k) anchors by descending score
             k = top.shape[1]
             rows = np.arange(n)[:, None]
             bx = ops.decode_boxes(a[top].reshape(-1, 4), dl[rows, top].reshape(-1, 4), image_size=(h, w)).reshape(n, k, 4)
@@ -214,7 +230,7 @@ class MaskRCNN:
         b.box_lab, b.box_tgt = ctx.empty((R,), np.int32), ctx.empty((R, 4), np.float32)
         b.roi14, b.roi14_grad = ctx.empty((Rm, 14, 14, F), np.float32), ctx.empty((Rm, 14, 14, F), np.float32)
         b.mask_t = ctx.empty((Rm, 28, 28), np.uint8)
-        b.masks, b.masks_n = None, 0
+        b.masks, b.masks_n, b.masks_of = None, 0, None
         self._buf_key, self._buf = key, b
         return b
 
@@ -274,15 +290,21 @@ class MaskRCNN:
             off += cnt
 
     def train_step(self, images, targets, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0):
-        x = np.ascontiguousarray(np.asarray(images, np.float32))
+        from ..runtime import DeviceArray
+        dev_in = isinstance(images, DeviceArray)                 # images already in HBM (float32 NHWC): no copy
+        x = images if dev_in else np.ascontiguousarray(np.asarray(images, np.float32))
         n, h, w, _ = x.shape
         ctx, F, k1 = self.backbone.ctx, self.F, self.num_classes
         P = lambda d: C.c_void_p(d.ptr)  # noqa: E731
         for m in (self.rpn, self.box, self.mask):
             m.train()
         b = self._buffers(n, h, w)
-        b.x.copy_from(x)
-        check(lib.rfi_backbone_forward(self.backbone._h, P(b.x), DEVICE, n, h, w, b.pf, DEVICE))
+        if dev_in:
+            b.x_in = x
+        else:
+            b.x.copy_from(x)
+            b.x_in = b.x
+        check(lib.rfi_backbone_forward(self.backbone._h, P(b.x_in), DEVICE, n, h, w, b.pf, DEVICE))
         anchors = self._anchors(h, w)
         all_anchors = np.concatenate(anchors)
         labels, tgts = self._rpn_targets(all_anchors, targets)
@@ -331,9 +353,10 @@ class MaskRCNN:
             gcount = [len(t["boxes"]) for t in targets]
             gbase = np.concatenate([[0], np.cumsum(gcount)])
             if b.masks is None or b.masks_n < gbase[-1]:
-                b.masks, b.masks_n = ctx.empty((int(gbase[-1]), h, w), np.uint8), int(gbase[-1])
-            allm = np.concatenate([np.asarray(t["masks"], np.uint8).reshape(-1, h, w) for t in targets])
-            self._upload(b.masks, allm)
+                b.masks, b.masks_n, b.masks_of = ctx.empty((int(gbase[-1]), h, w), np.uint8), int(gbase[-1]), None
+            if b.masks_of is not targets:                        # (the same annotation list as last step: its masks are resident)
+                self._upload(b.masks, np.concatenate([np.asarray(t["masks"], np.uint8).reshape(-1, h, w) for t in targets]))
+                b.masks_of = targets
             rm = rois[fg]
             rg = np.concatenate([(gbase[rm[:, 0].astype(int)] + rgt[fg])[:, None].astype(np.float32), rm[:, 1:]], 1)
             self._upload(b.rois_m, rm); self._upload(b.rois_g, rg)
@@ -345,7 +368,7 @@ class MaskRCNN:
             check(lib.rfi_model_input_grad(self.mask._h, P(b.roi14_grad), DEVICE))
             self._roi_align_dev(b, b.rois_m, lv[fg], None, 14, backward=True, grad_dev=b.roi14_grad)
             losses["loss_mask"] = lm.value
-        check(lib.rfi_backbone_backward(self.backbone._h, P(b.x), DEVICE, n, h, w, b.pdf, DEVICE))
+        check(lib.rfi_backbone_backward(self.backbone._h, P(b.x_in), DEVICE, n, h, w, b.pdf, DEVICE))
         norms = {}
         for name, m in zip(("backbone", "rpn", "box", "mask"), self.models()):
             if m is self.mask and not len(fg):
