@@ -789,6 +789,11 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
     }
     static const bool no_ws = getenv("RFI_NO_WS") != nullptr;                    // A/B runs: round 2's kernels
     static const bool no_gw = getenv("RFI_NO_GW") != nullptr;
+    static const bool no_stem = getenv("RFI_NO_STEM") != nullptr;
+    if (impl == IMPL_AUTO && a.bf16x3 && !no_stem && !no_ws && conv_stem_eligible(a)) {
+        launch_conv_stem(ctx, a);
+        return;
+    }
     if (impl == IMPL_AUTO && a.bf16x3 && a.wB3 && !no_ws && conv_ws_eligible(a)) {
         launch_conv_ws(ctx, a, a.wB3, 3);
         return;

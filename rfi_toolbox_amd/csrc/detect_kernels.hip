@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restr
         float* db = dx + (int64_t)g.n * H * W * C + c;
         if (g.gh <= 2 && g.gw <= 2) {
             // the usual 2 x 2 samples of a bin: where the bin is about a pixel wide or less they share corner pixels, so their
-            // contributions are summed in a 3 x 3 register window first -- 4 to 9 atomics per bin instead of 16 (the kernel
-            // is bound by the L2's atomic rate: ~270 G float adds / s measured in the Mask R-CNN step)
-            Bilin bs[4];                                 // (static indices only: everything stays in registers)
+            // contributions are summed per pixel of a 3 x 3 window first (static indices only: everything stays in
+            // registers) -- 4 to 9 atomics per bin instead of 16
+            Bilin bs[4];
             int ymin = H, xmin = W, ymax = -1, xmax = -1;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -163,32 +163,6 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restr
                         }
                         if (v != 0.0f && py <= ymax && px <= xmax) atomicAdd(db + ((int64_t)py * W + px) * C, gv * v);
                     }
-                continue;
-            }
-        }
-        for (int iy = 0; iy < g.gh; ++iy) {
-                const float yy = g.y1 + ph * g.bh + (iy + 0.5f) * g.bh / g.gh;
-                for (int ix = 0; ix < g.gw; ++ix) {
-                    const float xx = g.x1 + pw * g.bw + (ix + 0.5f) * g.bw / g.gw;
-                    const Bilin b = bilin(yy, xx, H, W);
-                    if (!b.ok) continue;
-                    bs[ns++] = b;
-                    ymin = min(ymin, b.y0); ymax = max(ymax, b.y1);
-                    xmin = min(xmin, b.x0); xmax = max(xmax, b.x1);
-                }
-            }
-            if (ns > 0 && ymax - ymin <= 2 && xmax - xmin <= 2) {
-                float win[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-                for (int k = 0; k < ns; ++k) {
-                    const Bilin& b = bs[k];
-                    win[b.y0 - ymin][b.x0 - xmin] += gv * b.w00;
-                    win[b.y0 - ymin][b.x1 - xmin] += gv * b.w01;
-                    win[b.y1 - ymin][b.x0 - xmin] += gv * b.w10;
-                    win[b.y1 - ymin][b.x1 - xmin] += gv * b.w11;
-                }
-                for (int yy = 0; yy <= ymax - ymin; ++yy)
-                    for (int xx = 0; xx <= xmax - xmin; ++xx)
-                        if (win[yy][xx] != 0.0f) atomicAdd(db + ((int64_t)(ymin + yy) * W + xmin + xx) * C, win[yy][xx]);
                 continue;
             }
         }

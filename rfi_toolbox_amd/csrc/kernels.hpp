@@ -100,6 +100,9 @@ size_t weights_x3_floats(int taps, int Cout, int Cin);
 void launch_weights_to_x3(rfi_ctx* ctx, const float* w, int taps, int Cout, int Cin, float* out);
 struct X3Desc { const float* src; float* dst; int64_t rows; int Cin; int nchunks; };
 void launch_weights_to_x3_batched(rfi_ctx* ctx, const X3Desc* descs_dev, int n, double total_bytes);
+// conv_stem.hip: the first 3x3 conv of a network (Cin = 4 padded, Cout 32 / 64) with K = (tap, channel) packed into three k-steps
+bool conv_stem_eligible(const ConvArgs& a);
+void launch_conv_stem(rfi_ctx* ctx, ConvArgs& a);
 void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl = IMPL_AUTO);
 
 // ---------------------------------------------------------------- weight gradient
