@@ -18,12 +18,13 @@ for f in sorted(glob.glob(os.path.join(src, "bench*.json"))):
 for d, name in (("stats_serial", "kernel_stats"), ("stats_overlap", "kernel_stats_overlap"),
                 ("stats_serial_bf16", "kernel_stats_bf16"), ("stats_overlap_bf16", "kernel_stats_overlap_bf16"),
                 ("stats_serial_cnn3", "kernel_stats_cnn3"), ("stats_serial_unet1024", "kernel_stats_unet1024"),
-                ("stats_serial_resnet1024", "kernel_stats_resnet1024")):
+                ("stats_serial_resnet1024", "kernel_stats_resnet1024"), ("stats_serial_maskrcnn", "kernel_stats_maskrcnn")):
     hits = glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, f"{tag}_{name}.csv"))
 here = os.path.join(ROOT, "tools")
-for dt, suffix in (("f32", ""), ("bf16", "_bf16"), ("cnn3", "_cnn3"), ("unet1024", "_unet1024_bf16"), ("resnet1024", "_resnet1024_bf16regs")):
+for dt, suffix in (("f32", ""), ("bf16", "_bf16"), ("cnn3", "_cnn3"), ("unet1024", "_unet1024_bf16"), ("resnet1024", "_resnet1024_bf16regs"),
+                   ("maskrcnn", "_maskrcnn")):
     fd, wd, md = (os.path.join(src, f"pmc_{k}_{dt}") for k in ("fetch", "write", "mfma"))
     if os.path.isdir(fd) and os.path.isdir(wd):
         subprocess.check_call([sys.executable, os.path.join(here, "summarize_pmc.py"), fd, wd,

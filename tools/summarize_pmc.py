@@ -13,7 +13,7 @@ import json
 import re
 import sys
 
-FAMILY = [(r"conv_igemm_kernel|pconv_kernel|conv_ws_kernel|gemm_ws_kernel", "conv_igemm_mfma"),
+FAMILY = [(r"conv_igemm_kernel|pconv_kernel|conv_ws_kernel|gemm_ws_kernel|conv_stem_kernel", "conv_igemm_mfma"),
           (r"wgrad_igemm_kernel|pwgrad_kernel|wgrad_split_kernel|wgrad_ws_kernel", "wgrad_igemm_mfma"),
           (r"bn_|finish_channel_sum", "batchnorm"), (r"reduce_slabs", "slab_reduce"),
           (r"adam|sumsq", "optimizer")]

@@ -16,7 +16,7 @@ n = len(ev)
 ev = ev[n // 3: 2 * n // 3]
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 steps = nsteps / 3.0
-MF = ("conv_ws", "gemm_ws", "conv_igemm", "wgrad_", "pconv", "pwgrad", "conv_direct")
+MF = ("conv_ws", "conv_stem", "gemm_ws", "conv_igemm", "wgrad_", "pconv", "pwgrad", "conv_direct")
 pts = []
 for s, e, name, q in ev:
     mf = any(k in name for k in MF)

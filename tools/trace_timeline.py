@@ -14,7 +14,7 @@ ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"
 marks = [i for i, e in enumerate(ev) if marker in e[2]]
 mid = len(marks) // 2
 step = ev[marks[mid - 1] + 1: marks[mid] + 1]
-MF = ("conv_ws", "gemm_ws", "conv_igemm", "wgrad_", "pconv", "pwgrad", "conv_direct")
+MF = ("conv_ws", "conv_stem", "gemm_ws", "conv_igemm", "wgrad_", "pconv", "pwgrad", "conv_direct")
 t0 = step[0][0]
 queues = sorted({e[3] for e in step})
 last_end = {}
