@@ -130,6 +130,8 @@ struct WgradArgs {
 size_t wgrad_slab_floats(const WgradArgs& a, int impl);
 bool wgrad_ws_eligible(const WgradArgs& a);      // wgrad_ws.hip: the wave-specialised kernel (float32 tensors, 3 x bf16 or bf16 operands)
 void launch_wgrad_ws(rfi_ctx* ctx, const WgradArgs& a);
+bool wgrad_stem_eligible(const WgradArgs& a);    // wgrad_stem.hip: the first conv of a network (Cx = 4 padded, Cy 32 / 64)
+void launch_wgrad_stem(rfi_ctx* ctx, const WgradArgs& a);
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);
 
 // The raw output Y of a conv layer as the elementwise kernels read it: float32 [M][C] or, in the bf16 data flow

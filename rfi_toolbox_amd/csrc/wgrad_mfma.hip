@@ -479,6 +479,11 @@ void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
         return;
     }
     static const bool no_ws = getenv("RFI_NO_WGRAD_WS") != nullptr;       // A/B runs: round 2's kernels
+    static const bool no_stem = getenv("RFI_NO_STEM") != nullptr;
+    if (!no_ws && !no_stem && a.bf16x3 && wgrad_stem_eligible(a)) {
+        launch_wgrad_stem(ctx, a);    // Cx = 4: (tap, channel) packed into the GEMM's N (wgrad_stem.hip)
+        return;
+    }
     if (!no_ws && (a.bf16x3 || a.bf16) && wgrad_ws_eligible(a) && wgrad_split_eligible(a)) {
         launch_wgrad_ws(ctx, a);      // (its slab plan -- 256 workgroups -- fits inside wgrad_split's, which sized the workspace)
         return;
