@@ -1117,6 +1117,33 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs,
     }
 }
 
+// the same sums four elements per thread (16-byte loads, the k loop unrolled so that eight loads are in flight): the
+// scalar form reached 1.4-1.7 TB/s of its slab reads (0.52 ms of the float32 U-Net step, round 3).  Element order of every
+// sum unchanged (k ascending): bit-identical results
+__global__ __launch_bounds__(256) void reduce_slabs_vec4_kernel(const float* __restrict__ slabs, int nslabs, int group, int kstride,
+                                                               int64_t n4, float* __restrict__ out, int64_t out_rowstride) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int base = blockIdx.y * group;
+    int cnt = nslabs - base;
+    if (cnt > group) cnt = group;
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(slabs) + (int64_t)base * kstride * n4;
+    f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(out) + (int64_t)blockIdx.y * out_rowstride * n4;
+    const int64_t step = (int64_t)kstride * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= cnt; k += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (int64_t)(k + u) * step + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < cnt; ++k) s += __builtin_nontemporal_load(src + (int64_t)k * step + i);
+        dst[i] = s;
+    }
+}
+
 static int grid_for(int64_t total, int cap = 256 * 16) {
     int64_t b = cdiv(total, kBlock);
     if (b > cap) b = cap;
@@ -1572,9 +1599,14 @@ void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n
     float* s = const_cast<float*>(slabs);
     int count = nslabs;      // live partial slabs, `stride` slabs apart
     int stride = 1;
+    const bool vec = n % 4 == 0 && !((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15);
     while (count > 32) {
         const int groups = (int)cdiv(count, 32);
         ProfScope ps(ctx, FAM_REDUCE, 0, (double)n * 4 * (count + groups));
+        if (vec)
+            hipLaunchKernelGGL(reduce_slabs_vec4_kernel, dim3(grid_for(n / 4, 1024), groups), dim3(kBlock), 0, ctx->stream, s, count, 32,
+                               stride, n / 4, s, (int64_t)32 * stride);
+        else
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n, 1024), groups), dim3(kBlock), 0,
                            ctx->stream, s, count, 32, stride, n, s, (int64_t)32 * stride);
         check_launch("reduce_slabs_fold");
@@ -1584,6 +1616,10 @@ void launch_reduce_slabs(rfi_ctx* ctx, const float* slabs, int nslabs, int64_t n
         stride *= 32;
     }
     ProfScope ps(ctx, FAM_REDUCE, 0, (double)n * 4 * (count + 1));
+    if (vec)
+        hipLaunchKernelGGL(reduce_slabs_vec4_kernel, dim3(grid_for(n / 4, 1024), 1), dim3(kBlock), 0, ctx->stream, s, count, 32, stride,
+                           n / 4, out, (int64_t)0);
+    else
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n, 1024), 1), dim3(kBlock), 0, ctx->stream, s,
                        count, 32, stride, n, out, (int64_t)0);
     check_launch("reduce_slabs");
