@@ -23,7 +23,17 @@ def test_bitwise_reproducible_with_bucketed_exchange():
     assert not probe("bfloat16", 200, emulate=2)
 
 
-def test_bitwise_reproducible_at_the_benched_shape():
-    """UNet(3,1,32) on 64 x 128 x 128: the kernel configurations and the co-residency of bench.py's step."""
+@pytest.mark.parametrize("mode,reps", [("bfloat16", 40), ("float32", 30)])
+def test_bitwise_reproducible_at_the_benched_shape(mode, reps):
+    """UNet(3,1,32) on 64 x 128 x 128: the kernel configurations and the co-residency of bench.py's step (float32: the
+    wave-specialised conv / weight-gradient kernels and the stem kernels next to each other on two streams)."""
     from race_probe import probe
-    assert not probe("bfloat16", 40, features=32, batch=64, size=128)
+    assert not probe(mode, reps, features=32, batch=64, size=128)
+
+
+@pytest.mark.parametrize("model,features,size", [("resnet", 16, 64), ("cnn3", 64, 64)])
+def test_other_models_are_bitwise_reproducible(model, features, size):
+    """The ResNet-18-encoder U-Net and the 3-layer CNN share the side stream, the slab workspace and the event rings with
+    the U-Net code path: the same bit-identical-gradients property."""
+    from race_probe import probe
+    assert not probe("float32", 100, features=features, batch=4, size=size, model=model)

@@ -15,16 +15,16 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
-def probe(mode="bfloat16", reps=300, emulate=0, features=16, batch=4, size=64):
+def probe(mode="bfloat16", reps=300, emulate=0, features=16, batch=4, size=64, model="unet"):
     import torch
-    from rfi_toolbox_amd.models import UNet
+    from rfi_toolbox_amd.models import SimpleCNN, UNet, UNetResNet18
     from rfi_toolbox_amd.runtime import Context
     ctx = Context.get(0)
     g = torch.Generator().manual_seed(41)
     x = torch.randn(batch, size, size, 3, generator=g)
     y = (torch.rand(batch, size, size, generator=g) > 0.7).to(torch.uint8)
     torch.manual_seed(23)
-    m = UNet(3, 1, features).set_compute_dtype(mode)
+    m = {"unet": UNet, "resnet": UNetResNet18, "cnn3": SimpleCNN}[model](3, 1, features).set_compute_dtype(mode)
     names = [n for n in m.state_dict() if "running" not in n and "num_batches" not in n]
     ref, bad = None, {}
     ctx.comm_emulate(emulate)
@@ -32,7 +32,7 @@ def probe(mode="bfloat16", reps=300, emulate=0, features=16, batch=4, size=64):
         for r in range(reps):
             m.forward_backward(x, y)
             cur = {n: np.array(m.grad(n), copy=True) for n in names}
-            for t in ("dconcat.1",):
+            for t in ("dconcat.1",) if model == "unet" else ():
                 cur["#" + t] = m.debug_tensor(t)
             if ref is None:
                 ref = cur
