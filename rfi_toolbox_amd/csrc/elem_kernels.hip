@@ -375,6 +375,22 @@ __global__ void finish_channel_sum_kernel(const double* __restrict__ partial, in
     if (rl == 0 && c < C) out[c] = (float)s;
 }
 
+// the same for a table of sums in ONE launch (blockIdx.y = entry): the conv-bias gradients of every layer of a backward pass,
+// whose per-block partials stay where bn_bwd_apply left them until the end of the pass (nothing reads a bias gradient
+// before the optimiser; 18 five-microsecond launches -- each behind a 5-us bubble -- leave the main stream's chain)
+__global__ void finish_channel_sum_batched_kernel(const FinishSumDesc* __restrict__ descs) {
+    __shared__ double red[kBlock];
+    const FinishSumDesc d = descs[blockIdx.y];
+    const int cl = threadIdx.x & (kFinCh - 1), rl = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
+    if (blockIdx.x * kFinCh >= d.count) return;          // (uniform for the block)
+    double s = 0;
+    if (c < d.count)
+        for (int r = rl; r < d.records; r += kFinLanes) s += d.partial[(int64_t)r * d.stride + c];
+    s = finish_sum(s, red);
+    if (rl == 0 && c < d.count) d.out[c] = (float)s;
+}
+
 template <int V>
 __global__ void channel_sum_kernel(const float* __restrict__ v_, int pstride, int64_t M, int C, int CL,
                                    int64_t rows_per_block, double* __restrict__ partial) {
@@ -1263,6 +1279,14 @@ void launch_bn_bwd_apply_finish(rfi_ctx* ctx, const float* partial_ws, int64_t M
     hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0,
                        ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, dbias);
     check_launch("finish_channel_sum");
+}
+
+int bn_bwd_apply_records(int64_t M, int C) { return geom_rows(M, C).rblocks; }
+void launch_finish_channel_sums_batched(rfi_ctx* ctx, const FinishSumDesc* descs_dev, int n, int max_count) {
+    if (n <= 0) return;
+    ProfScope ps(ctx, FAM_BN);
+    hipLaunchKernelGGL(finish_channel_sum_batched_kernel, dim3((int)cdiv(max_count, kFinCh), n), dim3(kBlock), 0, ctx->stream, descs_dev);
+    check_launch("finish_channel_sum_batched");
 }
 
 size_t channel_sum_ws_floats(int64_t M, int C) {

@@ -183,6 +183,10 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
 // finish_dbias = false: the per-block sums of dy stay in partial_ws (channel_sum_ws_floats(M, C) floats) and
 // launch_bn_bwd_apply_finish turns them into dbias later, e.g. on another stream (nothing consumes dbias before the optimiser)
 void launch_bn_bwd_apply_finish(rfi_ctx* ctx, const float* partial_ws, int64_t M, int C, float* dbias);
+// ... or for many layers at once: one table entry per sum (partials of `records` blocks, `stride` doubles apart)
+struct FinishSumDesc { const double* partial; int records; int64_t stride; int count; float* out; };
+int bn_bwd_apply_records(int64_t M, int C);      // per-block partials bn_bwd_apply leaves for an [M][C] tensor
+void launch_finish_channel_sums_batched(rfi_ctx* ctx, const FinishSumDesc* descs_dev, int n, int max_count);
 // planes_out != null: dy is written as a plane tensor (planes.hpp; P bf16 pieces per value) instead of in place
 // done != null: the event completes with the kernel that writes dy (hipExtLaunchKernel's stop event: the dispatch's own
 // completion signal) -- another stream can wait for dy without an event-record packet in this stream's queue, which

@@ -49,6 +49,8 @@ rfi_model::~rfi_model() {
     if (wb_pool) ctx->release(wb_pool);
     if (wb_descs) ctx->release(wb_descs);
     if (ws_pool) ctx->release(ws_pool);
+    if (dbias_pool) ctx->release(dbias_pool);
+    if (dbias_descs) ctx->release(dbias_descs);
     if (ws_descs) ctx->release(ws_descs);
     for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool, grad_acc})   // (rs_wpool: arch 2 and 5)
         if (p) ctx->release(p);
@@ -346,6 +348,34 @@ void rfi_model::prepare(int n, int h, int w) {
         slab_need = std::max(slab_need, wgrad_slab_floats(a, IMPL_AUTO));
     }
     bufs[ws_slab].ensure(ctx, slab_need + 16);
+    // per-layer regions for the partial sums of the conv-bias gradients + the table of the batched finisher
+    if (arch == 0 && !planesP) {
+        if (dbias_pool) { ctx->release(dbias_pool); dbias_pool = nullptr; }
+        if (dbias_descs) { ctx->release(dbias_descs); dbias_descs = nullptr; }
+        size_t need = 0;
+        std::vector<FinishSumDesc> hd;
+        for (size_t ci = 0; ci < convs.size(); ++ci) {
+            int H, W;
+            conv_geom((int)ci, H, W);
+            const int64_t M = (int64_t)n * H * W;
+            convs[ci].dbias_rec_off = need;
+            need += align4(channel_sum_ws_floats(M, convs[ci].cout)) + 4;
+        }
+        dbias_pool = static_cast<float*>(ctx->alloc(need * sizeof(float)));
+        dbias_max_c = 0;
+        for (size_t ci = 0; ci < convs.size(); ++ci) {
+            int H, W;
+            conv_geom((int)ci, H, W);
+            const ConvBN& c = convs[ci];
+            hd.push_back(FinishSumDesc{reinterpret_cast<const double*>(dbias_pool + c.dbias_rec_off), bn_bwd_apply_records((int64_t)n * H * W, c.cout),
+                                       (int64_t)c.cout, c.cout, grads + c.b_off});
+            dbias_max_c = std::max(dbias_max_c, c.cout);
+        }
+        dbias_n = (int)hd.size();
+        dbias_descs = ctx->alloc(hd.size() * sizeof(FinishSumDesc));
+        RFI_CHECK_HIP(hipMemcpyAsync(dbias_descs, hd.data(), hd.size() * sizeof(FinishSumDesc), hipMemcpyHostToDevice, ctx->stream));
+        RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // hd goes out of scope
+    }
     if (arch == 2) prepare_resnet(n, h, w);
     pN = n; pH = h; pW = w;
 }
@@ -768,8 +798,11 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
         launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(),
                              c.c2(), m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
     const hipEvent_t dy_done = m->next_fork_event();         // completes with the kernel that writes dY (over dA)
+    // (dbias_deferred: the partial sums of the conv-bias gradient stay in the layer's own region; backward() finishes every
+    // layer's in one launch at the end of the pass)
     launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
-                        m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope, nullptr, 0, 0, dy_done);
+                        m->params + c.g_off, c.c1(), c.c2(), m->dbias_deferred ? m->dbias_pool + c.dbias_rec_off : ws,
+                        m->grads + c.b_off, m->act_slope, nullptr, 0, 0, dy_done, !m->dbias_deferred);
     WgradArgs wa;
     wa.xop = in;
     wa.yop = View{dA, c.cout};
@@ -857,6 +890,8 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     if (planesP) return backward_planes(x_dev, labels_dev, n, h, w);
     static const int bound_env = getenv("RFI_SIDE_BOUND") ? atoi(getenv("RFI_SIDE_BOUND")) : 0;
     side_bound = arch == 0 ? bound_env : 2;       // (the ResNet-style encoder double-buffers by block parity: bound 2)
+    static const bool no_defer = getenv("RFI_NO_DEFER_DBIAS") != nullptr;
+    dbias_deferred = arch == 0 && dbias_pool && !no_defer && !ctx->exchange_active();
     // loss -> dlogits -> head
     if (loss_kind == 1)
         launch_focal_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, focal_alpha, focal_gamma, buf(dlogits));
@@ -978,6 +1013,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
                          (l == 1) ? nullptr : buf(dpool[l - 1]), rec, nullptr, nullptr);
         bucket_ready(c1.w_off, convs[l == D ? IB : 2 * l].w_off);       // convs[2 l] = first conv of the next level / the bottleneck
     }
+    if (dbias_deferred) launch_finish_channel_sums_batched(ctx, static_cast<const FinishSumDesc*>(dbias_descs), dbias_n, dbias_max_c);
     side_join();
     side_bound = 2;
 }

@@ -29,6 +29,7 @@ struct ConvBN {
     int cin = 0, cout = 0;
     int cin_p = 0;                      // cin rounded up to a multiple of 4 (library layout; zero padded)
     size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;   // offsets into the flat param/grad buffers
+    size_t dbias_rec_off = 0;           // this layer's region of rfi_model::dbias_pool (floats)
     int ema_repeats = 1;
     int level = 1;                      // resolution level of the OUTPUT: H >> (level - 1)
     int R = 3, stride = 1;              // ResNet-style encoder: 3x3 stride 1 / 2, or the 1x1 stride-2 projection (R = 1)
@@ -133,6 +134,13 @@ struct rfi_model {
         a.wB1 = ws_P == 1 ? p : nullptr;
     }
     void refresh_ws_weights(int P);
+    // conv-bias gradients of the float32 U-Net path: bn_bwd_apply leaves its per-block partial sums in a per-layer region of
+    // dbias_pool; ONE batched launch at the end of the backward pass finishes them all (single-GPU steps: with a gradient
+    // exchange the buckets need every gradient of a layer when the layer is done)
+    float* dbias_pool = nullptr;
+    void* dbias_descs = nullptr;
+    int dbias_n = 0, dbias_max_c = 0;
+    bool dbias_deferred = false;
     void* x3_descs = nullptr;         // device table of the batched rebuild
     int x3_n = 0;
     int x3_for_ws_P = -1;             // the ws_P the record list was built for (layers with ws copies are left out)
