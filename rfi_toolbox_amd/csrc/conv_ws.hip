@@ -23,6 +23,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "ws_common.hpp"
 
 namespace rfi {
@@ -580,7 +582,13 @@ void launch_ws(rfi_ctx* ctx, ConvArgs& a, WsDev& d) {
         return;
     }
 #endif
-    hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB, P>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
+    if (a.done) {
+        hipExtLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB, P>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, nullptr,
+                              a.done, 0, d);
+        a.done_used = true;
+    } else {
+        hipLaunchKernelGGL((conv_ws_kernel<TB, TH, TW, NTL, XF, ADB, P>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
+    }
     check_launch("conv_ws");
 }
 

@@ -70,6 +70,11 @@ struct ConvArgs {
     double* stats = nullptr;
     int stats_max_records = 0;
     int stats_records = 0;
+    // optional: an event that completes WITH this kernel (hipExtLaunchKernel's stop event: the dispatch's own completion
+    // signal, no event-record packet behind it -- that packet costs the stream's next kernel ~6.5 us).  done_used: the
+    // launcher honoured it (else the caller records an event as usual)
+    hipEvent_t done = nullptr;
+    bool done_used = false;
     // with `stats`: the output is dA, the gradient w.r.t. the ACTIVATED output of a Conv+BN layer whose raw output
     // is bwd_y (same shape as the output).  The records then hold the BatchNorm-BACKWARD sums (sum dz, sum dz * xhat;
     // dz = dA * act'(y*scale+shift), xhat = (y - mean) * invstd) instead of (sum y, sum y^2): bn_bwd_reduce's pass

@@ -850,10 +850,11 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
             a.bwd_mean = next->mean(); a.bwd_invstd = next->invstd();
             a.bwd_slope = m->act_slope;
         }
+        if (late) a.done = m->next_fork_event();      // the weight gradient starts when this kernel completes
         launch_conv(ctx, a);
         records = a.stats_records;
         if (late) {
-            SideScope side(m);
+            SideScope side(m, a.done_used ? a.done : nullptr);
             launch_wgrad(ctx, wa);
             side.end();
         }
