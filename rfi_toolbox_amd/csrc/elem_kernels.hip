@@ -308,7 +308,10 @@ __global__ void bn_bwd_apply_kernel(void* __restrict__ da_, int da16, const void
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ c1,
                                     const float* __restrict__ c2, double* __restrict__ partial, float slope,
-                                    unsigned short* __restrict__ planes, int64_t pl_stride, int P) {
+                                    unsigned short* __restrict__ planes, int64_t pl_stride, int P,
+                                    const float* __restrict__ head_dl, const float* __restrict__ head_w) {
+    // head_dl != null: da is NOT read -- it is d[pixel] * w[channel], the gradient a one-channel 1x1 head sends down
+    // (launch_head_bwd with skip_da); da_ is output only
     __shared__ double red[V * kBlock];
     const int RL = kBlock / CL;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
@@ -325,10 +328,19 @@ __global__ void bn_bwd_apply_kernel(void* __restrict__ da_, int da16, const void
         ldv<V>(gamma + c, g); ldv<V>(c1 + c, k1); ldv<V>(c2 + c, k2);
 #pragma unroll
         for (int v = 0; v < V; ++v) g[v] = g[v] * is[v];
+        float hw[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) hw[v] = head_dl ? head_w[c + v] : 0.0f;
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             float yv[V], dv[V], o[V];
             ldy<V>(y, y16, r * yps + c, yv);
-            ldy<V>(da_, da16, r * C + c, dv);
+            if (head_dl) {
+                const float d = head_dl[r];
+#pragma unroll
+                for (int v = 0; v < V; ++v) dv[v] = d * hw[v];
+            } else {
+                ldy<V>(da_, da16, r * C + c, dv);
+            }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
@@ -866,7 +878,10 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const void* __restric
                                                            const float* __restrict__ dl, float* __restrict__ da,
                                                            double* __restrict__ partial, float slope,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           double* __restrict__ bn_records, unsigned short* __restrict__ da16) {
+                                                           double* __restrict__ bn_records, unsigned short* __restrict__ da16,
+                                                           int store_da) {
+    // store_da == 0 (Cout == 1, bn_records != null): da is not written -- bn_bwd_apply's head form recomputes d * w from
+    // the logit gradients (1 float per pixel) instead of reading C floats per pixel back
     // da16 != null (Cout == 1): da is stored as bfloat16 there and the BatchNorm-backward sums are those of the stored values
     // bn_records != null (Cout == 1): also the BatchNorm-backward sums of the layer below (sum dz, sum dz * xhat with
     // dz = da * act'), one fp64 record per row block -- bn_bwd_reduce's pass over da and y disappears
@@ -898,7 +913,7 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const void* __restric
                     g[v] = o == 0 ? d * wv[v] : g[v] + d * wv[v];
                 }
                 if (da16) round_store_bf16x4(da16 + r * C + c, g);
-                else stv<4>(da + r * C + c, g);
+                else if (store_da) stv<4>(da + r * C + c, g);
                 if (bn_records) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
@@ -1256,7 +1271,8 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
                          float* partial_ws, float* dbias, float slope, unsigned short* planes_out,
-                         int64_t planes_pstride, int planes_P, hipEvent_t done, bool finish_dbias) {
+                         int64_t planes_pstride, int planes_P, hipEvent_t done, bool finish_dbias, const float* head_dl,
+                         const float* head_w) {
     ChanGeom g = geom_rows(M, C);
     {
         RFI_REQUIRE(da_inout.stride(C) == C && (!da_inout.bf16 || (planes_out && g.V == 4)),
@@ -1265,7 +1281,7 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
         auto launch = [&](auto kernel) {
             hipExtLaunchKernelGGL(kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, nullptr, done, 0,
                                   const_cast<void*>(da_inout.p), da_inout.bf16, y.p, y.bf16, y.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, mean, invstd, gamma,
-                                  c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P);
+                                  c1, c2, reinterpret_cast<double*>(partial_ws), slope, planes_out, planes_pstride, planes_P, head_dl, head_w);
         };
         if (g.V == 4) launch(bn_bwd_apply_kernel<4>);
         else launch(bn_bwd_apply_kernel<1>);
@@ -1483,7 +1499,10 @@ size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
 int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                     float* partial_ws, float* dw, float* db, float slope, const float* bn_mean, const float* bn_invstd,
-                    float* bn_records_ws, unsigned short* da16) {
+                    float* bn_records_ws, unsigned short* da16, bool* skip_da) {
+    // skip_da (in: the caller can do without da; out: it was not written -- only together with the BatchNorm-backward sums)
+    const bool may_skip = skip_da && *skip_da;
+    if (skip_da) *skip_da = false;
     int bn_records = 0;
     const bool vec = C % 4 == 0 && !((reinterpret_cast<uintptr_t>(yr.p) | reinterpret_cast<uintptr_t>(da) |
                                       reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
@@ -1500,8 +1519,9 @@ int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
             hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, yr.p, yr.bf16,
                                yr.stride(C), M, C, g.CL, g.rows_per_block, scale, shift, w, Cout, dlogits, da,
                                reinterpret_cast<double*>(partial_ws), slope, bn_mean, bn_invstd,
-                               sums ? reinterpret_cast<double*>(bn_records_ws) : nullptr, da16);
+                               sums ? reinterpret_cast<double*>(bn_records_ws) : nullptr, da16, (sums && may_skip && !da16) ? 0 : 1);
             if (sums) bn_records = g.rblocks;
+            if (sums && may_skip && !da16) *skip_da = true;
         }
         else
             hipLaunchKernelGGL(head_bwd_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, y,

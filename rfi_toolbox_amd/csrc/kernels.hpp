@@ -184,7 +184,10 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
                          const float* invstd, const float* gamma, const float* c1, const float* c2,
                          float* partial_ws, float* dbias, float slope = 0.0f,
                          unsigned short* planes_out = nullptr, int64_t planes_pstride = 0, int planes_P = 0,
-                         hipEvent_t done = nullptr, bool finish_dbias = true);
+                         hipEvent_t done = nullptr, bool finish_dbias = true, const float* head_dl = nullptr,
+                         const float* head_w = nullptr);
+// head_dl / head_w: da_inout is output only; the incoming gradient is head_dl[pixel] * head_w[channel] (a one-channel 1x1
+// head whose launch_head_bwd skipped writing da)
 // finish_dbias = false: the per-block sums of dy stay in partial_ws (channel_sum_ws_floats(M, C) floats) and
 // launch_bn_bwd_apply_finish turns them into dbias later, e.g. on another stream (nothing consumes dbias before the optimiser)
 void launch_bn_bwd_apply_finish(rfi_ctx* ctx, const float* partial_ws, int64_t M, int C, float* dbias);
@@ -240,7 +243,10 @@ void launch_focal_bwd(rfi_ctx* ctx, const float* logits, const uint8_t* labels, 
 int launch_head_bwd(rfi_ctx* ctx, YRef y, int64_t M, int C, const float* scale,
                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                     float* partial_ws, float* dw, float* db, float slope = 0.0f, const float* bn_mean = nullptr,
-                    const float* bn_invstd = nullptr, float* bn_records_ws = nullptr, unsigned short* da16 = nullptr);
+                    const float* bn_invstd = nullptr, float* bn_records_ws = nullptr, unsigned short* da16 = nullptr,
+                    bool* skip_da = nullptr);
+// skip_da: in -- the caller can do without da (it will run launch_bn_bwd_apply in its head form); out -- da was not written
+// (only where the BatchNorm-backward sums come out of this pass)
 size_t head_bwd_ws_floats(int64_t M, int C, int Cout);
 // per-channel sum over pixels of a view (convT bias grad)
 void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out);

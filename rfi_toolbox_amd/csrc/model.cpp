@@ -787,7 +787,8 @@ struct SideScope {
 // produced dA folded them into its epilogue).  `next` / `next_Y`: the Conv+BN layer whose activated output dx is
 // the gradient of (null: none); returns the number of records the dgrad left for it (0: none).
 int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in, InXform in_xf,
-                     Shape s, float* dx, int have_records, ConvBN* next, const float* next_Y) {
+                     Shape s, float* dx, int have_records, ConvBN* next, const float* next_Y,
+                     const float* head_dl = nullptr, const float* head_w = nullptr) {
     rfi_ctx* ctx = m->ctx;
     const int64_t M = (int64_t)s.N * s.H * s.W;
     float* ws = m->buf(m->ws_red);
@@ -802,7 +803,7 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
     // layer's in one launch at the end of the pass)
     launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
                         m->params + c.g_off, c.c1(), c.c2(), m->dbias_deferred ? m->dbias_pool + c.dbias_rec_off : ws,
-                        m->grads + c.b_off, m->act_slope, nullptr, 0, 0, dy_done, !m->dbias_deferred);
+                        m->grads + c.b_off, m->act_slope, nullptr, 0, 0, dy_done, !m->dbias_deferred, head_dl, head_w);
     WgradArgs wa;
     wa.xop = in;
     wa.yop = View{dA, c.cout};
@@ -900,13 +901,18 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         launch_loss_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, d_sums, buf(dlogits));
     if (head_sigmoid) launch_sigmoid_bwd(ctx, buf(probs), M1 * out_ch, buf(dlogits));
     int head_records = 0;
+    // a one-channel head sends d[pixel] * w[channel] down: where its BatchNorm-backward sums come out of launch_head_bwd's own
+    // pass the gradient tensor is never written -- bn_bwd_apply recomputes it from the logit gradients (268 MB of HBM traffic
+    // less at batch 64 x 128^2 x 32, in the one stretch of the step where no matrix-core kernel can run)
+    static const bool no_head_fuse = getenv("RFI_NO_HEAD_FUSE") != nullptr;
+    bool head_skip = out_ch == 1 && !no_head_fuse;
     {
         ConvBN& last = convs[IB + 2 + 2 * (D - 1) + 1];
         // (head partials behind the region where the next layer expects its BatchNorm-backward records)
         head_records = launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off,
                                        out_ch, buf(dlogits), buf(gA[1]), buf(ws_red) + bn_bwd_ws_floats(M1, feat),
                                        grads + head_w_off, grads + head_b_off, act_slope, last.mean(), last.invstd(),
-                                       buf(ws_red));
+                                       buf(ws_red), nullptr, &head_skip);
     }
     // decoders, shallow to deep
     int pending_records = head_records;   // BatchNorm-backward records a producing kernel left for the next layer
@@ -918,8 +924,10 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         ConvBN& c2 = convs[IB + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         // conv2: input = act(decY1) ; conv1: input = concat (materialised)
+        const bool from_head = l == 1 && head_skip;
         int rec = backward_conv_bn(this, c2, buf(gA[l]), buf(decY2[l]), View{buf(decY1[l]), c1.cout}, bn_xf(c1), s,
-                                   buf(gB[l]), pending_records, &c1, buf(decY1[l]));
+                                   buf(gB[l]), pending_records, &c1, buf(decY1[l]), from_head ? buf(dlogits) : nullptr,
+                                   from_head ? params + head_w_off : nullptr);
         backward_conv_bn(this, c1, buf(gB[l]), buf(decY1[l]), View{buf(concat[l]), 2 * u.cout}, InXform{}, s,
                          buf(dconcat[l]), rec, nullptr, nullptr);
         pending_records = 0;
