@@ -374,6 +374,10 @@ int rfi_op_roi_align(rfi_ctx* ctx, const float* x, int n, int h, int w, int c, c
 int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, const float* rois,
                               int r, float spatial_scale, int ph, int pw, int sampling_ratio, int aligned,
                               float* dx);
+/* roi_align_backward_sorted: the same gradient by gather -- RoIs sorted by batch index (ascending); every element of dx is
+ * WRITTEN (no prior zeroing, no accumulation), no float atomics: bit-reproducible.  Device pointers. */
+int rfi_op_roi_align_backward_sorted(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, const float* rois_sorted, int r,
+                                     float spatial_scale, int ph, int pw, int sampling_ratio, int aligned, float* dx);
 /* mask_targets: the training targets of the mask branch -- RoIAlign (rules above, scale 1, not aligned) of one-channel
  * uint8 instance masks [g][h][w], thresholded at 0.5: rois[r] = (instance index, x1, y1, x2, y2) -> out uint8 [r][ph][pw].
  * Device pointers. */

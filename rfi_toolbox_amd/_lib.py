@@ -112,6 +112,7 @@ _PROTOS = {
     "rfi_op_mask_targets": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "rfi_op_anchor_match_batched": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _vp, _f, _f, _i, _vp, _vp, _vp]),
     "rfi_op_nms_batched": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "rfi_op_roi_align_backward_sorted": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _i, _i, _i, _i, _vp]),
     "rfi_op_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _i, _i, _i, _i, _vp]),
     "rfi_op_fpn_merge": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rfi_op_box_decode": (_i, [_vp, _vp, _i64, _vp, _i64, _f, _f, _vp]),

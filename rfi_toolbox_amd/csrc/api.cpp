@@ -1748,6 +1748,13 @@ int rfi_op_roi_align_backward(rfi_ctx* ctx, const float* dout, int n, int h, int
         launch_roi_align_bwd(ctx, dout, n, h, w, c, rois, r, spatial_scale, ph, pw, sampling_ratio, aligned != 0, dx);
     });
 }
+int rfi_op_roi_align_backward_sorted(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, const float* rois_sorted, int r,
+                                     float spatial_scale, int ph, int pw, int sampling_ratio, int aligned, float* dx) {
+    return guarded([&] {
+        ctx->activate();
+        launch_roi_align_bwd_sorted(ctx, dout, n, h, w, c, rois_sorted, r, spatial_scale, ph, pw, sampling_ratio, aligned != 0, dx);
+    });
+}
 int rfi_op_mask_targets(rfi_ctx* ctx, const uint8_t* masks, int g, int h, int w, const float* rois, int r, int ph, int pw,
                         int sampling_ratio, uint8_t* out) {
     return guarded([&] {

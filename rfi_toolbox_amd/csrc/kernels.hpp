@@ -323,6 +323,9 @@ void launch_scale_inplace(rfi_ctx* ctx, float* x, int64_t n, float f);
 // RoIAlign over an NHWC feature map; rois = R x (batch index, x1, y1, x2, y2) float32 in image coordinates
 void launch_roi_align_fwd(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, const float* rois, int R, float scale,
                           int PH, int PW, int sampling_ratio, bool aligned, float* out);      // out [R][PH][PW][C]
+// gather form of the RoIAlign gradient: RoIs sorted by image index; writes EVERY element of dx (no accumulation, no atomics)
+void launch_roi_align_bwd_sorted(rfi_ctx* ctx, const float* dout, int N, int H, int W, int C, const float* rois, int R, float scale,
+                                 int PH, int PW, int sr, bool aligned, float* dx);
 void launch_mask_targets(rfi_ctx* ctx, const unsigned char* masks, int G, int H, int W, const float* rois, int R, int PH, int PW,
                          int sr, unsigned char* out);
 void launch_anchor_match_batched(rfi_ctx* ctx, const float* anchors, int64_t n, int64_t anchor_stride, const int* anchor_count,

@@ -280,9 +280,9 @@ class MaskRCNN:
                 n, hk, wk, _ = b.shapes[k]
                 rp = C.c_void_p(rois_dev.ptr + off * 20)
                 fp = C.c_void_p((grad_dev if backward else out_dev).ptr + off * res * res * F * 4)
-                if backward:
-                    check(lib.rfi_op_roi_align_backward(ctx.handle, fp, n, hk, wk, F, rp, cnt, 1.0 / _STRIDES[k], res, res, 2, 0,
-                                                        C.c_void_p(b.tmp[k].ptr)))
+                if backward:          # (gather form: the level's RoIs are in image order -- the level sort is stable; no atomics)
+                    check(lib.rfi_op_roi_align_backward_sorted(ctx.handle, fp, n, hk, wk, F, rp, cnt, 1.0 / _STRIDES[k], res, res, 2, 0,
+                                                               C.c_void_p(b.tmp[k].ptr)))
                     check(lib.rfi_op_add_inplace(ctx.handle, C.c_void_p(b.dfe[k].ptr), C.c_void_p(b.tmp[k].ptr), n * hk * wk * F))
                 else:
                     check(lib.rfi_op_roi_align(ctx.handle, C.c_void_p(b.feats[k].ptr), n, hk, wk, F, rp, cnt, 1.0 / _STRIDES[k],

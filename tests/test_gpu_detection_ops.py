@@ -139,3 +139,33 @@ def test_anchor_match_and_encode(n, g):
         assert lab[5] == 1 and matched[5] == 0
         for k in range(g):                                   # every ground truth keeps at least one positive anchor
             assert (matched == k).any() or (wm == k).sum() == 0
+
+
+def test_roi_align_backward_gather_form_matches_the_oracle_and_is_reproducible():
+    """rfi_op_roi_align_backward_sorted: RoIs sorted by image, every element of dx written once, no atomics."""
+    import ctypes as C
+    from oracle import detection_ref
+    from rfi_toolbox_amd._lib import check, lib
+    from rfi_toolbox_amd.runtime import Context
+    ctx = Context.get(0)
+    rng = np.random.default_rng(5)
+    for (n, h, w, c, res, scale, R) in ((3, 16, 16, 8, 7, 0.25, 40), (2, 8, 12, 4, 14, 0.125, 25), (2, 32, 32, 16, 7, 0.25, 64), (1, 4, 4, 4, 7, 1.0 / 32, 9)):
+        img = np.sort(rng.integers(0, n, R)).astype(np.float32)
+        size = h / scale
+        x1, y1 = rng.uniform(-0.1 * size, 0.8 * size, R), rng.uniform(-0.1 * size, 0.8 * size, R)
+        bw, bh = rng.uniform(0.02 * size, 0.6 * size, R), rng.uniform(0.02 * size, 0.6 * size, R)
+        rois = np.stack([img, x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+        rois[0, 1:] = [0.0, 0.0, size, size]                                    # the whole map
+        rois[-1, 1:] = [size * 0.9, size * 0.9, size * 1.3, size * 1.2]         # sticks out of the map
+        dout = rng.standard_normal((R, res, res, c)).astype(np.float32)
+        want = detection_ref.roi_align_backward(dout, (n, h, w, c), rois, scale, (res, res), 2, False)
+        dd, dr = ctx.to_device(dout), ctx.to_device(rois)
+        outs = []
+        for _ in range(2):
+            dx = ctx.to_device(np.full((n, h, w, c), 7.0, np.float32))           # (stale contents must be overwritten)
+            check(lib.rfi_op_roi_align_backward_sorted(ctx.handle, C.c_void_p(dd.ptr), n, h, w, c, C.c_void_p(dr.ptr), R, float(scale), res, res,
+                                                       2, 0, C.c_void_p(dx.ptr)))
+            ctx.synchronize()
+            outs.append(dx.numpy())
+        assert np.array_equal(outs[0], outs[1])
+        np.testing.assert_allclose(outs[0], want, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(want).max()))

@@ -166,3 +166,21 @@ def test_mask_targets_kernel_against_the_roi_align_oracle():
         clear = np.abs(v - 0.5) > 1e-4                                   # (a value within rounding of the threshold may fall either way)
         assert np.array_equal(got[j][clear], (v >= 0.5)[clear].astype(np.uint8)), j
     assert got[1][:26, :26].all()                                         # the RoI is the rectangle (its far edge interpolates to the outside)
+
+
+def test_assembled_step_is_bitwise_reproducible():
+    """No float atomics anywhere in the step (the RoIAlign gradient is a gather, every reduction has a fixed order): the
+    same weights, batch and sampler seed give bit-identical losses and gradient norms, with the weight-gradient kernels of
+    four models sharing the side stream, the slab workspace and the event rings."""
+    import torch
+    from rfi_toolbox_amd.models import MaskRCNN
+    torch.manual_seed(3)
+    det = MaskRCNN(2, 3, 16, 64, 128, seed=7)
+    x, targets = _batch(np.random.default_rng(1), n=4)
+    runs = []
+    for _ in range(4):
+        det.rng = np.random.default_rng(11)
+        losses = det.train_step(x, targets, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)
+        runs.append((losses, dict(det.last_trace["grad_norms"]), det.last_trace["rois"].copy()))
+    for losses, norms, rois in runs[1:]:
+        assert losses == runs[0][0] and norms == runs[0][1] and np.array_equal(rois, runs[0][2])
