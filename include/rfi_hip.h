@@ -184,6 +184,11 @@ int rfi_model_set_training(rfi_model* m, int training);
 /* model(x) -> logits (N,out,H,W)  (unet.py:60-77; train_model.py:145).  In training mode
  * BatchNorm uses batch statistics and updates the running buffers exactly as the
  * reference does, including the encoder's double EMA update (unet.py:28). */
+/* Synchronisation of the model entry points that take tensors with a memory-space argument (forward_nhwc / forward_nchw,
+ * backward_dlogits, input_grad, backbone_forward / backward): with a HOST pointer among the arguments the call returns when the
+ * data is in place; when every tensor argument is a DEVICE pointer it returns as soon as the work is enqueued on the
+ * context's stream (the next call that hands data to the host -- rfi_memcpy, a loss scalar, rfi_ctx_synchronize --
+ * waits).  RFI_SYNC_ALWAYS=1 restores a synchronisation at the end of every call. */
 int rfi_model_forward_nhwc(rfi_model* m, const float* x, int x_mem, int n, int h, int w,
                            float* logits, int logits_mem);
 int rfi_model_forward_nchw(rfi_model* m, const float* x, int x_mem, int n, int h, int w,
@@ -414,6 +419,11 @@ int rfi_op_nms_batched(rfi_ctx* ctx, const float* boxes_sorted, const int32_t* c
 int rfi_op_rpn_loss(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
                     const float* targets, int64_t num_sampled, float beta, float* dhead, float* loss_objectness,
                     float* loss_box);
+/* rpn_loss_dev: rpn_loss without the host round trip -- the two loss scalars land in loss2_dev[0..1] (device), nothing
+ * synchronises; workspace: rfi_op_rpn_loss_ws_bytes() bytes of device memory the caller keeps until the stream has passed. */
+int rfi_op_rpn_loss_dev(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
+                        const float* targets, int64_t num_sampled, float beta, float* dhead, void* workspace, float* loss2_dev);
+size_t rfi_op_rpn_loss_ws_bytes(void);
 int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out);
 int rfi_op_fpn_merge_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, float* dtop);
 int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean, float* var_biased);

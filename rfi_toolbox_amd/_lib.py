@@ -118,6 +118,8 @@ _PROTOS = {
     "rfi_op_box_decode": (_i, [_vp, _vp, _i64, _vp, _i64, _f, _f, _vp]),
     "rfi_op_nms": (_i, [_vp, _vp, _i, _f, _vp, _pi]),
     "rfi_op_anchor_match": (_i, [_vp, _vp, _i64, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "rfi_op_rpn_loss_dev": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _f, _vp, _vp, _vp]),
+    "rfi_op_rpn_loss_ws_bytes": (_sz, []),
     "rfi_op_rpn_loss": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _f, _vp, _pf, _pf]),
     "rfi_op_fpn_merge_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rfi_comm_allreduce_sum_f32": (_i, [_vp, _vp, _i64]),

@@ -409,7 +409,7 @@ int rfi_model_input_grad(rfi_model* m, float* dx, int dx_mem) {
         const size_t cnt = (size_t)m->pN * m->pH * m->pW * m->in_ch;
         RFI_CHECK_HIP(hipMemcpyAsync(dx, m->buf(m->mkGx), cnt * sizeof(float),
                                      dx_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
-        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        if (dx_mem != RFI_DEVICE || getenv("RFI_SYNC_ALWAYS")) RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));   // (sync_if_host below)
     });
 }
 int rfi_model_destroy(rfi_model* m) {
@@ -714,6 +714,13 @@ const uint8_t* stage_labels(rfi_model* m, const uint8_t* y, int y_mem, int n, in
     RFI_CHECK_HIP(hipMemcpyAsync(st, y, (size_t)n * h * w * m->out_scale * m->out_scale, hipMemcpyHostToDevice, m->ctx->stream));
     return st;
 }
+// Entry points whose every tensor argument is a DEVICE pointer return when their work is enqueued (the caller's next
+// call that hands data to the host -- rfi_memcpy, a loss scalar -- synchronises the stream); with a host pointer they
+// return when the data is there.  RFI_SYNC_ALWAYS=1: synchronise always (round 2's behaviour).
+void sync_if_host(rfi_model* m, int mem_a, int mem_b = RFI_DEVICE) {
+    static const bool always = getenv("RFI_SYNC_ALWAYS") != nullptr;
+    if (always || mem_a != RFI_DEVICE || mem_b != RFI_DEVICE) RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+}
 void emit_logits(rfi_model* m, float* out, int out_mem, int n, int h, int w, bool nchw) {
     h *= m->out_scale; w *= m->out_scale;         // (the mask head's output map is twice its input map)
     const size_t cnt = (size_t)n * h * w * m->out_ch;
@@ -725,7 +732,7 @@ void emit_logits(rfi_model* m, float* out, int out_mem, int n, int h, int w, boo
     RFI_CHECK_HIP(hipMemcpyAsync(out, src, cnt * sizeof(float),
                                  out_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                                  m->ctx->stream));
-    RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    sync_if_host(m, out_mem);
 }
 float read_scalar(rfi_model* m, const float* dev) {
     RFI_CHECK_HIP(hipMemcpyAsync(m->ctx->pinned, dev, sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
@@ -848,7 +855,7 @@ int rfi_model_backward_dlogits(rfi_model* m, const float* x, int x_mem, const fl
         struct Flag { rfi_model* m; ~Flag() { m->ext_dlogits = false; } } flag{m};
         m->ext_dlogits = true;
         m->backward(xd, nullptr, n, h, w);
-        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        sync_if_host(m, x_mem, dlogits_mem);
     });
 }
 int rfi_backbone_forward(rfi_model* m, const float* x, int x_mem, int n, int h, int w, float* const feats[5], int feats_mem) {
@@ -865,7 +872,7 @@ int rfi_backbone_forward(rfi_model* m, const float* x, int x_mem, int n, int h, 
             RFI_CHECK_HIP(hipMemcpyAsync(feats[i], m->buf(i < 4 ? m->fP[i] : m->fP6), cnt * sizeof(float),
                                          feats_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
         }
-        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        sync_if_host(m, x_mem, feats_mem);
     });
 }
 int rfi_backbone_backward(rfi_model* m, const float* x, int x_mem, int n, int h, int w, const float* const dfeats[5], int dfeats_mem) {
@@ -885,7 +892,7 @@ int rfi_backbone_backward(rfi_model* m, const float* x, int x_mem, int n, int h,
                 RFI_CHECK_HIP(hipMemsetAsync(dst, 0, cnt * sizeof(float), m->ctx->stream));
         }
         m->backward(xd, nullptr, n, h, w);
-        RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        sync_if_host(m, x_mem, dfeats_mem);
     });
 }
 int rfi_model_last_loss(rfi_model* m, float* loss_out, float* grad_norm_out) {
@@ -1857,6 +1864,16 @@ int rfi_op_rpn_loss(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors
         if (loss_box) *loss_box = h2[1];
     });
 }
+int rfi_op_rpn_loss_dev(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
+                        const float* targets, int64_t num_sampled, float beta, float* dhead, void* workspace, float* loss2_dev) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(workspace && loss2_dev, "rpn_loss_dev: workspace (rfi_op_rpn_loss_ws_bytes) and a 2-float device output");
+        launch_rpn_loss(ctx, head, pixels, anchors_per_pixel, reinterpret_cast<const signed char*>(labels), targets, num_sampled, beta,
+                        dhead, static_cast<double*>(workspace), loss2_dev);
+    });
+}
+size_t rfi_op_rpn_loss_ws_bytes(void) { return rpn_loss_ws_doubles() * sizeof(double); }
 int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out) {
     return guarded([&] {
         ctx->activate();

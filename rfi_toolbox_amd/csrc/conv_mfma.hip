@@ -806,10 +806,8 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
         launch_gemm_ws(ctx, a, a.wB3);
         return;
     }
-    // a layer that carries a wave-specialised filter copy keeps no pre-split records up to date (rfi_model::
-    // refresh_dgrad_weights): a shape those kernels declined runs here on a temporary split copy
-    static const bool keep_w3 = getenv("RFI_NO_WS") != nullptr || getenv("RFI_NO_GW") != nullptr;
-    if (a.wB3 && !keep_w3) a.w3 = nullptr;
+    // (a layer of the plain U-Net that carries a wave-specialised filter copy keeps no pre-split records up to date --
+    // rfi_model::ws_set clears ConvArgs::w3 for it -- so a shape those kernels declined runs below on a temporary split copy)
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.Cout > 0, "conv: empty shape");
     RFI_REQUIRE(a.x.pstride >= a.Cin && a.y.pstride >= a.Cout, "conv: pixel stride smaller than channels");
     RFI_REQUIRE(a.zgroups == 1 || (a.zgroups == 4 && a.R == 1), "conv: zgroups only for convT forward");

@@ -430,8 +430,9 @@ void rfi_model::refresh_dgrad_weights() {
             x3_for_ws_P = ws_P;
             x3_bytes = 0;
             std::vector<X3Desc> h;
+            x3_skips_ws_layers = !all_x3 && ws_P == 3 && arch == 0;
             auto add = [&](const float* src, float* dst, int taps, int cout, int cin) {
-                if (!all_x3 && ws_P == 3 && ws_by_w.count(src)) return;
+                if (x3_skips_ws_layers && ws_by_w.count(src)) return;
                 h.push_back(X3Desc{src, dst, (int64_t)taps * cout, cin, (cin + 15) / 16});
                 x3_bytes += (double)taps * cout * cin * 4 + (double)weights_x3_floats(taps, cout, cin) * 4;
             };

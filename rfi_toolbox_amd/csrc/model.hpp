@@ -132,7 +132,13 @@ struct rfi_model {
         const rfi::bf16_t* p = it == ws_by_w.end() || ws_P != ws_need() ? nullptr : it->second;
         a.wB3 = ws_P == 3 ? p : nullptr;
         a.wB1 = ws_P == 1 ? p : nullptr;
+        if (a.wB3 && x3_skips_ws_layers) a.w3 = nullptr;      // (no pre-split records are kept for this layer)
     }
+    // the plain U-Net keeps no pre-split (3 x bf16) filter records for the layers the wave-specialised kernels cover: at its
+    // shapes they never decline.  The other models (detector backbone on 4 x 4 maps, heads) keep every record up to date, so a
+    // declined shape runs the round-2 kernel on valid records instead of a temporary copy (an allocation + a stream
+    // synchronisation per launch)
+    bool x3_skips_ws_layers = false;
     void refresh_ws_weights(int P);
     // conv-bias gradients of the float32 U-Net path: bn_bwd_apply leaves its per-block partial sums in a per-layer region of
     // dbias_pool; ONE batched launch at the end of the backward pass finishes them all (single-GPU steps: with a gradient

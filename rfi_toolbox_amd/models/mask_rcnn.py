@@ -127,27 +127,32 @@ class MaskRCNN:
         """Per image: top ``pre_nms`` boxes per level by objectness, decoded and clipped, per-level NMS, the ``post_nms``
         best overall (+ ``extra`` boxes: the ground truth during training).  One decode launch per level and ONE NMS
         launch for all (image, level) sets."""
-        K = self.pre_nms
-        sets_b = np.zeros((n, len(anchors), K, 4), np.float32)
-        sets_s = np.full((n, len(anchors), K), -np.inf, np.float32)
-        counts = np.zeros((n, len(anchors)), np.int32)
+        K, L = self.pre_nms, len(anchors)
+        sets_b = np.zeros((n, L, K, 4), np.float32)
+        sets_s = np.full((n, L, K), -np.inf, np.float32)
+        counts = np.zeros((n, L), np.int32)
+        rows = np.arange(n)[:, None]
         for lvl, (o, a) in enumerate(zip(rpn_out, anchors)):
             oi = np.asarray(o).reshape(n, -1, 20)
             sc, dl = oi[:, :, :4].reshape(n, -1), oi[:, :, 4:].reshape(n, -1, 4)
             top = _topk_desc_stable(sc, K)                                                  # (n, k) anchors by descending score
             k = top.shape[1]
-            rows = np.arange(n)[:, None]
             bx = ops.decode_boxes(a[top].reshape(-1, 4), dl[rows, top].reshape(-1, 4), image_size=(h, w)).reshape(n, k, 4)
             ss = sc[rows, top]
             ok = ((bx[..., 2] - bx[..., 0]) >= 1e-2) & ((bx[..., 3] - bx[..., 1]) >= 1e-2)
-            for i in range(n):                                                               # drop degenerate boxes, keep the order
-                c = int(ok[i].sum())
-                sets_b[i, lvl, :c], sets_s[i, lvl, :c], counts[i, lvl] = bx[i][ok[i]], ss[i][ok[i]], c
-        keep = ops.nms_batched(sets_b.reshape(-1, K, 4), counts.reshape(-1), self.rpn_nms).reshape(n, len(anchors), K)
+            first = np.argsort(~ok, axis=1, kind="stable")                                  # degenerate boxes to the back, order kept
+            sets_b[:, lvl, :k] = np.take_along_axis(bx, first[..., None], 1)
+            sets_s[:, lvl, :k] = np.take_along_axis(np.where(ok, ss, -np.inf).astype(np.float32), first, 1)
+            counts[:, lvl] = ok.sum(1)
+        keep = ops.nms_batched(sets_b.reshape(-1, K, 4), counts.reshape(-1), self.rpn_nms).reshape(n, L, K)
+        # the post_nms best of an image over its levels: stable descending order of the level-major list of kept boxes
+        flat_s = np.where(keep, sets_s, -np.inf).astype(np.float32).reshape(n, L * K)
+        flat_b = sets_b.reshape(n, L * K, 4)
+        sel = _topk_desc_stable(flat_s, self.post_nms)
+        nsel = np.minimum(keep.sum((1, 2)), self.post_nms)
         props = []
         for i in range(n):
-            b, s_ = sets_b[i][keep[i]], sets_s[i][keep[i]]                                   # level-major, score order inside a level
-            b = b[np.argsort(-s_, kind="stable")[:self.post_nms]]
+            b = flat_b[i, sel[i, :nsel[i]]]
             if extra is not None and len(extra[i]):
                 b = np.concatenate([b, np.asarray(extra[i], np.float32).reshape(-1, 4)])
             props.append(b.astype(np.float32))
@@ -231,31 +236,44 @@ class MaskRCNN:
         b.roi14, b.roi14_grad = ctx.empty((Rm, 14, 14, F), np.float32), ctx.empty((Rm, 14, 14, F), np.float32)
         b.mask_t = ctx.empty((Rm, 28, 28), np.uint8)
         b.masks, b.masks_n, b.masks_of = None, 0, None
+        b.rpn_ws = [ctx.empty((int(lib.rfi_op_rpn_loss_ws_bytes()),), np.uint8) for _ in shapes]
+        b.rpn_loss2 = ctx.empty((len(shapes), 2), np.float32)
         self._buf_key, self._buf = key, b
         return b
 
-    def _rpn_targets(self, all_anchors, targets):
-        """Matcher (IoU 0.7 / 0.3, low-quality matches; one launch for the batch) + the random sampler: rpn_batch anchors
-        per image, at most half positive.  -> labels int8 (n, A) in {1, 0, -1 = not sampled}, regression targets (n, A, 4)."""
+    def _rpn_match(self, all_anchors, targets):
+        """Matcher of the RPN targets (IoU 0.7 / 0.3, low-quality matches; one launch for the batch).
+        -> labels int8 (n, A) in {1, 0, -1}, regression targets (n, A, 4)."""
         labels, _, tgts = ops.anchor_match_batched(all_anchors, [t["boxes"] for t in targets])
-        for i in range(len(targets)):
+        return labels, tgts
+
+    def _rpn_sample(self, labels):
+        """The random sampler on the matcher's labels (in place): rpn_batch anchors per image, at most half positive;
+        the others get -1 = not sampled."""
+        for i in range(len(labels)):
             lab = labels[i]
             pos, neg = np.flatnonzero(lab == 1), np.flatnonzero(lab == 0)
             npos = min(len(pos), self.rpn_batch // 2)
             lab[self.rng.permutation(pos)[npos:]] = -1
             lab[self.rng.permutation(neg)[self.rpn_batch - npos:]] = -1
-        return labels, tgts
+        return labels
 
-    def _sample_rois(self, props, targets):
-        """Proposals (+ ground truth) matched at IoU 0.5 (one launch for the batch); roi_batch per image with at most a
-        quarter foreground.  -> rois (R, 5), class labels (R,), regression targets (R, 4), matched ground-truth index (R,)
-        (-1: background)."""
+    def _rpn_targets(self, all_anchors, targets):
+        labels, tgts = self._rpn_match(all_anchors, targets)
+        return self._rpn_sample(labels), tgts
+
+    def _roi_match(self, props, targets):
+        """Proposals (+ ground truth) against the ground truth at IoU 0.5 (one launch for the batch)."""
         pmax = max(len(p) for p in props)
         pb = np.zeros((len(props), pmax, 4), np.float32)
         for i, p in enumerate(props):
             pb[i, :len(p)] = p
-        labs, midxs, tgs = ops.anchor_match_batched(pb, [t["boxes"] for t in targets], 0.5, 0.5, False,
-                                                    anchor_counts=[len(p) for p in props])
+        return ops.anchor_match_batched(pb, [t["boxes"] for t in targets], 0.5, 0.5, False, anchor_counts=[len(p) for p in props])
+
+    def _roi_sample(self, props, targets, match):
+        """The RoI sampler: roi_batch per image with at most a quarter foreground.  -> rois (R, 5), class labels (R,),
+        regression targets (R, 4), matched ground-truth index (R,) (-1: background)."""
+        labs, midxs, tgs = match
         rois, rlab, rtgt, rgt = [], [], [], []
         for i, p in enumerate(props):
             lab, midx, tg = labs[i, :len(p)], midxs[i, :len(p)], tgs[i, :len(p)]
@@ -268,6 +286,9 @@ class MaskRCNN:
             rois.append(np.concatenate([np.full((len(keep), 1), i, np.float32), p[keep]], 1))
             rlab.append(cls); rtgt.append(tg[keep]); rgt.append(np.where(np.arange(len(keep)) < npos, midx[keep], -1))
         return np.concatenate(rois), np.concatenate(rlab), np.concatenate(rtgt).astype(np.float32), np.concatenate(rgt)
+
+    def _sample_rois(self, props, targets):
+        return self._roi_sample(props, targets, self._roi_match(props, targets))
 
     def _roi_align_dev(self, b, rois_dev, lv, out_dev, res, backward=False, grad_dev=None):
         """Multi-level RoIAlign on device buffers; the RoIs are SORTED by level, so level k is one contiguous slice of the
@@ -304,34 +325,42 @@ class MaskRCNN:
         else:
             b.x.copy_from(x)
             b.x_in = b.x
-        check(lib.rfi_backbone_forward(self.backbone._h, P(b.x_in), DEVICE, n, h, w, b.pf, DEVICE))
+        # The order of the calls below overlaps the host's bookkeeping with the GPU: the matcher first (the GPU is idle
+        # anyway), then the backbone is enqueued and the host runs the anchor sampler under it; the RPN head's loss and
+        # backward passes are enqueued (no host round trip: rfi_op_rpn_loss_dev) BEHIND the proposal / matching launches, so
+        # they run while the host samples and sorts the RoIs.
         anchors = self._anchors(h, w)
         all_anchors = np.concatenate(anchors)
-        labels, tgts = self._rpn_targets(all_anchors, targets)
+        labels, tgts = self._rpn_match(all_anchors, targets)
+        check(lib.rfi_backbone_forward(self.backbone._h, P(b.x_in), DEVICE, n, h, w, b.pf, DEVICE))
+        labels = self._rpn_sample(labels)
         n_sampled = max(int((labels >= 0).sum()), 1)
         losses = {"loss_objectness": 0.0, "loss_rpn_box_reg": 0.0}
         rpn_out, off = [], 0
-        lo, lb = C.c_float(), C.c_float()
-        self.rpn.accumulate_gradients("begin")
         for lvl in range(5):
             cnt = len(anchors[lvl])
             _, hl, wl, _ = b.shapes[lvl]
             b.rpn_lab[lvl].copy_from(labels[:, off:off + cnt].reshape(-1))
             b.rpn_tgt[lvl].copy_from(tgts[:, off:off + cnt].reshape(-1, 4))
             check(lib.rfi_model_forward_nhwc(self.rpn._h, P(b.feats[lvl]), DEVICE, n, hl, wl, P(b.rpn_out[lvl]), DEVICE))
-            check(lib.rfi_op_rpn_loss(ctx.handle, P(b.rpn_out[lvl]), n * hl * wl, 4, P(b.rpn_lab[lvl]), P(b.rpn_tgt[lvl]), n_sampled,
-                                      1.0 / 9, P(b.rpn_dout[lvl]), C.byref(lo), C.byref(lb)))
+            off += cnt
+        rpn_out = [b.rpn_out[lvl].numpy() for lvl in range(5)]
+        # RoI heads' inputs: proposals and their matches (GPU launches + host top-k), THEN the RPN head's own training work
+        props = self._proposals(rpn_out, anchors, n, h, w, extra=[t["boxes"] for t in targets])
+        match = self._roi_match(props, targets)
+        self.rpn.accumulate_gradients("begin")
+        for lvl in (4, 0, 1, 2, 3):                              # (level 4 first: its forward pass was the last one above)
+            _, hl, wl, _ = b.shapes[lvl]
+            check(lib.rfi_op_rpn_loss_dev(ctx.handle, P(b.rpn_out[lvl]), n * hl * wl, 4, P(b.rpn_lab[lvl]), P(b.rpn_tgt[lvl]), n_sampled,
+                                          1.0 / 9, P(b.rpn_dout[lvl]), P(b.rpn_ws[lvl]), C.c_void_p(b.rpn_loss2.ptr + 8 * lvl)))
+            # (forward again: the head keeps the activations of ONE pass, and later passes overwrote this level's)
+            if lvl != 4:
+                check(lib.rfi_model_forward_nhwc(self.rpn._h, P(b.feats[lvl]), DEVICE, n, hl, wl, P(b.rpn_out[lvl]), DEVICE))
             check(lib.rfi_model_backward_dlogits(self.rpn._h, P(b.feats[lvl]), DEVICE, P(b.rpn_dout[lvl]), DEVICE, n, hl, wl))
             self.rpn.accumulate_gradients("add")
             check(lib.rfi_model_input_grad(self.rpn._h, P(b.dfe[lvl]), DEVICE))          # the first term of d loss / d P_l
-            rpn_out.append(b.rpn_out[lvl].numpy())
-            losses["loss_objectness"] += lo.value
-            losses["loss_rpn_box_reg"] += lb.value
-            off += cnt
         self.rpn.accumulate_gradients("end")
-        # RoI heads
-        props = self._proposals(rpn_out, anchors, n, h, w, extra=[t["boxes"] for t in targets])
-        rois, rlab, rtgt, rgt = self._sample_rois(props, targets)
+        rois, rlab, rtgt, rgt = self._roi_sample(props, targets, match)                     # (host; the GPU is in the RPN passes)
         lv = self._levels(rois[:, 1:], max(h, w))
         order = np.argsort(lv, kind="stable")                    # level-major: a level is one slice of every RoI tensor
         rois, rlab, rtgt, rgt, lv = rois[order], rlab[order], rtgt[order], rgt[order], lv[order]
@@ -377,6 +406,8 @@ class MaskRCNN:
                 m.allreduce_gradients()
             norms[name] = m.apply_gradients(lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
                                             grad_scale=1.0 / max(self.grad_sync, 1))
+        l2 = b.rpn_loss2.numpy()
+        losses["loss_objectness"], losses["loss_rpn_box_reg"] = float(l2[:, 0].sum(dtype=np.float32)), float(l2[:, 1].sum(dtype=np.float32))
         losses["loss"] = float(sum(losses.values()))
         # the discrete decisions and gradient norms of the step (tests replay them through oracle/mask_rcnn_ref.py)
         self.last_trace = {"rpn_labels": labels, "rpn_targets": tgts, "proposals": props, "rois": rois, "roi_labels": rlab,
