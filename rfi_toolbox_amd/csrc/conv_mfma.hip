@@ -766,6 +766,11 @@ void launch_conv(rfi_ctx* ctx, ConvArgs& a, int impl) {
         a.wB3 = nullptr;                // (this implementation was asked for by name)
         impl = IMPL_MFMA;
     }
+    if (impl == IMPL_WS_X3 && conv_stem_eligible(a)) {       // kernel-level API / tests: the stem kernel by name
+        a.bf16x3 = true;
+        launch_conv_stem(ctx, a);
+        return;
+    }
     if (impl == IMPL_WS_X3 || impl == IMPL_WS_BF16) {       // kernel-level API / tests: a temporary B-operand-order copy of the filters
         const int P = impl == IMPL_WS_X3 ? 3 : 1;
         const bool gw = !conv_ws_eligible(a) && gemm_ws_eligible(a);

@@ -17,6 +17,8 @@ TOL = 2e-5
 CONV_SHAPES = [
     (2, 16, 16, 3, 8), (1, 8, 8, 4, 4), (2, 32, 32, 32, 32), (2, 64, 64, 32, 64), (1, 16, 16, 64, 128),
     (2, 8, 8, 128, 64), (1, 24, 40, 16, 48), (3, 4, 4, 8, 16), (1, 128, 128, 32, 32), (1, 12, 20, 20, 36),
+    # the stem shapes (Cin = 4 = three channels padded, Cout 32 / 64): conv_stem.hip / wgrad_stem.hip, whole and ragged tiles
+    (2, 16, 32, 4, 32), (1, 13, 37, 4, 32), (3, 8, 16, 4, 64), (1, 40, 24, 4, 64),
 ]
 
 
@@ -25,8 +27,8 @@ IMPL_PX3 = 5      # plane kernels (LDS-DMA staged bf16 pieces), 3 x bf16 arithme
 IMPL_WS = 7       # wave-specialised kernel (producer waves split, consumer waves multiply), 3 x bf16; H, W >= 8, Cin % 16 == 0
 
 
-def _impls(cin, h=0, w=0):
-    ws = [IMPL_WS] if cin % 16 == 0 and h >= 8 and w >= 8 else []
+def _impls(cin, h=0, w=0, cout=0, xform=False):
+    ws = [IMPL_WS] if (cin % 16 == 0 and h >= 8 and w >= 8) or (cin == 4 and cout in (32, 64) and not xform) else []
     return [IMPL_DIRECT, IMPL_MFMA, IMPL_X3, IMPL_PX3] + ws if cin % 4 == 0 else [IMPL_DIRECT, IMPL_PX3]
 
 
@@ -45,7 +47,7 @@ def test_conv3x3_forward(shape, xform):
     c = ctx()
     dx, dw, db = c.to_device(nhwc(x)), c.to_device(wt.numpy()), c.to_device(b.numpy())
     dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
-    for impl in _impls(cin, h, w):
+    for impl in _impls(cin, h, w, cout, xform):
         dy = c.empty((n, h, w, cout))
         check(lib.rfi_op_conv3x3(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout,
                                  P(dsc) if xform else None, P(dsh) if xform else None, 1 if xform else 0, P(dy)))
@@ -388,3 +390,28 @@ def test_stride2_convolutions(shape, ksize):
         gw = c.empty((cout, cin, ksize, ksize))
         check(lib.rfi_op_conv_s2_wgrad(c.handle, impl, ksize, P(dxd), P(ddy), n, h, w, cin, cout, P(gw)))
         assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, f"wgrad impl={impl}"
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 32, 64, 64), (2, 4, 4, 64, 64), (1, 8, 32, 3136, 128), (250, 1, 1, 3136, 128), (1, 8, 32, 256, 1024),
+                                   (1, 8, 32, 2048, 512), (1, 8, 32, 64, 32), (3, 5, 7, 32, 96)])
+@pytest.mark.parametrize("xform", [False, True])
+def test_conv1x1(shape, xform):
+    """1x1 stride-1 conv = a GEMM over the pixels (the Bottleneck / pyramid / fully connected layers of the detector): the
+    round-2 kernel (auto) and the wave-specialised GEMM kernel (IMPL_WS) against torch."""
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    x = torch.randn(n, h, w, cin, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g)
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    xin = torch.relu(x * sc + sh) if xform else x
+    want = (xin.reshape(-1, cin) @ wt.reshape(cout, cin).T + b).reshape(n, h, w, cout).numpy()
+    c = ctx()
+    dx, dw, db = c.to_device(x.numpy()), c.to_device(wt.numpy()), c.to_device(b.numpy())
+    dsc, dsh = c.to_device(sc.numpy()), c.to_device(sh.numpy())
+    for impl in (0, IMPL_WS):
+        dy = c.empty((n, h, w, cout))
+        check(lib.rfi_op_conv1x1(c.handle, impl, P(dx), n, h, w, cin, P(dw), P(db), cout, P(dsc) if xform else None,
+                                 P(dsh) if xform else None, 1 if xform else 0, P(dy)))
+        assert rel_err(dy.numpy(), want) <= TOL, f"impl={impl}"
