@@ -1309,7 +1309,7 @@ size_t channel_sum_ws_floats(int64_t M, int C) {
     (void)M;
     return (size_t)kMaxRowBlocks * C * 2;
 }
-void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out) {
+void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out, bool finish) {
     ChanGeom g = geom_rows(M, C);
     const bool vec = g.V == 4 && v.pstride % 4 == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0;
     if (!vec && g.V == 4) g = geom_rows(M, C, false);   // unaligned view: scalar lanes
@@ -1325,7 +1325,7 @@ void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_w
                            reinterpret_cast<double*>(partial_ws));
         check_launch("channel_sum");
     }
-    {
+    if (finish) {
         ProfScope ps(ctx, FAM_REDUCE);
         hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0,
                            ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, out);

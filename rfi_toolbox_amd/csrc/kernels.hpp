@@ -249,7 +249,9 @@ int launch_head_bwd(rfi_ctx* ctx, YRef y, int64_t M, int C, const float* scale,
 // (only where the BatchNorm-backward sums come out of this pass)
 size_t head_bwd_ws_floats(int64_t M, int C, int Cout);
 // per-channel sum over pixels of a view (convT bias grad)
-void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out);
+void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out, bool finish = true);
+// finish = false (16-byte aligned views with C % 4 == 0 only): the per-block partials stay in partial_ws (bn_bwd_apply_records(M, C)
+// records, C doubles apart) for launch_finish_channel_sums_batched
 size_t channel_sum_ws_floats(int64_t M, int C);
 
 // ---------------------------------------------------------------- layouts

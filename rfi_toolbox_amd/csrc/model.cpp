@@ -361,6 +361,11 @@ void rfi_model::prepare(int n, int h, int w) {
             convs[ci].dbias_rec_off = need;
             need += align4(channel_sum_ws_floats(M, convs[ci].cout)) + 4;
         }
+        for (int k = 0; k < depth; ++k) {               // the transposed convs' bias gradients (decoder level l = D - k)
+            const int l = depth - k;
+            ups[k].dbias_rec_off = need;
+            need += align4(channel_sum_ws_floats((int64_t)n * (h >> (l - 1)) * (w >> (l - 1)), ups[k].cout)) + 4;
+        }
         dbias_pool = static_cast<float*>(ctx->alloc(need * sizeof(float)));
         dbias_max_c = 0;
         for (size_t ci = 0; ci < convs.size(); ++ci) {
@@ -370,6 +375,15 @@ void rfi_model::prepare(int n, int h, int w) {
             hd.push_back(FinishSumDesc{reinterpret_cast<const double*>(dbias_pool + c.dbias_rec_off), bn_bwd_apply_records((int64_t)n * H * W, c.cout),
                                        (int64_t)c.cout, c.cout, grads + c.b_off});
             dbias_max_c = std::max(dbias_max_c, c.cout);
+        }
+        for (int k = 0; k < depth; ++k) {
+            const int l = depth - k;
+            const UpConv& u = ups[k];
+            if (u.cout % 4) continue;                 // (launch_channel_sum keeps its own finish for such a layer)
+            hd.push_back(FinishSumDesc{reinterpret_cast<const double*>(dbias_pool + u.dbias_rec_off),
+                                       bn_bwd_apply_records((int64_t)n * (h >> (l - 1)) * (w >> (l - 1)), u.cout), (int64_t)u.cout, u.cout,
+                                       grads + u.b_off});
+            dbias_max_c = std::max(dbias_max_c, u.cout);
         }
         dbias_n = (int)hd.size();
         dbias_descs = ctx->alloc(hd.size() * sizeof(FinishSumDesc));
@@ -936,7 +950,11 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
         ConvBN& prevBN = (l == D) ? convs[IB + 1] : convs[IB + 2 + 2 * (k - 1) + 1];
         View dUp{buf(dconcat[l]), 2 * u.cout};
-        launch_channel_sum(ctx, dUp, (int64_t)s.N * s.H * s.W, u.cout, buf(ws_red), grads + u.b_off);
+        {
+            const bool defer = dbias_deferred && u.cout % 4 == 0;
+            launch_channel_sum(ctx, dUp, (int64_t)s.N * s.H * s.W, u.cout, defer ? dbias_pool + u.dbias_rec_off : buf(ws_red),
+                               grads + u.b_off, !defer);
+        }
         WgradArgs wa;
         wa.xop = dUp;
         wa.yop = View{prevY, u.cin};

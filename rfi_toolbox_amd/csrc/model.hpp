@@ -62,6 +62,7 @@ struct UpConv {
     std::string name;                   // "decoder4.up"
     int cin = 0, cout = 0;
     size_t w_off = 0, b_off = 0;        // forward layout [4][cout][cin]
+    size_t dbias_rec_off = 0;           // this layer's region of rfi_model::dbias_pool (floats)
     float* wd = nullptr;                // dgrad layout [4][cin][cout]
     float* w3 = nullptr;                // 3 x bf16 records of both layouts
     float* wd3 = nullptr;
