@@ -1499,7 +1499,7 @@ size_t head_bwd_ws_floats(int64_t M, int C, int Cout) {
 int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                     float* partial_ws, float* dw, float* db, float slope, const float* bn_mean, const float* bn_invstd,
-                    float* bn_records_ws, unsigned short* da16, bool* skip_da) {
+                    float* bn_records_ws, unsigned short* da16, bool* skip_da, bool finish) {
     // skip_da (in: the caller can do without da; out: it was not written -- only together with the BatchNorm-backward sums)
     const bool may_skip = skip_da && *skip_da;
     if (skip_da) *skip_da = false;
@@ -1529,7 +1529,7 @@ int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
                                reinterpret_cast<double*>(partial_ws), slope);
         check_launch("head_bwd");
     }
-    {
+    if (finish) {
         // dw (Cout*C values) followed by db (Cout values) are contiguous in each partial record
         const int n = Cout * C + Cout;
         ProfScope ps(ctx, FAM_REDUCE);
@@ -1539,7 +1539,7 @@ int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
                            ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)n, Cout * C, dw);
         check_launch("head_bwd_finish_dw");
     }
-    {
+    if (finish) {
         const int n = Cout * C + Cout;
         ProfScope ps(ctx, FAM_REDUCE);
         hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(Cout, kFinCh)), dim3(kBlock), 0,

@@ -244,7 +244,9 @@ int launch_head_bwd(rfi_ctx* ctx, YRef y, int64_t M, int C, const float* scale,
                     const float* shift, const float* w, int Cout, const float* dlogits, float* da,
                     float* partial_ws, float* dw, float* db, float slope = 0.0f, const float* bn_mean = nullptr,
                     const float* bn_invstd = nullptr, float* bn_records_ws = nullptr, unsigned short* da16 = nullptr,
-                    bool* skip_da = nullptr);
+                    bool* skip_da = nullptr, bool finish = true);
+// finish = false (vector path: C % 4 == 0, aligned): the partial records (bn_bwd_apply_records(M, C) of them, Cout * C + Cout
+// doubles each: dw then db) stay in partial_ws for launch_finish_channel_sums_batched
 // skip_da: in -- the caller can do without da (it will run launch_bn_bwd_apply in its head form); out -- da was not written
 // (only where the BatchNorm-backward sums come out of this pass)
 size_t head_bwd_ws_floats(int64_t M, int C, int Cout);

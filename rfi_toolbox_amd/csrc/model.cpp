@@ -366,6 +366,8 @@ void rfi_model::prepare(int n, int h, int w) {
             ups[k].dbias_rec_off = need;
             need += align4(channel_sum_ws_floats((int64_t)n * (h >> (l - 1)) * (w >> (l - 1)), ups[k].cout)) + 4;
         }
+        head_rec_off = need;
+        need += align4(head_bwd_ws_floats((int64_t)n * h * w, feat, out_ch)) + 4;
         dbias_pool = static_cast<float*>(ctx->alloc(need * sizeof(float)));
         dbias_max_c = 0;
         for (size_t ci = 0; ci < convs.size(); ++ci) {
@@ -384,6 +386,15 @@ void rfi_model::prepare(int n, int h, int w) {
                                        bn_bwd_apply_records((int64_t)n * (h >> (l - 1)) * (w >> (l - 1)), u.cout), (int64_t)u.cout, u.cout,
                                        grads + u.b_off});
             dbias_max_c = std::max(dbias_max_c, u.cout);
+        }
+        head_fin_deferred = feat % 4 == 0;
+        if (head_fin_deferred) {                       // the head's dw (out_ch x feat) and db (out_ch), contiguous in every record
+            const int recs = bn_bwd_apply_records((int64_t)n * h * w, feat);
+            const int64_t stride = (int64_t)out_ch * feat + out_ch;
+            const double* hp = reinterpret_cast<const double*>(dbias_pool + head_rec_off);
+            hd.push_back(FinishSumDesc{hp, recs, stride, out_ch * feat, grads + head_w_off});
+            hd.push_back(FinishSumDesc{hp + (size_t)out_ch * feat, recs, stride, out_ch, grads + head_b_off});
+            dbias_max_c = std::max(dbias_max_c, out_ch * feat);
         }
         dbias_n = (int)hd.size();
         dbias_descs = ctx->alloc(hd.size() * sizeof(FinishSumDesc));
@@ -924,10 +935,12 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     {
         ConvBN& last = convs[IB + 2 + 2 * (D - 1) + 1];
         // (head partials behind the region where the next layer expects its BatchNorm-backward records)
+        const bool hdefer = dbias_deferred && head_fin_deferred;
         head_records = launch_head_bwd(ctx, buf(decY2[1]), M1, feat, last.scale(), last.shift(), params + head_w_off,
-                                       out_ch, buf(dlogits), buf(gA[1]), buf(ws_red) + bn_bwd_ws_floats(M1, feat),
+                                       out_ch, buf(dlogits), buf(gA[1]),
+                                       hdefer ? dbias_pool + head_rec_off : buf(ws_red) + bn_bwd_ws_floats(M1, feat),
                                        grads + head_w_off, grads + head_b_off, act_slope, last.mean(), last.invstd(),
-                                       buf(ws_red), nullptr, &head_skip);
+                                       buf(ws_red), nullptr, &head_skip, !hdefer);
     }
     // decoders, shallow to deep
     int pending_records = head_records;   // BatchNorm-backward records a producing kernel left for the next layer

@@ -148,6 +148,8 @@ struct rfi_model {
     void* dbias_descs = nullptr;
     int dbias_n = 0, dbias_max_c = 0;
     bool dbias_deferred = false;
+    size_t head_rec_off = 0;            // the head's region of dbias_pool (its dw / db partials)
+    bool head_fin_deferred = false;
     void* x3_descs = nullptr;         // device table of the batched rebuild
     int x3_n = 0;
     int x3_for_ws_P = -1;             // the ws_P the record list was built for (layers with ws copies are left out)
