@@ -77,7 +77,8 @@ def test_default_init_matches_module_construction():
 # the MFMA tile shapes (the kernels themselves are pinned by tests/test_gpu_ops.py) and carry the bound of
 # test_gpu_bench_config.py.
 @pytest.mark.parametrize("mode,f,n,s,flip_tol", [("float32", 8, 3, 32, 2e-3), ("float32", 16, 4, 64, 2e-2),
-                                                  ("float32_mfma", 16, 4, 64, 2e-2), ("float32", 64, 2, 128, 2e-2)])
+                                                  ("float32_mfma", 16, 4, 64, 2e-2), ("float32", 64, 2, 128, 2e-2),
+                                                  ("float32", 8, 1, 1024, 2e-2)])      # (the spatial size of BASELINE configs[2])
 def test_training_gradients_vs_oracle(mode, f, n, s, flip_tol):
     st = _perturbed_state(f, 11)
     x, y, xo, yo = _inputs(n, s, 12)
