@@ -74,7 +74,7 @@ def cpu_baseline(workload, features, size, gpu_batch=64, seconds_cap=25.0):
     x = torch.randn(batch, 3, size, size, generator=g)
     y = (torch.rand(batch, 1, size, size, generator=g) > 0.8).float()
 
-    def timed(nthreads, warm, n_timed, cap):
+    def timed(nthreads, warm, n_timed, cap, min_timed=2):
         torch.set_num_threads(nthreads)
         st = mk(3, 1, features, seed=0)
         adam = unet_ref.new_adam_state(st)
@@ -85,7 +85,7 @@ def cpu_baseline(workload, features, size, gpu_batch=64, seconds_cap=25.0):
             dt = time.perf_counter() - t0
             if i >= warm:
                 times.append(dt)
-            if time.perf_counter() - t_all0 > cap and len(times) >= 2:
+            if time.perf_counter() - t_all0 > cap and len(times) >= min_timed:
                 break
         return float(np.median(times)), len(times)
 
@@ -106,10 +106,14 @@ def cpu_baseline(workload, features, size, gpu_batch=64, seconds_cap=25.0):
         batch, x_small, y_small = gpu_batch, x, y
         x = torch.randn(batch, 3, size, size, generator=g)
         y = (torch.rand(batch, 1, size, size, generator=g) > 0.8).float()
-        medb, nb = timed(threads, 1, 3, 12.0)
+        medb, nb = timed(threads, 1, 3, 12.0, min_timed=3)
         out["at_gpu_batch"] = {"value": round(batch / medb, 3), "unit": unit, "cores": threads,
                                "sample": f"same step at batch {batch}, {nb} timed steps after 1 warm-up, median "
-                                         f"{medb * 1e3:.1f} ms/step, torch.set_num_threads({threads})"}
+                                         f"{medb * 1e3:.1f} ms/step, torch.set_num_threads({threads})",
+                               "note": "slower per patch than the batch-4 sample: autograd keeps every activation of the step "
+                                       "(about 40 MB per 128x128 patch for UNet(3,1,32): ~0.15 GB at batch 4, ~2.5 GB at batch 64), "
+                                       "so the batch-64 step streams its working set from DRAM where the batch-4 step largely "
+                                       "stays in the host's last-level cache (an estimate from tensor sizes, not a measurement)"}
     return out
 
 
@@ -120,70 +124,231 @@ def log(msg):
 T0 = time.perf_counter()
 
 
-def self_launch(n):
-    """`python bench.py --gpus N` with no launcher around it: start N fresh child processes (one rank per
-    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this process has touched
-    the GPU or loaded the HIP library, watch ALL of them and relay rank 0's JSON line.  If any rank exits
-    non-zero the others are terminated at once and this process exits non-zero with that rank's stderr tail
-    (a rank that died at init would otherwise leave the rest in the rendezvous / the first all-reduce until
-    the caller's time limit); RFI_BENCH_LAUNCH_TIMEOUT (seconds, default 1500) bounds the whole run."""
-    import socket
-    import subprocess
-    import tempfile
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    limit = float(os.environ.get("RFI_BENCH_LAUNCH_TIMEOUT", "1500"))
-    procs, errs = [], []
-    out0 = tempfile.TemporaryFile()
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        errs.append(tempfile.TemporaryFile())
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[r]))
+# ---------------------------------------------------------------------------------------------- multi-GPU supervision
+# A run with N > 1 ranks must not be able to end in silence.  The process the caller starts -- `python bench.py --gpus N`
+# alone, or one rank of `python -m torch.distributed.run ... bench.py --gpus N` -- is a SUPERVISOR: it never touches the GPU
+# or the HIP library, starts the actual rank(s) as fresh child processes (RFI_BENCH_WORKER=1), reads the heartbeat line each
+# child writes when it passes a phase (imports, control plane, RCCL init + first all-reduce, first training step, warm-up,
+# timed region, done) and bounds every phase.  A child that exits non-zero or overstays a phase ends the attempt: every
+# child is killed and a SECOND attempt starts a fresh set of children with RFI_NO_BUCKETS=1 RFI_NO_STOP_EVENTS=1 (ONE
+# all-reduce after the backward pass on the main stream, event-record packets between the streams); its JSON line carries
+# "fallback": "unbucketed".  A second failure exits non-zero with the phase, the rank and every local rank's stderr tail.
+# Under an external launcher the per-rank supervisors agree on "this attempt failed" / "everybody is done" through a
+# TCPStore (the launcher's own agent store, or one hosted by rank 0's supervisor).
+PHASES = ("spawned", "imports", "control_plane", "rccl_init", "first_step", "warmup", "timed", "done")
+# seconds a child may spend getting from the phase named to the next one (the first `import torch` on a fresh box takes 1-2 min)
+PHASE_BOUND = {"spawned": 200.0, "imports": 60.0, "control_plane": 60.0, "rccl_init": 60.0, "first_step": 45.0, "warmup": 60.0,
+               "timed": 90.0}
 
+
+def beat(phase):
+    """Worker side: one heartbeat line per phase passed (the supervisor's watchdog reads the last one)."""
+    path = os.environ.get("RFI_BENCH_HB")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{phase} {time.time():.3f}\n")
+    if os.environ.get("RFI_BENCH_STALL_PHASE") == phase and os.environ.get("RFI_BENCH_STALL_RANK") == os.environ.get("RANK") \
+            and not os.environ.get("RFI_BENCH_FALLBACK"):
+        time.sleep(3600)          # fault injection (launcher tests): this rank hangs right after `phase`, first attempt only
+
+
+class Supervisor:
+    def __init__(self, n, argv):
+        import tempfile
+        self.n, self.argv = n, argv
+        self.external = "WORLD_SIZE" in os.environ          # one rank of an external launcher: supervise that rank only
+        self.ranks = [int(os.environ["RANK"])] if self.external else list(range(n))
+        self.limit = float(os.environ.get("RFI_BENCH_LAUNCH_TIMEOUT", "240"))
+        pt = os.environ.get("RFI_BENCH_PHASE_TIMEOUT")
+        self.bound = {k: (float(pt) if pt else v) for k, v in PHASE_BOUND.items()}
+        self.tmp = tempfile.mkdtemp(prefix="rfi_bench_")
+        self.store = None
+        self.procs, self.errs, self.out0 = {}, {}, None
+        self.warned = set()
+
+    # ---- coordination between the supervisors of an external launcher's ranks
+    def connect_store(self):
+        if not self.external:
+            return
+        import datetime
+
+        from torch.distributed import TCPStore
+        addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500"))
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"     # torch.distributed.run hosts a store there
+        self.store = TCPStore(addr, port, None if agent else self.n, is_master=(not agent and self.ranks[0] == 0),
+                              timeout=datetime.timedelta(seconds=60), wait_for_workers=False)
+
+    def worker_port(self, attempt):
+        import socket
+        if not self.external:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                return sock.getsockname()[1]
+        key = f"rfi_bench/port/{attempt}"
+        if self.ranks[0] == 0:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            self.store.set(key, str(port))
+            return port
+        return int(self.store.get(key))          # (blocks until rank 0's supervisor has published it; store timeout 60 s)
+
+    def flag(self, key, value=None):
+        """Set (value given) or test a flag every supervisor sees.  A store that has gone away (its host, the supervisor of
+        rank 0 or the launcher's agent, has exited) leaves this supervisor with its local watchdog only."""
+        if self.store is None:
+            return False
+        try:
+            if value is not None:
+                self.store.set(key, value)
+                return True
+            return self.store.check([key])
+        except Exception:
+            self.store = None
+            return False
+
+    def count(self, key, inc):
+        if self.store is None:
+            return None
+        try:
+            return self.store.add(key, inc)
+        except Exception:
+            self.store = None
+            return None
+
+    # ---- children
+    def spawn(self, attempt, port):
+        import subprocess
+        import tempfile
+        self.procs, self.errs = {}, {}
+        self.out0 = tempfile.TemporaryFile()
+        for r in self.ranks:
+            env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}     # the children rendezvous on
+            env.update(RANK=str(r), LOCAL_RANK=str(r if not self.external else os.environ.get("LOCAL_RANK", r)),       # their own store
+                       WORLD_SIZE=str(self.n), LOCAL_WORLD_SIZE=str(self.n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       RFI_BENCH_WORKER="1", RFI_BENCH_HB=os.path.join(self.tmp, f"hb_{attempt}_{r}"))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if attempt > 0:
+                env.update(RFI_NO_BUCKETS="1", RFI_NO_STOP_EVENTS="1", RFI_BENCH_FALLBACK="unbucketed")
+            self.errs[r] = tempfile.TemporaryFile()
+            self.procs[r] = subprocess.Popen([sys.executable, os.path.abspath(__file__), *self.argv], env=env,
+                                             stdout=self.out0 if r == 0 else subprocess.DEVNULL, stderr=self.errs[r])
+
+    def last_beat(self, attempt, r):
+        try:
+            with open(os.path.join(self.tmp, f"hb_{attempt}_{r}")) as f:
+                lines = f.read().split("\n")
+            phase, t = [ln for ln in lines if ln][-1].split()
+            return phase, float(t)
+        except Exception:
+            return "spawned", None
+
+    @staticmethod
     def tail(f, nbytes=3000):
         f.seek(0, os.SEEK_END)
         f.seek(max(0, f.tell() - nbytes))
         return f.read().decode(errors="replace")
 
-    def stop_all():
-        for p in procs:
+    def stop_all(self):
+        import subprocess
+        for p in self.procs.values():
             if p.poll() is None:
                 p.terminate()
         t_end = time.time() + 5.0
-        for p in procs:
+        for p in self.procs.values():
             try:
                 p.wait(timeout=max(0.1, t_end - time.time()))
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
 
-    t_start, failed = time.time(), None
-    while True:
-        codes = [p.poll() for p in procs]
-        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad:
-            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
-            break
-        if all(c == 0 for c in codes):
-            break
-        if time.time() - t_start > limit:
-            failed = f"no result after {limit:.0f} s (RFI_BENCH_LAUNCH_TIMEOUT)"
-            bad = [(r, None) for r, c in enumerate(codes) if c is None][:1]
-            break
-        time.sleep(0.1)
-    if failed:
-        stop_all()
-        r = bad[0][0]
-        sys.stderr.write(f"bench: {failed}; the other ranks were terminated.  stderr tail of rank {r}:\n{tail(errs[r])}\n")
-        raise SystemExit(1)
-    sys.stderr.write(tail(errs[0], 20000))        # rank 0's progress log
-    out0.seek(0)
-    sys.stdout.write(out0.read().decode())
-    sys.stdout.flush()
+    def attempt(self, a):
+        """Run one set of children to the end.  Returns None on success, else the reason of the failure."""
+        port = self.worker_port(a)
+        t_start = time.time()
+        self.spawn(a, port)
+        fail_key, ok_key = f"rfi_bench/fail/{a}", f"rfi_bench/ok/{a}"
+        reported_ok, failed = False, None
+        while failed is None:
+            now = time.time()
+            codes = {r: p.poll() for r, p in self.procs.items()}
+            for r, c in codes.items():
+                if c not in (None, 0):
+                    if self.last_beat(a, r)[0] == "done":      # everything was measured and printed: a crash in the teardown of
+                        codes[r] = 0                           # the process is reported, not turned into a failed run
+                        if r not in self.warned:
+                            self.warned.add(r)
+                            sys.stderr.write(f"bench: rank {r} exited with code {c} AFTER its last phase ('done'); ignored\n")
+                        continue
+                    failed = f"rank {r} exited with code {c} after phase '{self.last_beat(a, r)[0]}'"
+            if failed is None:
+                for r, c in codes.items():
+                    if c is not None:
+                        continue
+                    phase, t = self.last_beat(a, r)
+                    since = now - (t if t is not None else t_start)
+                    if phase in self.bound and since > self.bound[phase]:
+                        failed = (f"rank {r} has been in the phase after '{phase}' (-> '{PHASES[PHASES.index(phase) + 1]}') for "
+                                  f"{since:.0f} s (bound {self.bound[phase]:.0f} s)")
+            if failed is None and now - t_start > self.limit:
+                failed = f"no result after {self.limit:.0f} s (RFI_BENCH_LAUNCH_TIMEOUT)"
+            if failed is not None:
+                self.flag(fail_key, f"[supervisor of rank {self.ranks[0]}] {failed}")
+                break
+            if self.flag(fail_key):
+                try:
+                    failed = "another rank's supervisor ended the attempt: " + self.store.get(fail_key).decode(errors="replace")
+                except Exception:
+                    failed = "another rank's supervisor ended the attempt"
+                break
+            if all(c == 0 for c in codes.values()):
+                if not reported_ok:
+                    self.count(ok_key, 1)
+                    reported_ok = True
+                done = self.count(ok_key, 0)
+                if done is None or done >= self.n:        # every rank's child has finished (or nobody is left to ask)
+                    return None
+            time.sleep(0.1)
+        self.stop_all()
+        return failed
+
+    def leave(self):
+        """The supervisor that hosts the store leaves last (the others still poll it until they have seen everybody finish)."""
+        if self.store is None:
+            return
+        hosts = self.external and self.ranks[0] == 0 and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") != "True"
+        n = self.count("rfi_bench/bye", 1)
+        t_end = time.time() + 10.0
+        while hosts and n is not None and n < self.n and time.time() < t_end:
+            time.sleep(0.05)
+            n = self.count("rfi_bench/bye", 0)
+
+    def run(self):
+        try:
+            self.connect_store()
+        except Exception as e:          # no coordination possible: a local watchdog is still better than none
+            sys.stderr.write(f"bench: no store between the supervisors ({e}); watchdog only, no coordinated fallback\n")
+            self.store = None
+        reasons = []
+        for a in range(2):
+            why = self.attempt(a)
+            if why is None:
+                self.leave()
+                sys.stderr.write(self.tail(self.errs[self.ranks[0]], 20000))        # progress log of the first local rank
+                if 0 in self.ranks:
+                    self.out0.seek(0)
+                    sys.stdout.write(self.out0.read().decode())
+                    sys.stdout.flush()
+                return 0
+            reasons.append(why)
+            sys.stderr.write(f"bench: attempt {a + 1} ({'bucketed exchange' if a == 0 else 'unbucketed fallback'}) failed: {why}\n")
+            for r in self.ranks:
+                sys.stderr.write(f"---- stderr tail of rank {r}:\n{self.tail(self.errs[r])}\n")
+            if a == 0:
+                sys.stderr.write("bench: starting a fresh set of ranks with RFI_NO_BUCKETS=1 RFI_NO_STOP_EVENTS=1\n")
+            sys.stderr.flush()
+        sys.stderr.write("bench: both attempts failed: " + " | ".join(reasons) + "\n")
+        return 1
 
 
 def roofline_of(launches, fam_serial, profile_steps, dtype, workload, peak_tf):
@@ -274,10 +439,14 @@ def measure(model, ctx, D, d_x, d_y, hp, args, dtype, rank, launch_csv=None):
     import tempfile
     B, S = args.batch, args.size
     model.set_compute_dtype(MODE_BY_DTYPE[dtype])
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+        if i == 0:
+            ctx.synchronize()                     # the first step (with its first bucketed gradient exchange) has run
+            beat("first_step")
     ctx.synchronize()
     D.barrier()
+    beat("warmup")
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
@@ -288,10 +457,29 @@ def measure(model, ctx, D, d_x, d_y, hp, args, dtype, rank, launch_csv=None):
     wall = time.perf_counter() - t0
     D.barrier()
     wall = D.max_over_ranks(wall)
+    beat("timed")
     log(f"[{dtype}] timed region done: {wall * 1e3 / args.steps:.2f} ms/step (host enqueue {enq * 1e3 / args.steps:.2f} ms/step)")
     loss, _ = model.last_loss()
     if not np.isfinite(loss):
         raise SystemExit(f"non-finite loss {loss}")
+    # ---- sustained sample: the contract's K steps are a fraction of a second on a power-bound kernel mix; the same step for
+    # about two more seconds, in windows of 20 steps (a synchronisation between windows), shows the clock the chip settles at
+    sustained = None
+    if args.sustain_steps > 0:
+        win, times = 20, []
+        for _ in range(max(1, args.sustain_steps // win)):
+            t1 = time.perf_counter()
+            for _ in range(win):
+                model.train_step_async(d_x.ptr, d_y.ptr, B, S, S, hp)
+            ctx.synchronize()
+            times.append(D.max_over_ranks(time.perf_counter() - t1))
+        n_s, tot = win * len(times), float(sum(times))
+        per = sorted(t * 1e3 / win for t in times)
+        sustained = {"steps": n_s, "ms_per_step": round(tot * 1e3 / n_s, 4), "value": round(D.world_size() * B * n_s / tot, 2),
+                     "windows_of_20_steps_ms_per_step": {"min": round(per[0], 4), "median": round(per[len(per) // 2], 4), "max": round(per[-1], 4),
+                                                         "first": round(times[0] * 1e3 / win, 4), "last": round(times[-1] * 1e3 / win, 4)},
+                     "note": "run right after the timed region; `value` of the line stays the contract's K-step figure"}
+        log(f"[{dtype}] sustained: {sustained['ms_per_step']:.3f} ms/step over {n_s} steps")
     # ---- per-kernel-family HIP-event profile (separate steps so events do not sit in the timed region).
     # Two passes: OVERLAPPED (the mode the timed region ran in; durations of co-running kernels stretch) and SERIAL
     # (side-stream overlap off: every kernel alone on the chip -> the per-kernel durations the roofline is computed
@@ -318,7 +506,7 @@ def measure(model, ctx, D, d_x, d_y, hp, args, dtype, rank, launch_csv=None):
                 fam_ov = ctx.profile_report()
         ctx.set_overlap(not os.environ.get("RFI_NO_OVERLAP") == "1")
     D.barrier()
-    return {"wall": wall, "ev_ms": ev_ms, "loss": float(loss), "fam": fam, "fam_ov": fam_ov, "launches": launches}
+    return {"wall": wall, "ev_ms": ev_ms, "loss": float(loss), "fam": fam, "fam_ov": fam_ov, "launches": launches, "sustained": sustained}
 
 
 def synthetic_instances(batch, size, seed, per_image=3):
@@ -383,17 +571,22 @@ def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
     x = ctx.to_device(x)                              # inputs resident in HBM before the timed region (the instance masks go up
     log(f"detector built, batch {B} x {S}x{S}x3 with {len(targets[0]['boxes'])} instances per patch")     # with the first warm-up step)
     losses = None
-    for _ in range(args.warmup):
-        losses = det.train_step(x, targets)
+    for i in range(args.warmup):
+        losses = det.train_step(x, targets, masks_resident=True)
+        if i == 0:
+            ctx.synchronize()
+            beat("first_step")
     ctx.synchronize()
     D.barrier()
+    beat("warmup")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = det.train_step(x, targets)
+        losses = det.train_step(x, targets, masks_resident=True)
     ctx.synchronize()
     wall = time.perf_counter() - t0
     D.barrier()
     wall = D.max_over_ranks(wall)
+    beat("timed")
     log(f"[{args.dtype}] timed region done: {wall * 1e3 / args.steps:.1f} ms/step")
     if not np.isfinite(losses["loss"]):
         raise SystemExit(f"non-finite loss {losses}")
@@ -404,7 +597,7 @@ def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
         ctx.profile_reset()
         ctx.profile(True)
         for _ in range(args.profile_steps):
-            det.train_step(x, targets)
+            det.train_step(x, targets, masks_resident=True)
         ctx.synchronize()
         ctx.profile(False)
         fam = ctx.profile_report()
@@ -420,6 +613,8 @@ def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
         D.barrier()
         ctx.comm_destroy()
     if rank != 0:
+        beat("done")
+        D.shutdown()
         return
     P = max(args.profile_steps, 1)
     ms_per_step = wall * 1e3 / args.steps
@@ -428,7 +623,7 @@ def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
     kernel_ms = sum(f["ms"] for f in fam.values()) / P
     step_flops = sum(f["flops"] for f in fam.values()) / P
     out = {"metric": "training patches/sec (128x128x3)", "value": round(world * B * args.steps / wall, 2), "unit": "patches/s",
-           "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+           "n_gpus": world, "n_ranks_seen": n_ranks_seen, "fallback": os.environ.get("RFI_BENCH_FALLBACK"), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype.startswith("bf16") else "f32",
            "data": "synthetic",
            "config": {"workload": f"MaskRCNN(2 classes; ResNet-50-FPN 64/256, RPN on P2..P6, RoIAlign 7x7 + 14x14, 1024-wide box head, "
@@ -449,7 +644,9 @@ def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline ...")
         out["cpu_baseline"] = cpu_baseline_maskrcnn(S, B)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    beat("done")
+    D.shutdown()
 
 
 ARITHMETIC = {"f32": "float32 (contractions by 3 x bf16 splitting, float32-level accuracy; --dtype f32mfma selects the "
@@ -487,6 +684,8 @@ def main():
                          "f32planes: the f32 arithmetic on pre-split plane tensors; bf16regs: bf16 operands rounded in "
                          "registers, float32 storage (round 1's bf16 mode)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--sustain-steps", type=int, default=None,
+                    help="steps of the sustained sample run after the timed region (default: 300 for the 128x128 workloads, 0 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", "--no-float32-line", dest="no_companion", action="store_true",
                     help="skip the bfloat16 measurement the default N = 1 U-Net line carries next to the float32 one")
@@ -495,10 +694,13 @@ def main():
                     help="control plane only (rendezvous, barrier, max-over-ranks, one JSON line); no GPU work")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return self_launch(args.gpus)
+    if args.gpus > 1 and not os.environ.get("RFI_BENCH_WORKER"):
+        raise SystemExit(Supervisor(args.gpus, sys.argv[1:]).run())
     if os.environ.get("RFI_BENCH_FAIL_RANK") is not None and os.environ.get("RFI_BENCH_FAIL_RANK") == os.environ.get("RANK"):
         raise SystemExit("fault injection (RFI_BENCH_FAIL_RANK): this rank exits at init")     # launcher tests
+    if args.gpus > 1:
+        import torch  # noqa: F401  (the slow import of a fresh box belongs to the phase in front of "imports")
+    beat("imports")
 
     if args.batch is None:
         args.batch = 1 if args.workload.endswith("1024") else 64
@@ -506,6 +708,8 @@ def main():
         args.size = 1024 if args.workload.endswith("1024") else 128
     if args.features is None:
         args.features = 64 if args.workload in ("cnn3", "resnet", "resnet1024") else 32
+    if args.sustain_steps is None:
+        args.sustain_steps = 300 if args.workload in ("unet", "cnn3") else 0
     default_dtype = args.dtype is None
     if default_dtype:
         args.dtype = "bf16" if args.workload in ("unet1024", "resnet1024") else "f32"    # (configs[2] names bf16)
@@ -519,15 +723,18 @@ def main():
     rank, local_rank, world = D.init_control_plane("gloo")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    D.barrier()
+    beat("control_plane")
     if args.dry_run:
-        D.barrier()
         t0 = time.perf_counter()
         D.barrier()
         wall = D.max_over_ranks(time.perf_counter() - t0)
         seen = D.count_ranks()
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
-                              "barrier_ms": round(wall * 1e3, 3)}))
+                              "barrier_ms": round(wall * 1e3, 3), "fallback": os.environ.get("RFI_BENCH_FALLBACK")}), flush=True)
+        beat("done")
+        D.shutdown()
         return
 
     import torch
@@ -543,6 +750,7 @@ def main():
     n_ranks_seen = D.count_ranks_rccl(ctx, world)      # a sum of ones over the RCCL communicator itself
     if n_ranks_seen != world:
         raise SystemExit(f"RCCL communicator sees {n_ranks_seen} ranks, expected {world}")
+    beat("rccl_init")
 
     if args.workload == "maskrcnn":
         return run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen)
@@ -582,6 +790,8 @@ def main():
         D.barrier()
         ctx.comm_destroy()
     if rank != 0:
+        beat("done")
+        D.shutdown()
         return
 
     def line_of(r, dtype):
@@ -592,6 +802,7 @@ def main():
         return {"value": round(world * B * args.steps / r["wall"], 2), "ms_per_step": round(ms_per_step, 4),
                 "dtype": "bf16" if dtype.startswith("bf16") else "f32", "arithmetic": ARITHMETIC[dtype],
                 "roofline": roof,
+                "sustained": r["sustained"],
                 "step": {"algorithmic_gflop_per_patch": round(step_flops / B / 1e9, 3),
                          "tflops_whole_step": round(step_tflops, 3),
                          "frac_of_instruction_peak": round(step_tflops / peak, 4),
@@ -603,7 +814,7 @@ def main():
     out = {
         "metric": ("training patches/sec (128x128x3)" if S == 128 else f"training samples/sec ({S}x{S}x3)"),
         "value": main_line["value"], "unit": "patches/s" if S < 512 else "samples/s",
-        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],
+        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "fallback": os.environ.get("RFI_BENCH_FALLBACK"), "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_line["dtype"], "data": "synthetic",
         "config": {"workload": {
             "unet": f"UNet(3,1,{args.features}) train step (fwd+BCE/dice+bwd+clip+Adam), "
@@ -622,6 +833,7 @@ def main():
                    "global_batch": B * world, "patch": [S, S, 3], "parallelism": f"dp{world}",
                    "params": n_params},
         "roofline": main_line["roofline"],
+        "sustained": main_line["sustained"],
         "step": main_line["step"],
         "families": main_line["families"],
         "families_overlapped": main_line["families_overlapped"],
@@ -634,7 +846,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline ...")
         out["cpu_baseline"] = cpu_baseline(args.workload, args.features, S, B)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    beat("done")
+    D.shutdown()
 
 
 if __name__ == "__main__":

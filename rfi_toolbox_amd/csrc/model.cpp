@@ -58,6 +58,7 @@ rfi_model::~rfi_model() {
     if (x3_descs) ctx->release(x3_descs);
     if (d_sums) ctx->release(d_sums);
     if (d_scalars) ctx->release(d_scalars);
+    if (wd_ready) (void)hipEventDestroy(wd_ready);
 }
 
 // ------------------------------------------------------------------------------------ build
@@ -405,6 +406,13 @@ void rfi_model::prepare(int n, int h, int w) {
     pN = n; pH = h; pW = w;
 }
 
+// the main stream waits for the side stream's rebuild of the input-gradient-direction filter copies (refresh_dgrad_weights)
+void rfi_model::wait_wd() {
+    if (!wd_pending) return;
+    RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, wd_ready, 0));
+    wd_pending = false;
+}
+
 void rfi_model::refresh_dgrad_weights() {
     if (!wd_dirty && (!use_w3() || x3_fresh) && ws_P == ws_need()) return;
     if (!relayout_descs) {          // one descriptor per conv-like layer, built once
@@ -425,9 +433,27 @@ void rfi_model::refresh_dgrad_weights() {
                                      hipMemcpyHostToDevice, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // h goes out of scope
     }
-    launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
-                                   wd_pool, relayout_bytes, relayout_tiles);
-    refresh_ws_weights(ws_need());
+    // Split rebuild (plain U-Net, float32 tensors, overlap on): the forward pass needs the forward-direction copies only, so
+    // the dgrad layout and its B-operand images are rebuilt on the SIDE stream (idle during the forward pass) under the first
+    // convs; backward() waits for them (wait_wd).  RFI_NO_WD_SIDE=1: everything on the main stream, as before
+    static const bool no_wd_side = getenv("RFI_NO_WD_SIDE") != nullptr;
+    const bool split = !no_wd_side && ctx->overlap && !ctx->profiling && arch == 0 && !planesP && ws_need() != 0 && ws_pool && ws_P == ws_need() &&
+                       ws_n_fwd > 0 && (!use_w3() || (x3_descs && !x3_reads_wd && x3_for_ws_P == ws_P)) && ctx->stream == ctx->main_stream;
+    if (split) {
+        if (!wd_ready) RFI_CHECK_HIP(hipEventCreateWithFlags(&wd_ready, hipEventDisableTiming));
+        side_begin();                             // the side stream waits for the optimiser step (everything on main so far)
+        struct Back { rfi_ctx* c; ~Back() { c->stream = c->main_stream; } } back{ctx};
+        launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
+                                       wd_pool, relayout_bytes, relayout_tiles);
+        refresh_ws_weights(ws_need(), 2);
+        RFI_CHECK_HIP(hipEventRecord(wd_ready, ctx->side_stream));
+        wd_pending = true;
+    } else {
+        wait_wd();
+        launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
+                                       wd_pool, relayout_bytes, relayout_tiles);
+    }
+    refresh_ws_weights(ws_need(), split ? 1 : 0);
     if (use_w3()) {       // pre-split records of both layouts of the conv-like layers (the round-2 kernels read them as is)
         if (!w3_pool) {
             size_t need = 0;
@@ -456,8 +482,10 @@ void rfi_model::refresh_dgrad_weights() {
             x3_bytes = 0;
             std::vector<X3Desc> h;
             x3_skips_ws_layers = !all_x3 && ws_P == 3 && arch == 0;
+            x3_reads_wd = false;
             auto add = [&](const float* src, float* dst, int taps, int cout, int cin) {
                 if (x3_skips_ws_layers && ws_by_w.count(src)) return;
+                if (src < params || src >= params + n_flat) x3_reads_wd = true;
                 h.push_back(X3Desc{src, dst, (int64_t)taps * cout, cin, (cin + 15) / 16});
                 x3_bytes += (double)taps * cout * cin * 4 + (double)weights_x3_floats(taps, cout, cin) * 4;
             };
@@ -485,12 +513,12 @@ void rfi_model::refresh_dgrad_weights() {
 // filters of every 3x3 stride-1 layer in MFMA B-operand order with three planes (conv_ws.hip), both directions, rebuilt
 // with the other derived copies after each optimiser step by ONE batched launch.  Callers find them by the layer's
 // float32 filter pointer (ws_set(ConvArgs) looks up ConvArgs::w), which every model's conv helper already passes around
-void rfi_model::refresh_ws_weights(int P) {
+void rfi_model::refresh_ws_weights(int P, int which) {
     if (P != ws_P) {                  // another arithmetic: its copies have another size
         if (ws_pool) { ctx->release(ws_pool); ws_pool = nullptr; }
         if (ws_descs) { ctx->release(ws_descs); ws_descs = nullptr; }
         ws_by_w.clear();
-        ws_n = 0;
+        ws_n = ws_n_fwd = 0;
         ws_P = P;
     }
     if (P == 0) return;
@@ -512,9 +540,11 @@ void rfi_model::refresh_ws_weights(int P) {
         if (need == 0) return;
         ws_pool = static_cast<bf16_t*>(ctx->alloc(need * 2));
         RFI_CHECK_HIP(hipMemsetAsync(ws_pool, 0, need * 2, ctx->stream));
-        std::vector<WBDesc> hd;
+        // forward-direction images first (sources in `params`), then the input-gradient direction (sources in wd_pool): the
+        // two halves can be rebuilt by separate launches (refresh_dgrad_weights puts the second on the side stream)
+        std::vector<WBDesc> hd, hdg;
         size_t o = 0;
-        ws_bytes = 0;
+        ws_bytes = ws_bytes_fwd = 0;
         for (ConvBN& c : convs) {
             if (conv_f(c)) {
                 c.ws3f = ws_pool + o;
@@ -522,13 +552,13 @@ void rfi_model::refresh_ws_weights(int P) {
                 o += e + 32;
                 hd.push_back(WBDesc{params + c.w_off, c.ws3f, 9, c.cout, c.cin_p, {c.cin_p, 0}, P});
                 ws_by_w[params + c.w_off] = c.ws3f;
-                ws_bytes += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
+                ws_bytes_fwd += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
             }
             if (conv_d(c)) {
                 c.ws3d = ws_pool + o;
                 const size_t e = wb_elems(9, c.cin_p, c.cout, 0, P);
                 o += e + 32;
-                hd.push_back(WBDesc{c.wd, c.ws3d, 9, c.cin_p, c.cout, {c.cout, 0}, P});
+                hdg.push_back(WBDesc{c.wd, c.ws3d, 9, c.cin_p, c.cout, {c.cout, 0}, P});
                 ws_by_w[c.wd] = c.ws3d;
                 ws_bytes += 2.0 * e + 4.0 * 9 * c.cin_p * c.cout;
             }
@@ -537,10 +567,11 @@ void rfi_model::refresh_ws_weights(int P) {
                 hd.push_back(WBDesc{params + c.w_off, ws_pool + o, 1, c.cout, c.cin_p, {c.cin_p, 0}, P});
                 ws_by_w[params + c.w_off] = ws_pool + o;
                 o += ef + 32;
-                hd.push_back(WBDesc{c.wd, ws_pool + o, 1, c.cin_p, c.cout, {c.cout, 0}, P});
+                hdg.push_back(WBDesc{c.wd, ws_pool + o, 1, c.cin_p, c.cout, {c.cout, 0}, P});
                 ws_by_w[c.wd] = ws_pool + o;
                 o += ed + 32;
-                ws_bytes += 2.0 * (ef + ed) + 8.0 * c.cin_p * c.cout;
+                ws_bytes_fwd += 2.0 * ef + 4.0 * c.cin_p * c.cout;
+                ws_bytes += 2.0 * ed + 4.0 * c.cin_p * c.cout;
             }
         }
         // transposed convs (gemm_ws.hip): forward = ONE tap of 4 cout channels ([4][cout][cin] IS [4 cout][cin]); input
@@ -551,17 +582,24 @@ void rfi_model::refresh_ws_weights(int P) {
             hd.push_back(WBDesc{params + u.w_off, ws_pool + o, 1, 4 * u.cout, u.cin, {u.cin, 0}, P});
             ws_by_w[params + u.w_off] = ws_pool + o;
             o += ef + 32;
-            hd.push_back(WBDesc{u.wd, ws_pool + o, 4, u.cin, u.cout, {u.cout, 0}, P});
+            hdg.push_back(WBDesc{u.wd, ws_pool + o, 4, u.cin, u.cout, {u.cout, 0}, P});
             ws_by_w[u.wd] = ws_pool + o;
             o += ed + 32;
-            ws_bytes += 2.0 * (ef + ed) + 8.0 * 4 * u.cin * u.cout;
+            ws_bytes_fwd += 2.0 * ef + 4.0 * 4 * u.cin * u.cout;
+            ws_bytes += 2.0 * ed + 4.0 * 4 * u.cin * u.cout;
         }
+        ws_n_fwd = (int)hd.size();
+        ws_bytes += ws_bytes_fwd;
+        hd.insert(hd.end(), hdg.begin(), hdg.end());
         ws_n = (int)hd.size();
         ws_descs = ctx->alloc(hd.size() * sizeof(WBDesc));
         RFI_CHECK_HIP(hipMemcpyAsync(ws_descs, hd.data(), hd.size() * sizeof(WBDesc), hipMemcpyHostToDevice, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // hd goes out of scope
     }
-    if (ws_n) launch_weights_to_wb(ctx, static_cast<const WBDesc*>(ws_descs), ws_n, ws_bytes);
+    const WBDesc* descs = static_cast<const WBDesc*>(ws_descs);
+    if (which == 0 && ws_n) launch_weights_to_wb(ctx, descs, ws_n, ws_bytes);
+    if (which == 1 && ws_n_fwd) launch_weights_to_wb(ctx, descs, ws_n_fwd, ws_bytes_fwd);
+    if (which == 2 && ws_n > ws_n_fwd) launch_weights_to_wb(ctx, descs + ws_n_fwd, ws_n - ws_n_fwd, ws_bytes - ws_bytes_fwd);
 }
 
 // ------------------------------------------------------------------------------------ forward
@@ -760,7 +798,8 @@ static hipEvent_t bucket_event(rfi_ctx* ctx) {
 void rfi_model::bucket_ready(size_t lo, size_t hi) {
     if (!exchange_in_backward || !ctx->exchange_active() || hi <= lo) return;
     static const bool no_buckets = getenv("RFI_NO_BUCKETS") != nullptr;
-    static const size_t min_floats = getenv("RFI_BUCKET_MIN_FLOATS") ? (size_t)atoll(getenv("RFI_BUCKET_MIN_FLOATS")) : (size_t)1 << 20;
+    const char* mf = getenv("RFI_BUCKET_MIN_FLOATS");              // (read per call: tests switch it inside one process)
+    const size_t min_floats = mf ? (size_t)atoll(mf) : (size_t)1 << 20;
     if (pend_hi > pend_lo) {
         RFI_REQUIRE(hi == pend_lo || lo == pend_hi, "bucket_ready: buckets must be adjacent");
         pend_lo = std::min(pend_lo, lo);
@@ -824,7 +863,14 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
     else
         launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(),
                              c.c2(), m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
-    const hipEvent_t dy_done = m->next_fork_event();         // completes with the kernel that writes dY (over dA)
+    // RFI_WGRAD_LATE=1 (default): the weight gradient is enqueued BEHIND the input-gradient conv of the same layer (the side
+    // stream waits for it): two matrix-core kernels sharing the chip finish no sooner than one after the other, but a
+    // weight gradient that runs next to the following layer's BatchNorm-backward passes (memory-bound) hides them
+    static const bool late = !(getenv("RFI_WGRAD_LATE") && atoi(getenv("RFI_WGRAD_LATE")) == 0);
+    // a kernel that carries a completion signal leaves a ~5 us bubble behind it on its stream: only the kernel the side stream
+    // actually waits for gets one (RFI_ALL_STOP_EVENTS=1: every bn_bwd_apply too, as in round 3)
+    static const bool all_stop = getenv("RFI_ALL_STOP_EVENTS") != nullptr;
+    const hipEvent_t dy_done = (all_stop || !late || !dx) ? m->next_fork_event() : nullptr;      // completes with the kernel that writes dY (over dA)
     // (dbias_deferred: the partial sums of the conv-bias gradient stay in the layer's own region; backward() finishes every
     // layer's in one launch at the end of the pass)
     launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
@@ -845,10 +891,6 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
     wa.slab_floats = m->bufs[m->ws_slab].n;
     wa.bf16 = m->compute_bf16;
     wa.bf16x3 = m->compute_x3;
-    // RFI_WGRAD_LATE=1 (default): the weight gradient is enqueued BEHIND the input-gradient conv of the same layer (the side
-    // stream waits for it): two matrix-core kernels sharing the chip finish no sooner than one after the other, but a
-    // weight gradient that runs next to the following layer's BatchNorm-backward passes (memory-bound) hides them
-    static const bool late = !(getenv("RFI_WGRAD_LATE") && atoi(getenv("RFI_WGRAD_LATE")) == 0);
     if (!late || !dx) {
         SideScope side(m, dy_done);
         launch_wgrad(ctx, wa);
@@ -915,6 +957,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     const int D = depth, IB = i_bott;
     const int64_t M1 = (int64_t)n * h * w;
     refresh_dgrad_weights();
+    wait_wd();                        // (the input-gradient-direction filter copies were rebuilt on the side stream)
     if (planesP) return backward_planes(x_dev, labels_dev, n, h, w);
     static const int bound_env = getenv("RFI_SIDE_BOUND") ? atoi(getenv("RFI_SIDE_BOUND")) : 0;
     side_bound = arch == 0 ? bound_env : 2;       // (the ResNet-style encoder double-buffers by block parity: bound 2)

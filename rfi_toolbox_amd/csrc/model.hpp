@@ -140,7 +140,15 @@ struct rfi_model {
     // declined shape runs the round-2 kernel on valid records instead of a temporary copy (an allocation + a stream
     // synchronisation per launch)
     bool x3_skips_ws_layers = false;
-    void refresh_ws_weights(int P);
+    int ws_n_fwd = 0;                 // the first ws_n_fwd descriptors build the forward-direction copies (sources in `params`)
+    double ws_bytes_fwd = 0;
+    void refresh_ws_weights(int P, int which = 0);      // which: 0 every copy, 1 the forward direction, 2 the input-gradient direction
+    // the input-gradient-direction copies (dgrad layout + their B-operand images) are rebuilt on the SIDE stream while the main
+    // stream runs the forward pass; the backward pass waits for wd_ready
+    hipEvent_t wd_ready = nullptr;
+    bool wd_pending = false;
+    bool x3_reads_wd = false;         // the batched 3 x bf16 record rebuild reads dgrad-layout filters
+    void wait_wd();
     // conv-bias gradients of the float32 U-Net path: bn_bwd_apply leaves its per-block partial sums in a per-layer region of
     // dbias_pool; ONE batched launch at the end of the backward pass finishes them all (single-GPU steps: with a gradient
     // exchange the buckets need every gradient of a layer when the layer is done)

@@ -72,6 +72,22 @@ def barrier():
         dist.barrier()
 
 
+def shutdown():
+    """Leave the control plane in an orderly way: a last barrier, then destroy the process group (a rank that simply exits
+    while its peers still hold connections to it can take them down in their teardown)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def count_ranks() -> int:
     """Ranks the control plane really connects: a sum of ones (1 without a process group)."""
     import torch

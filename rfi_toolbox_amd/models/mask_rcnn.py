@@ -310,7 +310,10 @@ class MaskRCNN:
                                                res, res, 2, 0, fp))
             off += cnt
 
-    def train_step(self, images, targets, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0):
+    def train_step(self, images, targets, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, masks_resident=False):
+        """One training step.  masks_resident=True: the caller promises that `targets` (the SAME list object as in the
+        previous step) still holds the same instance masks, so the copy already in HBM is used; otherwise the masks are
+        uploaded every step (a list refilled in place must not train the mask branch on last step's masks)."""
         from ..runtime import DeviceArray
         dev_in = isinstance(images, DeviceArray)                 # images already in HBM (float32 NHWC): no copy
         x = images if dev_in else np.ascontiguousarray(np.asarray(images, np.float32))
@@ -383,7 +386,7 @@ class MaskRCNN:
             gbase = np.concatenate([[0], np.cumsum(gcount)])
             if b.masks is None or b.masks_n < gbase[-1]:
                 b.masks, b.masks_n, b.masks_of = ctx.empty((int(gbase[-1]), h, w), np.uint8), int(gbase[-1]), None
-            if b.masks_of is not targets:                        # (the same annotation list as last step: its masks are resident)
+            if not (masks_resident and b.masks_of is targets):   # (resident only on the caller's word AND for the same list object)
                 self._upload(b.masks, np.concatenate([np.asarray(t["masks"], np.uint8).reshape(-1, h, w) for t in targets]))
                 b.masks_of = targets
             rm = rois[fg]
@@ -401,7 +404,14 @@ class MaskRCNN:
         norms = {}
         for name, m in zip(("backbone", "rpn", "box", "mask"), self.models()):
             if m is self.mask and not len(fg):
-                continue
+                # no foreground RoI on THIS rank.  Alone (grad_sync == 1) the mask head skips its step; in a data-parallel job
+                # the other ranks enter the all-reduce of its gradients, so this rank must too -- with zero gradients -- and
+                # then apply the same averaged update (a rank that skipped would hang the collective or leave the replicas
+                # different)
+                if self.grad_sync <= 1:
+                    continue
+                m.accumulate_gradients("begin")
+                m.accumulate_gradients("end")                    # grads = 0
             if self.grad_sync > 1:
                 m.allreduce_gradients()
             norms[name] = m.apply_gradients(lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm,

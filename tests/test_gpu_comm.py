@@ -249,3 +249,34 @@ def test_bucketed_exchange_emulation_is_bitwise_neutral(mode):
     for i in (2, 3):
         np.testing.assert_array_equal(out[0][i][0], out[1][i][0])
         np.testing.assert_array_equal(out[0][i][1], out[1][i][1])
+
+
+@pytest.mark.parametrize("min_floats", [None, "1"])
+@pytest.mark.parametrize("arch", ["resnet", "cnn3"])
+def test_bucketed_exchange_emulation_other_architectures(arch, min_floats, monkeypatch):
+    """The same bit-for-bit property for the models whose backward passes hand their gradient ranges to bucket_ready in
+    another order (the ResNet-style encoder) or as one range (the 3-layer CNN), with the default merge threshold (buckets
+    below 4 MB wait for their neighbours) and with RFI_BUCKET_MIN_FLOATS=1 (every bucket leaves alone): a range that is
+    not adjacent to the pending one, or one that is never flushed, fails here and not at step 1 of an N-GPU job."""
+    from rfi_toolbox_amd.models import SimpleCNN, UNetResNet18
+    if min_floats is None:
+        monkeypatch.delenv("RFI_BUCKET_MIN_FLOATS", raising=False)
+    else:
+        monkeypatch.setenv("RFI_BUCKET_MIN_FLOATS", min_floats)
+    ctx = Context.get(0)
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(4, 64, 64, 3, generator=g)
+    y = (torch.rand(4, 64, 64, generator=g) > 0.7).to(torch.uint8)
+    out = []
+    try:
+        for world in (0, 2):
+            ctx.comm_emulate(world)
+            torch.manual_seed(29)
+            m = UNetResNet18(3, 1, 16) if arch == "resnet" else SimpleCNN(3, 1, 32)
+            stats = [(m.train_step(x, y, lr=1e-3), m.last_loss()[1]) for _ in range(3)]
+            out.append((stats, m.state_dict()))
+    finally:
+        ctx.comm_emulate(0)
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k

@@ -184,3 +184,40 @@ def test_assembled_step_is_bitwise_reproducible():
         runs.append((losses, dict(det.last_trace["grad_norms"]), det.last_trace["rois"].copy()))
     for losses, norms, rois in runs[1:]:
         assert losses == runs[0][0] and norms == runs[0][1] and np.array_equal(rois, runs[0][2])
+
+
+def test_data_parallel_step_on_a_rank_without_foreground():
+    """grad_sync = 2 (emulated exchange, rfi_comm_emulate): a rank whose images hold no box has no foreground RoI, hence no
+    mask-branch gradient -- it must still take part in the all-reduce of the mask head's gradients (with zeros) and apply the
+    averaged update like every other rank; skipping both would hang the collective of a real job.  With targets present the
+    emulated step must equal the plain one bit for bit (every element exchanged once, scaled back by 1 / 2)."""
+    import torch
+    from rfi_toolbox_amd.models import MaskRCNN
+    from rfi_toolbox_amd.runtime import Context
+    ctx = Context.get(0)
+    x, targets = _batch(np.random.default_rng(5))
+    empty = [{"boxes": np.zeros((0, 4), np.float32), "labels": np.zeros(0, np.int64), "masks": np.zeros((0, 128, 128), np.uint8)} for _ in targets]
+    try:
+        res = []
+        for world in (0, 2):
+            ctx.comm_emulate(world)
+            torch.manual_seed(4)
+            det = MaskRCNN(2, 3, 16, 64, 128, seed=9)
+            det.grad_sync = max(world, 1)
+            det.rng = np.random.default_rng(3)
+            losses = det.train_step(x, targets, lr=1e-3)
+            res.append((losses, dict(det.last_trace["grad_norms"]), {k: v.clone() for k, v in det.mask.state_dict().items()}))
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], res[1][2][k]), k
+        # the rank without a box: the mask head is stepped (zero gradients: only the L2 term moves it)
+        ctx.comm_emulate(2)
+        before = {k: v.clone() for k, v in det.mask.state_dict().items()}
+        losses = det.train_step(x, empty, lr=1e-3, weight_decay=1e-2)
+        assert losses["loss_mask"] == 0.0 and np.isfinite(losses["loss"])
+        assert det.last_trace["grad_norms"]["mask"] == 0.0
+        after = det.mask.state_dict()
+        assert any(not torch.equal(before[k], after[k]) for k in before)          # weight decay acted: the step was applied
+        assert all(torch.isfinite(v).all() for v in after.values())
+    finally:
+        ctx.comm_emulate(0)
