@@ -1188,6 +1188,11 @@ void comm_bucket_allreduce(rfi_ctx* ctx, float* dptr, int64_t count) {
 }  // namespace rfi
 extern "C" {
 int rfi_model_allreduce_grads(rfi_model* m) {
+    if (m->ctx->comm_emulate > 1)          // rfi_comm_emulate: the explicit exchange of the split API is emulated like the buckets
+        return guarded([&] {
+            m->ctx->activate();
+            launch_scale_inplace(m->ctx, m->grads, (int64_t)m->n_flat, (float)m->ctx->comm_emulate);
+        });
     return rfi_comm_allreduce_sum_f32(m->ctx, m->grads, (int64_t)m->n_flat);
 }
 

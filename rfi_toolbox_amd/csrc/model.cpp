@@ -408,9 +408,26 @@ void rfi_model::prepare(int n, int h, int w) {
 
 // the main stream waits for the side stream's rebuild of the input-gradient-direction filter copies (refresh_dgrad_weights)
 void rfi_model::wait_wd() {
+    side_rebuild_wd();
     if (!wd_pending) return;
     RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, wd_ready, 0));
     wd_pending = false;
+}
+
+// the side-stream half of the split rebuild: dgrad layout + its B-operand images.  Started by forward() AFTER the first
+// conv is enqueued (the stem is bound by its HBM writes: next to it the rebuild slowed it from 33 to 62 us; the convs that
+// follow are matrix-bound) -- or by whoever needs the copies first (wait_wd)
+void rfi_model::side_rebuild_wd() {
+    if (!wd_side_todo) return;
+    wd_side_todo = false;
+    if (!wd_ready) RFI_CHECK_HIP(hipEventCreateWithFlags(&wd_ready, hipEventDisableTiming));
+    side_begin();                                 // the side stream waits for everything on main so far (the optimiser step)
+    struct Back { rfi_ctx* c; ~Back() { c->stream = c->main_stream; } } back{ctx};
+    launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
+                                   wd_pool, relayout_bytes, relayout_tiles);
+    refresh_ws_weights(ws_need(), 2);
+    RFI_CHECK_HIP(hipEventRecord(wd_ready, ctx->side_stream));
+    wd_pending = true;
 }
 
 void rfi_model::refresh_dgrad_weights() {
@@ -440,14 +457,7 @@ void rfi_model::refresh_dgrad_weights() {
     const bool split = !no_wd_side && ctx->overlap && !ctx->profiling && arch == 0 && !planesP && ws_need() != 0 && ws_pool && ws_P == ws_need() &&
                        ws_n_fwd > 0 && (!use_w3() || (x3_descs && !x3_reads_wd && x3_for_ws_P == ws_P)) && ctx->stream == ctx->main_stream;
     if (split) {
-        if (!wd_ready) RFI_CHECK_HIP(hipEventCreateWithFlags(&wd_ready, hipEventDisableTiming));
-        side_begin();                             // the side stream waits for the optimiser step (everything on main so far)
-        struct Back { rfi_ctx* c; ~Back() { c->stream = c->main_stream; } } back{ctx};
-        launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
-                                       wd_pool, relayout_bytes, relayout_tiles);
-        refresh_ws_weights(ws_need(), 2);
-        RFI_CHECK_HIP(hipEventRecord(wd_ready, ctx->side_stream));
-        wd_pending = true;
+        wd_side_todo = true;                      // (forward() starts it behind the first conv: side_rebuild_wd)
     } else {
         wait_wd();
         launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
@@ -671,6 +681,7 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
         run_conv_bn(this, c1, cur, InXform{}, s, buf(encY1[l]), train_mode);
+        if (l == 1) side_rebuild_wd();
         run_conv_bn(this, c2, View{buf(encY1[l]), c1.cout}, bn_xf(c1), s, buf(encY2[l]), train_mode);
         launch_bn_relu_pool(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
                             MutView{buf(concat[l]) + c2.cout, 2 * c2.cout}, buf(pool[l]), act_slope);
@@ -891,11 +902,8 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
     wa.slab_floats = m->bufs[m->ws_slab].n;
     wa.bf16 = m->compute_bf16;
     wa.bf16x3 = m->compute_x3;
-    if (!late || !dx) {
-        SideScope side(m, dy_done);
-        launch_wgrad(ctx, wa);
-        side.end();
-    }
+    const int ci = (int)(&c - m->convs.data());
+    if (!late || !dx) m->wgrad_on_side(ci, wa, dy_done);
     int records = 0;
     if (dx) {
         ConvArgs a;
@@ -922,16 +930,44 @@ int backward_conv_bn(rfi_model* m, ConvBN& c, float* dA, const float* Y, View in
         if (late) a.done = m->next_fork_event();      // the weight gradient starts when this kernel completes
         launch_conv(ctx, a);
         records = a.stats_records;
-        if (late) {
-            SideScope side(m, a.done_used ? a.done : nullptr);
-            launch_wgrad(ctx, wa);
-            side.end();
-        }
+        if (late) m->wgrad_on_side(ci, wa, a.done_used ? a.done : nullptr, !a.done_used);
     }
     return records;
 }
 
 }  // namespace
+
+// A layer's weight gradient has no consumer before the optimiser: it is a FILLER for the stretches in which the main stream
+// runs memory-bound BatchNorm-backward kernels.  By default it is enqueued on the side stream when its layer is done; the
+// defer map (RFI_WGRAD_DEFER="9>2,4>1": the weight gradient of convs[9] goes behind that of convs[2], ...; ">-1": the end of
+// the pass) moves weight gradients of deep layers -- whose own BatchNorm chains are short, so that they only queue behind
+// matrix-bound kernels -- to the shallow levels, whose BatchNorm chains outlast their own weight gradients.  Everything a
+// weight-gradient kernel reads stays untouched until side_join, so the order is free.  Not with a gradient exchange: the
+// buckets leave in layer order.
+void rfi_model::wgrad_on_side(int ci, const rfi::WgradArgs& wa, hipEvent_t after, bool after_everything) {
+    auto issue = [&](const rfi::WgradArgs& w, hipEvent_t ev, bool all) {
+        SideScope side(this, all ? nullptr : ev);      // (no event: the side stream waits for everything enqueued on main so far)
+        launch_wgrad(ctx, w);
+        side.end();
+    };
+    const int to = (ci >= 0 && ci < (int)defer_to.size() && !ctx->exchange_active() && ctx->overlap) ? defer_to[ci] : -2;
+    if (to != -2) deferred.push_back(DeferredWgrad{wa, after_everything ? nullptr : after, to});
+    else issue(wa, after, after_everything);
+    for (size_t i = 0; i < deferred.size();) {    // whatever was parked behind this layer's weight gradient
+        if (deferred[i].to == ci && to == -2) {
+            issue(deferred[i].a, deferred[i].after, false);
+            deferred.erase(deferred.begin() + i);
+        } else ++i;
+    }
+}
+void rfi_model::flush_deferred_wgrads() {
+    for (auto& d : deferred) {
+        SideScope side(this, d.after);
+        launch_wgrad(ctx, d.a);
+        side.end();
+    }
+    deferred.clear();
+}
 
 void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
     if (arch == 6) {
@@ -961,6 +997,19 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     if (planesP) return backward_planes(x_dev, labels_dev, n, h, w);
     static const int bound_env = getenv("RFI_SIDE_BOUND") ? atoi(getenv("RFI_SIDE_BOUND")) : 0;
     side_bound = arch == 0 ? bound_env : 2;       // (the ResNet-style encoder double-buffers by block parity: bound 2)
+    deferred.clear();
+    if (defer_to.empty()) {                       // parsed once per model
+        defer_to.assign(convs.size(), -2);
+        const char* e = getenv("RFI_WGRAD_DEFER");
+        if (arch == 0 && e) {
+            int a = 0, b = 0, nread = 0;
+            while (*e && sscanf(e, "%d>%d%n", &a, &b, &nread) == 2) {
+                if (a >= 0 && a < (int)convs.size() && b >= -1 && b < (int)convs.size()) defer_to[a] = b;
+                e += nread;
+                if (*e == ',') ++e;
+            }
+        }
+    }
     static const bool no_defer = getenv("RFI_NO_DEFER_DBIAS") != nullptr;
     dbias_deferred = arch == 0 && dbias_pool && !no_defer && !ctx->exchange_active();
     // loss -> dlogits -> head
@@ -1070,6 +1119,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
     }
     if (arch == 2) {                  // ResNet-style encoder (model_resnet.cpp)
         backward_resnet_encoder(x_dev, n, h, w);
+        flush_deferred_wgrads();
         side_join();
         return;
     }
@@ -1097,6 +1147,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
                          (l == 1) ? nullptr : buf(dpool[l - 1]), rec, nullptr, nullptr);
         bucket_ready(c1.w_off, convs[l == D ? IB : 2 * l].w_off);       // convs[2 l] = first conv of the next level / the bottleneck
     }
+    flush_deferred_wgrads();
     if (dbias_deferred) launch_finish_channel_sums_batched(ctx, static_cast<const FinishSumDesc*>(dbias_descs), dbias_n, dbias_max_c);
     side_join();
     side_bound = 2;

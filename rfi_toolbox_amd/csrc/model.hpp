@@ -147,6 +147,8 @@ struct rfi_model {
     // stream runs the forward pass; the backward pass waits for wd_ready
     hipEvent_t wd_ready = nullptr;
     bool wd_pending = false;
+    bool wd_side_todo = false;        // the side half of a split rebuild has not been enqueued yet
+    void side_rebuild_wd();
     bool x3_reads_wd = false;         // the batched 3 x bf16 record rebuild reads dgrad-layout filters
     void wait_wd();
     // conv-bias gradients of the float32 U-Net path: bn_bwd_apply leaves its per-block partial sums in a per-layer region of
@@ -285,6 +287,12 @@ struct rfi_model {
     void side_begin_after(hipEvent_t producer_done);   // side stream waits for that producer kernel only (null: as side_begin)
     void side_end();                  // marks the side launch; bounds the main stream's run-ahead
     void side_join();                 // main stream waits for all side work
+    // weight gradients parked for a later point of the backward pass (model.cpp, wgrad_on_side)
+    struct DeferredWgrad { rfi::WgradArgs a; hipEvent_t after; int to; };
+    std::vector<DeferredWgrad> deferred;
+    std::vector<int> defer_to;        // per conv: -2 at once; k >= 0: behind convs[k]'s weight gradient; -1: at the end of the pass
+    void wgrad_on_side(int ci, const rfi::WgradArgs& wa, hipEvent_t after, bool after_everything = false);
+    void flush_deferred_wgrads();
     // bucketed gradient exchange (common.hpp): grads[lo, hi) are final once everything enqueued so far on the main
     // and side streams has run -> all-reduce them on the communication stream; exchange_join: main waits for all
     bool exchange_in_backward = false;   // set by the full-step entry points only (the split API exchanges explicitly)
