@@ -424,6 +424,66 @@ int rfi_op_rpn_loss(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors
 int rfi_op_rpn_loss_dev(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
                         const float* targets, int64_t num_sampled, float beta, float* dhead, void* workspace, float* loss2_dev);
 size_t rfi_op_rpn_loss_ws_bytes(void);
+/* ---- The detector's box bookkeeping on the device (csrc/detect_sample.hip): the work rfi_toolbox_amd.models.MaskRCNN did in
+ * NumPy between the GPU stages (the reference has no detector, so no reference interface is replaced: SURVEY 8a A11).  All
+ * pointers are device pointers unless named *_host; nothing here synchronises or allocates.
+ * rpn_loss_devcount: rfi_op_rpn_loss_dev with the normaliser read from device memory (the sampler's count).
+ * fastrcnn_loss_dev: rfi_op_fastrcnn_loss leaving (classification, box) in loss2_dev; workspace as rpn_loss_dev.
+ * anchor_match_batched_ws: rfi_op_anchor_match_batched with a caller-held workspace of images x gt_max floats.
+ * segsort_u64: n_segs segments of `stride` (a power of two <= 8192) 64-bit keys, each sorted ascending in place.
+ * sample_keys: labels [images][n] (1 positive, 0 negative) -> keys [images][stride] = class << 48 | r << 16 | i with
+ *   r = Philox4x32-10(counter (i, image, stream0 + class, step), key seed).x; rows >= count[image] (null: n) get ~0.
+ * rpn_sample_apply: from the SORTED keys, `batch` anchors per image (at most max_pos positive, smallest keys first) keep their
+ *   label, other labels >= 0 become -1; labels / targets are written level by level (level l holds anchors
+ *   [level_off[l], level_off[l + 1]) of every image: [images][count_l] and [..][4]); *n_sampled += anchors sampled.
+ * topk_keys / topk_decode: keys of the objectness logits of head [images][pixels][5 A] (descending, ties by anchor index);
+ *   from the sorted keys the k best are decoded against `anchors`, clipped, boxes under min_size moved behind the rest
+ *   (score -inf) -> slot `level` of boxes [images][levels][k][4], scores [images][levels][k], counts [images][levels].
+ * proposals_select: per image the post_nms best kept candidates (descending score, ties level-major) followed by its
+ *   ground-truth boxes -> props [images][pmax][4], pcount [images].
+ * roi_sample: `batch` proposals per image, at most max_pos with matcher label 1 -> sel [images][batch] (positives first, -1
+ *   padding), nsel / npos [images].  roi_compact: the batch's RoIs, image-major and compact: rois [R][5], class labels
+ *   (gt_labels [images][gt_max] of the matched instance; 0 background), targets, matched instance (-1), pyramid level
+ *   0 + [area >= t1] + [area >= t2] + [area >= t3], img_start [images + 1]; the foreground rows again (rois_fg, rois_gt with
+ *   the global instance index gt_base[image] + matched as column 0, level_fg, fg_start); counts = (R, Rf).
+ * roi_align_ml / _backward: RoIAlign where RoI r uses map level[r] of four ([n][h0 >> k][w0 >> k][c], scale scale0 / 2^k; host
+ *   arrays of device pointers); the row count is read from count_dev, max_rois sizes the launch; backward ADDS into dmaps.
+ * readback_begin / _end: a copy of <= 2048 bytes to the host that waits for the work enqueued BEFORE begin only. */
+int rfi_op_rpn_loss_devcount(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
+                             const float* targets, const int32_t* num_sampled_dev, float beta, float* dhead, void* workspace,
+                             float* loss2_dev);
+int rfi_op_fastrcnn_loss_dev(rfi_ctx* ctx, const float* head, int64_t rois, int num_classes, const int32_t* labels, const float* targets,
+                             float beta, float* dhead, void* workspace, float* loss2_dev);
+int rfi_op_anchor_match_batched_ws(rfi_ctx* ctx, const float* anchors, int64_t n, int64_t anchor_stride, const int32_t* anchor_count,
+                                   const float* gt_boxes, int images, int gt_max, const int32_t* gt_count, float fg_iou, float bg_iou,
+                                   int allow_low_quality, float* best_ws, int8_t* labels, int32_t* matched, float* targets);
+int rfi_op_segsort_u64(rfi_ctx* ctx, uint64_t* keys, int n_segs, int stride);
+int rfi_op_sample_keys(rfi_ctx* ctx, const int8_t* labels, int images, int n, const int32_t* count, uint64_t seed, uint32_t step,
+                       uint32_t stream0, uint64_t* keys, int stride);
+int rfi_op_rpn_sample_apply(rfi_ctx* ctx, const uint64_t* keys_sorted, int images, int n, int stride, int batch, int max_pos,
+                            const int8_t* labels, const float* targets, int levels, const int32_t* level_off_host,
+                            int8_t* const* level_labels_host, float* const* level_targets_host, int32_t* n_sampled);
+int rfi_op_topk_keys(rfi_ctx* ctx, const float* head, int images, int pixels, int anchors_per_pixel, uint64_t* keys, int stride);
+int rfi_op_topk_decode(rfi_ctx* ctx, const uint64_t* keys_sorted, int images, int stride, int pixels, int anchors_per_pixel, int k,
+                       const float* head, const float* anchors, float clip_h, float clip_w, float min_size, float* boxes, float* scores,
+                       int32_t* counts, int levels, int level);
+int rfi_op_proposals_select(rfi_ctx* ctx, const float* boxes, const float* scores, const uint8_t* keep, int images, int levels, int k,
+                            int post_nms, const float* gt_boxes, int gt_max, const int32_t* gt_count, int pmax, float* props,
+                            int32_t* pcount);
+int rfi_op_roi_sample(rfi_ctx* ctx, const int8_t* labels, const int32_t* pcount, int images, int pmax, int batch, int max_pos,
+                      uint64_t seed, uint32_t step, uint32_t stream0, int32_t* sel, int32_t* nsel, int32_t* npos);
+int rfi_op_roi_compact(rfi_ctx* ctx, const int32_t* sel, const int32_t* nsel, const int32_t* npos, int images, int batch, int pmax,
+                       const float* props, const int32_t* matched, const float* targets, const int32_t* gt_labels, int gt_max,
+                       const int32_t* gt_base, float t1, float t2, float t3, float* rois, int32_t* cls, float* tgt, int32_t* gt,
+                       int32_t* level, int32_t* img_start, float* rois_fg, float* rois_gt, int32_t* level_fg, int32_t* fg_start,
+                       int32_t* counts);
+int rfi_op_roi_align_ml(rfi_ctx* ctx, const float* const* maps_host, int n, int h0, int w0, int c, float scale0, const float* rois,
+                        const int32_t* level, const int32_t* count_dev, int max_rois, int ph, int pw, int sampling_ratio, float* out);
+int rfi_op_roi_align_ml_backward(rfi_ctx* ctx, float* const* dmaps_host, int n, int h0, int w0, int c, float scale0, const float* dout,
+                                 const float* rois, const int32_t* level, const int32_t* img_start, int max_rois, int ph, int pw,
+                                 int sampling_ratio);
+int rfi_readback_begin(rfi_ctx* ctx, const void* src_dev, size_t bytes);
+int rfi_readback_end(rfi_ctx* ctx, void* dst_host, size_t bytes);
 int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out);
 int rfi_op_fpn_merge_backward(rfi_ctx* ctx, const float* dout, int n, int h, int w, int c, float* dtop);
 int rfi_op_bn_stats(rfi_ctx* ctx, const float* y, int64_t m, int c, float* mean, float* var_biased);

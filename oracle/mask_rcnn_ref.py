@@ -16,8 +16,10 @@ pieces the other oracle files hold:
     level k = clip(floor(4 + log2(sqrt(area) / (size / 2))), 2, 5);  RoIAlign 7 x 7 -> BoxHeadModule -> Fast R-CNN losses
     foreground RoIs: RoIAlign 14 x 14 -> MaskHeadModule -> BCE against the matched instance mask RoIAligned to 28 x 28 (>= 0.5)
 
-everything in float32 torch / NumPy on the CPU, autograd for the gradients.  The random samplers draw from a NumPy
-``Generator`` in a fixed order (per image: positives, then negatives), so the step is a function of (weights, batch, seed).
+everything in float32 torch / NumPy on the CPU, autograd for the gradients.  The random samplers are COUNTER BASED (round 4:
+the device step samples in HBM, rfi_toolbox_amd/csrc/detect_sample.hip): candidate i of image b draws
+r = Philox4x32-10(counter (i, b, stream, step), key seed).x and a class keeps its candidates of smallest (r, i); streams 0 / 1
+= RPN positives / negatives, 2 / 3 = RoI foreground / background.  The step is a function of (weights, batch, seed, step).
 ``decisions`` replays the discrete choices of another run (labels, proposals, RoIs) so that continuous quantities can be
 compared even where a threshold decision differs in the last bit.
 """
@@ -28,8 +30,20 @@ import torch
 import torch.nn.functional as F
 
 from . import backbone_ref, detection_ref, mask_head_ref
+from .synth_ref import philox4x32_10
 
 STRIDES = (4, 8, 16, 32, 64)
+
+
+def sample_order(idx, image, stream, seed, step):
+    """The candidates ``idx`` of one class of image ``image`` in the order the counter-based sampler prefers them: ascending
+    (Philox word, index)."""
+    idx = np.asarray(idx, np.int64)
+    if len(idx) == 0:
+        return idx
+    r = philox4x32_10(idx, np.full(len(idx), image), np.full(len(idx), stream), np.full(len(idx), step), int(seed) & 0xFFFFFFFF,
+                      (int(seed) >> 32) & 0xFFFFFFFF)[0].astype(np.uint64)
+    return idx[np.lexsort((idx, r))]
 
 
 def level_anchors(h, w, stride, size):
@@ -44,10 +58,18 @@ def level_anchors(h, w, stride, size):
     return out.reshape(-1, 4)
 
 
+def level_thresholds(size):
+    """Areas (float32) at which a box moves up a pyramid level: k = clip(floor(4 + log2(sqrt(area) / (size / 2))), 2, 5) written
+    as comparisons (exact in float32 on any device: no log2, no sqrt)."""
+    half = np.float32(size) / np.float32(2.0)
+    return tuple(np.float32(c * half) * np.float32(c * half) for c in (0.5, 1.0, 2.0))
+
+
 def roi_levels(boxes, size):
-    area = np.maximum((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), 1e-6)
-    k = np.floor(4 + np.log2(np.sqrt(area) / (size / 2.0) + 1e-9))
-    return np.clip(k, 2, 5).astype(int) - 2
+    boxes = np.asarray(boxes, np.float32)
+    area = np.maximum((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), np.float32(1e-6))
+    t1, t2, t3 = level_thresholds(size)
+    return (area >= t1).astype(int) + (area >= t2).astype(int) + (area >= t3).astype(int)                # index into P2..P5
 
 
 def roi_align_torch(feat, rois, scale, res, sampling_ratio=2):
@@ -112,7 +134,8 @@ class MaskRCNNRef:
         return self
 
     # ---- the discrete parts
-    def rpn_targets(self, all_anchors, targets, rng):
+    def rpn_targets(self, all_anchors, targets, sampler):
+        seed, step = sampler
         n = len(targets)
         labels = np.empty((n, len(all_anchors)), np.int8)
         tgts = np.empty((n, len(all_anchors), 4), np.float32)
@@ -121,8 +144,8 @@ class MaskRCNNRef:
             lab = lab.astype(np.int8)
             pos, neg = np.flatnonzero(lab == 1), np.flatnonzero(lab == 0)
             npos = min(len(pos), self.rpn_batch // 2)
-            lab[rng.permutation(pos)[npos:]] = -1
-            lab[rng.permutation(neg)[self.rpn_batch - npos:]] = -1
+            lab[sample_order(pos, i, 0, seed, step)[npos:]] = -1
+            lab[sample_order(neg, i, 1, seed, step)[self.rpn_batch - npos:]] = -1
             labels[i], tgts[i] = lab, tg
         return labels, tgts
 
@@ -146,14 +169,15 @@ class MaskRCNNRef:
             props.append(b.astype(np.float32))
         return props
 
-    def sample_rois(self, props, targets, rng):
+    def sample_rois(self, props, targets, sampler):
+        seed, step = sampler
         rois, rlab, rtgt, rgt = [], [], [], []
         for i, p in enumerate(props):
             g = np.asarray(targets[i]["boxes"], np.float32).reshape(-1, 4)
             lab, midx, tg = detection_ref.anchor_match(p, g, 0.5, 0.5, False)
             pos, neg = np.flatnonzero(lab == 1), np.flatnonzero(lab == 0)
             npos = min(len(pos), self.roi_batch // 4)
-            pos, neg = rng.permutation(pos)[:npos], rng.permutation(neg)[:self.roi_batch - npos]
+            pos, neg = sample_order(pos, i, 2, seed, step)[:npos], sample_order(neg, i, 3, seed, step)[:self.roi_batch - npos]
             keep = np.concatenate([pos, neg])
             cls = np.zeros(len(keep), np.int32)
             cls[:npos] = np.asarray(targets[i]["labels"], np.int32).reshape(-1)[midx[pos]]
@@ -163,7 +187,8 @@ class MaskRCNNRef:
         return rois, rlab, rtgt, rgt
 
     # ---- the step: losses, gradient norms of the four parameter sets, the decisions taken
-    def step(self, images_nhwc, targets, rng=None, decisions=None, grads=True):
+    def step(self, images_nhwc, targets, sampler=None, decisions=None, grads=True):
+        """sampler = (seed, step) of the counter-based samplers (needed unless ``decisions`` replays every discrete choice)."""
         x = torch.as_tensor(np.asarray(images_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
         n, _, h, w = x.shape
         dec = decisions or {}
@@ -175,7 +200,7 @@ class MaskRCNNRef:
         if "rpn_labels" in dec:
             labels, tgts = np.asarray(dec["rpn_labels"]), np.asarray(dec["rpn_targets"], np.float32)
         else:
-            labels, tgts = self.rpn_targets(all_anchors, targets, rng)
+            labels, tgts = self.rpn_targets(all_anchors, targets, sampler)
         n_sampled = max(int((labels >= 0).sum()), 1)
         l_obj, l_box, off, rpn_out = 0.0, 0.0, 0, []
         for lvl, f in enumerate(feats):
@@ -198,7 +223,7 @@ class MaskRCNNRef:
             rois, rlab, rtgt, rgt = (np.asarray(dec[k]) for k in ("rois", "roi_labels", "roi_targets", "roi_gt"))
             rois, rtgt = rois.astype(np.float32), rtgt.astype(np.float32)
         else:
-            rois, rlab, rtgt, rgt = self.sample_rois(props, targets, rng)
+            rois, rlab, rtgt, rgt = self.sample_rois(props, targets, sampler)
         lv = roi_levels(rois[:, 1:], max(h, w))
 
         def pooled(sel, res):

@@ -120,6 +120,22 @@ _PROTOS = {
     "rfi_op_anchor_match": (_i, [_vp, _vp, _i64, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
     "rfi_op_rpn_loss_dev": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _f, _vp, _vp, _vp]),
     "rfi_op_rpn_loss_ws_bytes": (_sz, []),
+    "rfi_op_rpn_loss_devcount": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "rfi_op_fastrcnn_loss_dev": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "rfi_op_anchor_match_batched_ws": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _vp, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "rfi_op_segsort_u64": (_i, [_vp, _vp, _i, _i]),
+    "rfi_op_sample_keys": (_i, [_vp, _vp, _i, _i, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, _i]),
+    "rfi_op_rpn_sample_apply": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "rfi_op_topk_keys": (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
+    "rfi_op_topk_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _i, _i]),
+    "rfi_op_proposals_select": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "rfi_op_roi_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_uint64, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "rfi_op_roi_compact": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp]),
+    "rfi_op_roi_align_ml": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rfi_op_roi_align_ml_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "rfi_readback_begin": (_i, [_vp, _vp, _sz]),
+    "rfi_readback_end": (_i, [_vp, _vp, _sz]),
     "rfi_op_rpn_loss": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _f, _vp, _pf, _pf]),
     "rfi_op_fpn_merge_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rfi_comm_allreduce_sum_f32": (_i, [_vp, _vp, _i64]),

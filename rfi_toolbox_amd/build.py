@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 SOURCES = ["api.cpp", "model.cpp", "model_cnn.cpp", "model_planes.cpp", "model_resnet.cpp", "model_mask.cpp", "model_backbone.cpp", "model_mlp.cpp", "elem_kernels.hip", "conv_direct.hip", "conv_mfma.hip",
-           "wgrad_mfma.hip", "preprocess.hip", "synth.hip", "order_stats.hip", "planes_elem.hip", "conv_planes.hip", "conv_ws.hip", "conv_stem.hip", "gemm_ws.hip", "wgrad_ws.hip", "wgrad_stem.hip", "wgrad_planes.hip", "wgrad_split.hip", "detect_kernels.hip", "rpn_kernels.hip", "resnet_kernels.hip"]
+           "wgrad_mfma.hip", "preprocess.hip", "synth.hip", "order_stats.hip", "planes_elem.hip", "conv_planes.hip", "conv_ws.hip", "conv_stem.hip", "gemm_ws.hip", "wgrad_ws.hip", "wgrad_stem.hip", "wgrad_planes.hip", "wgrad_split.hip", "detect_kernels.hip", "detect_sample.hip", "rpn_kernels.hip", "resnet_kernels.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "model.hpp", "planes.hpp", "ws_common.hpp", os.path.join(ROOT, "include", "rfi_hip.h")]
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

@@ -125,6 +125,7 @@ int rfi_ctx_destroy(rfi_ctx* ctx) {
         for (auto e : ctx->event_pool) hipEventDestroy(e);
         for (auto& kv : ctx->allocs) hipFree(kv.first);
         if (ctx->pinned) hipHostFree(ctx->pinned);
+        if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
         hipEventDestroy(ctx->t0);
         hipEventDestroy(ctx->t1);
         hipStreamSynchronize(ctx->side_stream);
@@ -1879,6 +1880,140 @@ int rfi_op_rpn_loss_dev(rfi_ctx* ctx, const float* head, int64_t pixels, int anc
     });
 }
 size_t rfi_op_rpn_loss_ws_bytes(void) { return rpn_loss_ws_doubles() * sizeof(double); }
+// ---- the detector's box bookkeeping on the device (detect_sample.hip): nothing here synchronises or allocates
+int rfi_op_rpn_loss_devcount(rfi_ctx* ctx, const float* head, int64_t pixels, int anchors_per_pixel, const int8_t* labels,
+                             const float* targets, const int32_t* num_sampled_dev, float beta, float* dhead, void* workspace,
+                             float* loss2_dev) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(workspace && loss2_dev && num_sampled_dev, "rpn_loss_devcount: workspace, a 2-float device output and the device count");
+        launch_rpn_loss(ctx, head, pixels, anchors_per_pixel, reinterpret_cast<const signed char*>(labels), targets, 1, beta, dhead,
+                        static_cast<double*>(workspace), loss2_dev, num_sampled_dev);
+    });
+}
+int rfi_op_fastrcnn_loss_dev(rfi_ctx* ctx, const float* head, int64_t rois, int num_classes, const int32_t* labels, const float* targets,
+                             float beta, float* dhead, void* workspace, float* loss2_dev) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(workspace && loss2_dev, "fastrcnn_loss_dev: workspace (rfi_op_rpn_loss_ws_bytes) and a 2-float device output");
+        launch_fastrcnn_loss(ctx, head, rois, num_classes, labels, targets, beta, dhead, static_cast<double*>(workspace), loss2_dev);
+    });
+}
+int rfi_op_anchor_match_batched_ws(rfi_ctx* ctx, const float* anchors, int64_t n, int64_t anchor_stride, const int32_t* anchor_count,
+                                   const float* gt_boxes, int images, int gt_max, const int32_t* gt_count, float fg_iou, float bg_iou,
+                                   int allow_low_quality, float* best_ws, int8_t* labels, int32_t* matched, float* targets) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(best_ws, "anchor_match_batched_ws: workspace of images x gt_max floats");
+        launch_anchor_match_batched(ctx, anchors, n, anchor_stride, anchor_count, gt_boxes, images, gt_max, gt_count, fg_iou, bg_iou,
+                                    allow_low_quality != 0, best_ws, reinterpret_cast<signed char*>(labels), matched, targets);
+    });
+}
+int rfi_op_segsort_u64(rfi_ctx* ctx, uint64_t* keys, int n_segs, int stride) {
+    return guarded([&] {
+        ctx->activate();
+        launch_segsort_u64(ctx, reinterpret_cast<unsigned long long*>(keys), n_segs, stride);
+    });
+}
+int rfi_op_sample_keys(rfi_ctx* ctx, const int8_t* labels, int images, int n, const int32_t* count, uint64_t seed, uint32_t step,
+                       uint32_t stream0, uint64_t* keys, int stride) {
+    return guarded([&] {
+        ctx->activate();
+        launch_sample_keys(ctx, reinterpret_cast<const signed char*>(labels), images, n, count, seed, step, stream0,
+                           reinterpret_cast<unsigned long long*>(keys), stride);
+    });
+}
+int rfi_op_rpn_sample_apply(rfi_ctx* ctx, const uint64_t* keys_sorted, int images, int n, int stride, int batch, int max_pos,
+                            const int8_t* labels, const float* targets, int levels, const int32_t* level_off_host,
+                            int8_t* const* level_labels_host, float* const* level_targets_host, int32_t* n_sampled) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(level_off_host && level_labels_host && level_targets_host && n_sampled, "rpn_sample_apply: null table");
+        launch_rpn_sample_apply(ctx, reinterpret_cast<const unsigned long long*>(keys_sorted), images, n, stride, batch, max_pos,
+                                reinterpret_cast<const signed char*>(labels), targets, levels, level_off_host,
+                                reinterpret_cast<signed char* const*>(level_labels_host), level_targets_host, n_sampled);
+    });
+}
+int rfi_op_topk_keys(rfi_ctx* ctx, const float* head, int images, int pixels, int anchors_per_pixel, uint64_t* keys, int stride) {
+    return guarded([&] {
+        ctx->activate();
+        launch_topk_keys(ctx, head, images, pixels, anchors_per_pixel, reinterpret_cast<unsigned long long*>(keys), stride);
+    });
+}
+int rfi_op_topk_decode(rfi_ctx* ctx, const uint64_t* keys_sorted, int images, int stride, int pixels, int anchors_per_pixel, int k,
+                       const float* head, const float* anchors, float clip_h, float clip_w, float min_size, float* boxes, float* scores,
+                       int32_t* counts, int levels, int level) {
+    return guarded([&] {
+        ctx->activate();
+        launch_topk_decode(ctx, reinterpret_cast<const unsigned long long*>(keys_sorted), images, stride, pixels, anchors_per_pixel, k, head,
+                           anchors, clip_h, clip_w, min_size, boxes, scores, counts, levels, level);
+    });
+}
+int rfi_op_proposals_select(rfi_ctx* ctx, const float* boxes, const float* scores, const uint8_t* keep, int images, int levels, int k,
+                            int post_nms, const float* gt_boxes, int gt_max, const int32_t* gt_count, int pmax, float* props,
+                            int32_t* pcount) {
+    return guarded([&] {
+        ctx->activate();
+        launch_proposals_select(ctx, boxes, scores, keep, images, levels, k, post_nms, gt_boxes, gt_max, gt_count, pmax, props, pcount);
+    });
+}
+int rfi_op_roi_sample(rfi_ctx* ctx, const int8_t* labels, const int32_t* pcount, int images, int pmax, int batch, int max_pos,
+                      uint64_t seed, uint32_t step, uint32_t stream0, int32_t* sel, int32_t* nsel, int32_t* npos) {
+    return guarded([&] {
+        ctx->activate();
+        launch_roi_sample(ctx, reinterpret_cast<const signed char*>(labels), pcount, images, pmax, batch, max_pos, seed, step, stream0, sel,
+                          nsel, npos);
+    });
+}
+int rfi_op_roi_compact(rfi_ctx* ctx, const int32_t* sel, const int32_t* nsel, const int32_t* npos, int images, int batch, int pmax,
+                       const float* props, const int32_t* matched, const float* targets, const int32_t* gt_labels, int gt_max,
+                       const int32_t* gt_base, float t1, float t2, float t3, float* rois, int32_t* cls, float* tgt, int32_t* gt,
+                       int32_t* level, int32_t* img_start, float* rois_fg, float* rois_gt, int32_t* level_fg, int32_t* fg_start,
+                       int32_t* counts) {
+    return guarded([&] {
+        ctx->activate();
+        launch_roi_compact(ctx, sel, nsel, npos, images, batch, pmax, props, matched, targets, gt_labels, gt_max, gt_base, t1, t2, t3, rois,
+                           cls, tgt, gt, level, img_start, rois_fg, rois_gt, level_fg, fg_start, counts);
+    });
+}
+int rfi_op_roi_align_ml(rfi_ctx* ctx, const float* const* maps_host, int n, int h0, int w0, int c, float scale0, const float* rois,
+                        const int32_t* level, const int32_t* count_dev, int max_rois, int ph, int pw, int sampling_ratio, float* out) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(maps_host && count_dev, "roi_align_ml: null table");
+        launch_roi_align_ml_fwd(ctx, maps_host, n, h0, w0, c, scale0, rois, level, count_dev, max_rois, ph, pw, sampling_ratio, out);
+    });
+}
+int rfi_op_roi_align_ml_backward(rfi_ctx* ctx, float* const* dmaps_host, int n, int h0, int w0, int c, float scale0, const float* dout,
+                                 const float* rois, const int32_t* level, const int32_t* img_start, int max_rois, int ph, int pw,
+                                 int sampling_ratio) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(dmaps_host && img_start, "roi_align_ml_backward: null table");
+        launch_roi_align_ml_bwd(ctx, dmaps_host, n, h0, w0, c, scale0, dout, rois, level, img_start, max_rois, ph, pw, sampling_ratio);
+    });
+}
+// a small device -> host copy that does NOT stall the host at once: begin enqueues the copy into pinned memory and an event
+// behind it; whatever the caller enqueues next runs on; end waits for the event only (not for the later work)
+int rfi_readback_begin(rfi_ctx* ctx, const void* src_dev, size_t bytes) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(src_dev && bytes > 0 && bytes <= 2048, "readback_begin: 1 .. 2048 bytes");
+        if (!ctx->readback_ev) RFI_CHECK_HIP(hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming));
+        RFI_CHECK_HIP(hipMemcpyAsync(reinterpret_cast<char*>(ctx->pinned) + 2048, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        RFI_CHECK_HIP(hipEventRecord(ctx->readback_ev, ctx->stream));
+        ctx->readback_bytes = bytes;
+    });
+}
+int rfi_readback_end(rfi_ctx* ctx, void* dst_host, size_t bytes) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(ctx->readback_ev && dst_host && bytes == ctx->readback_bytes, "readback_end: no matching readback_begin");
+        RFI_CHECK_HIP(hipEventSynchronize(ctx->readback_ev));
+        std::memcpy(dst_host, reinterpret_cast<char*>(ctx->pinned) + 2048, bytes);
+        ctx->readback_bytes = 0;
+    });
+}
 int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out) {
     return guarded([&] {
         ctx->activate();

@@ -100,6 +100,8 @@ struct rfi_ctx {
     std::vector<hipEvent_t> event_pool;
     // pinned scratch for small D2H readbacks
     float* pinned = nullptr;
+    hipEvent_t readback_ev = nullptr;        // rfi_readback_begin / _end: the upper half of `pinned` + this event
+    size_t readback_bytes = 0;
     // grow-only device scratch (per-patch min/max words of the preprocessing kernels)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;

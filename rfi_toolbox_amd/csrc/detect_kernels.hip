@@ -270,6 +270,103 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     }
 }
 
+// ---- multi-level forms: every RoI reads (or sends its gradient to) the pyramid level `level[r]`; level k is an
+// [N][H >> k][W >> k][C] map with spatial scale scale0 / 2^k.  One launch for all levels: no sort of the RoIs by level, no
+// per-level slices, no host-side counts
+struct MlMaps { const float* x[4]; float* dx[4]; int H[4], W[4]; float scale[4]; };
+__global__ __launch_bounds__(256) void roi_align_ml_fwd_kernel(MlMaps m, int N, int C, const float* __restrict__ rois,
+                                                              const int* __restrict__ level, const int* __restrict__ count, int PH,
+                                                              int PW, int sr, float* __restrict__ out) {
+    const int C4 = C / 4, R = *count;
+    const int64_t total = (int64_t)R * PH * PW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        int64_t t = i / C4;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH);
+        const int r = (int)(t / PH);
+        const int k = level[r];
+        const int H = m.H[k], W = m.W[k];
+        const RoiGeom g = roi_geom(rois, r, m.scale[k], PH, PW, sr, false);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (g.n >= 0 && g.n < N) {
+            const float* xb = m.x[k] + (int64_t)g.n * H * W * C + c;
+            for (int iy = 0; iy < g.gh; ++iy) {
+                const float yy = g.y1 + ph * g.bh + (iy + 0.5f) * g.bh / g.gh;
+                for (int ix = 0; ix < g.gw; ++ix) {
+                    const float xx = g.x1 + pw * g.bw + (ix + 0.5f) * g.bw / g.gw;
+                    const Bilin b = bilin(yy, xx, H, W);
+                    if (!b.ok) continue;
+                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)b.y0 * W + b.x0) * C);
+                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)b.y0 * W + b.x1) * C);
+                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)b.y1 * W + b.x0) * C);
+                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)b.y1 * W + b.x1) * C);
+                    acc += v00 * b.w00 + v01 * b.w01 + v10 * b.w10 + v11 * b.w11;
+                }
+            }
+            acc = acc * (1.0f / (float)(g.gh * g.gw > 0 ? g.gh * g.gw : 1));
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+    }
+}
+// the gradient by gather (roi_align_bwd_gather_kernel's scheme): blockIdx.z = level, blockIdx.y = image; the RoIs of image n
+// are rows [img_start[n], img_start[n + 1]) and those of another level are skipped; the pixel's sum is ADDED to dx (the
+// level's gradient map already holds the other terms): one read-modify-write per element by its own thread, no atomics
+__global__ __launch_bounds__(256) void roi_align_ml_bwd_kernel(MlMaps m, int C, const float* __restrict__ dout, const float* __restrict__ rois,
+                                                              const int* __restrict__ level, const int* __restrict__ img_start, int PH, int PW,
+                                                              int sr) {
+    __shared__ RoiGeom sg[kGatherRois];
+    __shared__ int s_lvl[kGatherRois];
+    const int k = blockIdx.z, n = blockIdx.y, C4 = C / 4;
+    const int H = m.H[k], W = m.W[k];
+    const int lo = img_start[n], hi = img_start[n + 1];
+    const int64_t items = (int64_t)H * W * C4;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < items; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < items;
+        const int c = live ? (int)(i % C4) * 4 : 0;
+        const int px = live ? (int)((i / C4) % W) : 0, py = live ? (int)(i / ((int64_t)C4 * W)) : 0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int r0 = lo; r0 < hi; r0 += kGatherRois) {
+            const int cnt = min(kGatherRois, hi - r0);
+            __syncthreads();
+            if ((int)threadIdx.x < cnt) {
+                sg[threadIdx.x] = roi_geom(rois, r0 + threadIdx.x, m.scale[k], PH, PW, sr, false);
+                s_lvl[threadIdx.x] = level[r0 + threadIdx.x];
+            }
+            __syncthreads();
+            if (!live) continue;
+            for (int q = 0; q < cnt; ++q) {
+                if (s_lvl[q] != k) continue;
+                const RoiGeom g = sg[q];
+                int by0 = (int)floorf(((float)py - 1.0f - g.y1) / g.bh) - 1, by1 = (int)ceilf(((float)py + 1.0f - g.y1) / g.bh) + 1;
+                int bx0 = (int)floorf(((float)px - 1.0f - g.x1) / g.bw) - 1, bx1 = (int)ceilf(((float)px + 1.0f - g.x1) / g.bw) + 1;
+                if (py == 0) by0 = 0;
+                if (py == H - 1) by1 = PH - 1;
+                if (px == 0) bx0 = 0;
+                if (px == W - 1) bx1 = PW - 1;
+                by0 = max(by0, 0); by1 = min(by1, PH - 1); bx0 = max(bx0, 0); bx1 = min(bx1, PW - 1);
+                const float inv = 1.0f / (float)(g.gh * g.gw > 0 ? g.gh * g.gw : 1);
+                const float* dr = dout + ((int64_t)(r0 + q) * PH * PW) * C + c;
+                for (int by = by0; by <= by1; ++by) {
+                    const float wy = bin_weight(g.y1, g.bh, by, g.gh, py, H);
+                    if (wy == 0.0f) continue;
+                    for (int bx = bx0; bx <= bx1; ++bx) {
+                        const float wx = bin_weight(g.x1, g.bw, bx, g.gw, px, W);
+                        if (wx == 0.0f) continue;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(dr + ((int64_t)by * PW + bx) * C);
+                        acc += v * (wy * wx * inv);
+                    }
+                }
+            }
+        }
+        if (live) {
+            f32x4* d = reinterpret_cast<f32x4*>(m.dx[k] + (((int64_t)n * H + py) * W + px) * C + c);
+            *d = *d + acc;
+        }
+    }
+}
+
 // FPN top-down pathway: out = lateral + nearest-neighbour 2x upsampling of the coarser level
 __global__ __launch_bounds__(256) void fpn_merge_fwd_kernel(const float* __restrict__ lateral, const float* __restrict__ top,
                                                            int N, int H, int W, int C, float* __restrict__ out) {
@@ -352,6 +449,36 @@ void launch_roi_align_bwd(rfi_ctx* ctx, const float* dout, int N, int H, int W, 
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(grid_of((int64_t)R * PH * PW * C)), dim3(256), 0, ctx->stream, dout, N, H, W, C,
                        rois, R, scale, PH, PW, sampling_ratio, aligned ? 1 : 0, dx);
     check_launch("roi_align_bwd");
+}
+static MlMaps ml_maps(const float* const* x, float* const* dx, int H0, int W0, float scale0) {
+    MlMaps m{};
+    for (int k = 0; k < 4; ++k) {
+        m.x[k] = x ? x[k] : nullptr;
+        m.dx[k] = dx ? dx[k] : nullptr;
+        m.H[k] = H0 >> k;
+        m.W[k] = W0 >> k;
+        m.scale[k] = scale0 / (float)(1 << k);
+    }
+    return m;
+}
+// rows beyond *count_dev (the RoI count lives on the device) are not written; max_rois sizes the grid
+void launch_roi_align_ml_fwd(rfi_ctx* ctx, const float* const* maps, int N, int H0, int W0, int C, float scale0, const float* rois,
+                             const int* level, const int* count_dev, int max_rois, int PH, int PW, int sr, float* out) {
+    RFI_REQUIRE(C % 4 == 0 && N > 0 && (H0 >> 3) > 0 && (W0 >> 3) > 0 && PH > 0 && PW > 0 && max_rois > 0, "roi_align_ml: C % 4 == 0, four levels, positive sizes");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)max_rois * PH * PW * C * 4 * 5);
+    hipLaunchKernelGGL(roi_align_ml_fwd_kernel, dim3(grid_of((int64_t)max_rois * PH * PW * C / 4)), dim3(256), 0, ctx->stream,
+                       ml_maps(maps, nullptr, H0, W0, scale0), N, C, rois, level, count_dev, PH, PW, sr, out);
+    check_launch("roi_align_ml_fwd");
+}
+void launch_roi_align_ml_bwd(rfi_ctx* ctx, float* const* dmaps, int N, int H0, int W0, int C, float scale0, const float* dout,
+                             const float* rois, const int* level, const int* img_start, int max_rois, int PH, int PW, int sr) {
+    RFI_REQUIRE(C % 4 == 0 && N > 0 && (H0 >> 3) > 0 && (W0 >> 3) > 0 && PH > 0 && PW > 0, "roi_align_ml_backward: C % 4 == 0, four levels, positive sizes");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)max_rois * PH * PW * C * 4 * 4 + (double)N * H0 * W0 * C * 8 * 1.33);
+    const int64_t items = (int64_t)H0 * W0 * (C / 4);
+    int bx = (int)std::min<int64_t>(cdiv(items, 256), 1024);
+    hipLaunchKernelGGL(roi_align_ml_bwd_kernel, dim3(bx, N, 4), dim3(256), 0, ctx->stream, ml_maps(nullptr, dmaps, H0, W0, scale0), C, dout,
+                       rois, level, img_start, PH, PW, sr);
+    check_launch("roi_align_ml_bwd");
 }
 void launch_fpn_merge_fwd(rfi_ctx* ctx, const float* lateral, const float* top, int N, int H, int W, int C, float* out) {
     RFI_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0, "fpn_merge: C % 4 == 0 and positive sizes");

@@ -361,7 +361,47 @@ size_t rpn_loss_ws_doubles();
 void launch_fastrcnn_loss(rfi_ctx* ctx, const float* head, int64_t R, int K1, const int* labels, const float* targets, float beta,
                           float* dhead, double* partial_ws, float* loss2_dev);
 void launch_rpn_loss(rfi_ctx* ctx, const float* head, int64_t P, int A, const signed char* labels, const float* targets,
-                     int64_t num_sampled, float beta, float* dhead, double* partial_ws, float* loss2_dev);
+                     int64_t num_sampled, float beta, float* dhead, double* partial_ws, float* loss2_dev,
+                     const int* num_sampled_dev = nullptr);      // num_sampled_dev != null: the normaliser is read from the device
+
+// ---------------------------------------------------------------- the detector's box bookkeeping on the device (detect_sample.hip)
+// keys: 64-bit, one segment of `stride` (a power of two <= 8192) keys per workgroup, sorted ascending in place
+void launch_segsort_u64(rfi_ctx* ctx, unsigned long long* keys, int n_segs, int stride);
+// sampler keys of labels [B][n] (1 positive, 0 negative, else neither): class << 48 | Philox(seed; i, b, stream, step) << 16 | i;
+// entries beyond count[b] (null: n) or n get the largest key
+void launch_sample_keys(rfi_ctx* ctx, const signed char* labels, int B, int n, const int* count, unsigned long long seed, unsigned step,
+                        unsigned stream0, unsigned long long* keys, int stride);
+// RPN sampler on the SORTED keys: `batch` anchors per image with at most max_pos positives keep their label, the rest of the
+// labels >= 0 become -1; labels / targets are written per pyramid level ([images][anchors of the level]); *n_sampled += count
+void launch_rpn_sample_apply(rfi_ctx* ctx, const unsigned long long* keys_sorted, int B, int n, int stride, int batch, int max_pos,
+                             const signed char* labels, const float* targets, int L, const int* level_off, signed char* const* level_labels,
+                             float* const* level_targets, int* n_sampled);
+// top-k of the objectness logits of one pyramid level: keys of head [B][P][5 A] (descending score, ties by anchor index) ...
+void launch_topk_keys(rfi_ctx* ctx, const float* head, int B, int P, int A, unsigned long long* keys, int stride);
+// ... and, from the sorted keys, the K best decoded + clipped into slot `lvl` of boxes [B][L][K][4] / scores [B][L][K] (boxes
+// under min_size moved behind the others, score -inf) with counts [B][L] of the boxes that remain
+void launch_topk_decode(rfi_ctx* ctx, const unsigned long long* keys_sorted, int B, int stride, int P, int A, int K, const float* head,
+                        const float* anchors, float clip_h, float clip_w, float min_size, float* boxes, float* scores, int* counts, int L,
+                        int lvl);
+// per image: the post_nms best kept boxes of its L x K candidates, then its ground-truth boxes -> props [B][Pmax][4], pcount [B]
+void launch_proposals_select(rfi_ctx* ctx, const float* boxes, const float* scores, const unsigned char* keep, int B, int L, int K,
+                             int post_nms, const float* gt, int Gmax, const int* gt_count, int Pmax, float* props, int* pcount);
+// RoI sampler: `batch` proposals per image with at most max_pos foreground -> sel [B][batch] (positives first), nsel / npos [B]
+void launch_roi_sample(rfi_ctx* ctx, const signed char* labels, const int* pcount, int B, int Pmax, int batch, int max_pos,
+                       unsigned long long seed, unsigned step, unsigned stream0, int* sel, int* nsel, int* npos);
+// the sampled RoIs of the batch, image-major and compact, with class labels, targets, matched instance, pyramid level
+// (0 + [area >= t1] + [area >= t2] + [area >= t3]), the foreground rows again for the mask branch, counts = (R, Rf)
+void launch_roi_compact(rfi_ctx* ctx, const int* sel, const int* nsel, const int* npos, int B, int batch, int Pmax, const float* props,
+                        const int* matched, const float* targets, const int* gt_labels, int Gmax, const int* gbase, float t1, float t2,
+                        float t3, float* rois, int* cls, float* tgt, int* gt, int* level, int* img_start, float* rois_fg, float* rois_gt,
+                        int* level_fg, int* fg_start, int* counts);
+// multi-level RoIAlign: RoI r reads level[r] of maps[4] ([N][H0 >> k][W0 >> k][C], spatial scale scale0 / 2^k); the RoI count is
+// read from the device (rows beyond it are not written); backward: ADDS every level's gradient into dmaps[k] (gather form:
+// the RoIs of image n are rows [img_start[n], img_start[n + 1]))
+void launch_roi_align_ml_fwd(rfi_ctx* ctx, const float* const* maps, int N, int H0, int W0, int C, float scale0, const float* rois,
+                             const int* level, const int* count_dev, int max_rois, int PH, int PW, int sr, float* out);
+void launch_roi_align_ml_bwd(rfi_ctx* ctx, float* const* dmaps, int N, int H0, int W0, int C, float scale0, const float* dout,
+                             const float* rois, const int* level, const int* img_start, int max_rois, int PH, int PW, int sr);
 
 // ---------------------------------------------------------------- ResNet-style encoder pieces (resnet_kernels.hip)
 void launch_s2d(rfi_ctx* ctx, const float* x, int N, int H, int W, int C, float* out);          // [N,H,W,C] -> [N,H/2,W/2,4C]

@@ -60,9 +60,10 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 // [block][2] = (sum BCE over sampled, sum smooth-L1 over positives), both terms scaled by inv_count.
 __global__ __launch_bounds__(kB) void rpn_loss_kernel(const float* __restrict__ head, int64_t P, int A,
                                                      const signed char* __restrict__ labels, const float* __restrict__ targets,
-                                                     float inv_count, float beta, float* __restrict__ dhead,
-                                                     double* __restrict__ partial) {
+                                                     float inv_count, const int* __restrict__ count_dev, float beta,
+                                                     float* __restrict__ dhead, double* __restrict__ partial) {
     __shared__ double red[2][kB];
+    if (count_dev) inv_count = 1.0f / (float)max(*count_dev, 1);         // the normaliser lives on the device (the sampler's count)
     double s_obj = 0.0, s_box = 0.0;
     const int64_t total = P * A;
     const int ps = 5 * A;
@@ -109,8 +110,10 @@ __global__ __launch_bounds__(kB) void rpn_loss_kernel(const float* __restrict__ 
         partial[blockIdx.x * 2 + 1] = red[1][0];
     }
 }
-__global__ void rpn_loss_finish_kernel(const double* __restrict__ partial, int blocks, double inv_count, float* __restrict__ out2) {
+__global__ void rpn_loss_finish_kernel(const double* __restrict__ partial, int blocks, double inv_count, float* __restrict__ out2,
+                                       const int* __restrict__ count_dev = nullptr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (count_dev) inv_count = (double)(1.0f / (float)max(*count_dev, 1));
         double a = 0.0, b = 0.0;
         for (int i = 0; i < blocks; ++i) { a += partial[i * 2]; b += partial[i * 2 + 1]; }     // fixed order
         out2[0] = (float)(a * inv_count);
@@ -379,7 +382,8 @@ void launch_fastrcnn_loss(rfi_ctx* ctx, const float* head, int64_t R, int K1, co
     hipLaunchKernelGGL(fastrcnn_loss_kernel, dim3((unsigned)blocks), dim3(kB), 0, ctx->stream, head, R, K1, labels, targets, inv, beta,
                        dhead, partial_ws);
     check_launch("fastrcnn_loss");
-    hipLaunchKernelGGL(rpn_loss_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial_ws, (int)blocks, (double)inv, loss2_dev);
+    hipLaunchKernelGGL(rpn_loss_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial_ws, (int)blocks, (double)inv, loss2_dev,
+                       (const int*)nullptr);
     check_launch("fastrcnn_loss_finish");
 }
 
@@ -404,7 +408,7 @@ void launch_nms_mask(rfi_ctx* ctx, const float* boxes, int n, float thr, unsigne
 }
 size_t rpn_loss_ws_doubles() { return 2 * 1024; }
 void launch_rpn_loss(rfi_ctx* ctx, const float* head, int64_t P, int A, const signed char* labels, const float* targets,
-                     int64_t num_sampled, float beta, float* dhead, double* partial_ws, float* loss2_dev) {
+                     int64_t num_sampled, float beta, float* dhead, double* partial_ws, float* loss2_dev, const int* num_sampled_dev) {
     RFI_REQUIRE(P > 0 && A > 0 && A % 4 == 0, "rpn_loss: P > 0 and anchors per pixel a multiple of 4 (16-byte aligned delta groups)");
     RFI_REQUIRE(!((reinterpret_cast<uintptr_t>(head) | reinterpret_cast<uintptr_t>(targets) | reinterpret_cast<uintptr_t>(dhead)) & 15),
                 "rpn_loss: 16-byte aligned tensors");
@@ -412,10 +416,11 @@ void launch_rpn_loss(rfi_ctx* ctx, const float* head, int64_t P, int A, const si
     int64_t blocks = cdiv(P * A, kB);
     if (blocks > 1024) blocks = 1024;
     ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)P * A * (5 * 8 + 17));
-    hipLaunchKernelGGL(rpn_loss_kernel, dim3((unsigned)blocks), dim3(kB), 0, ctx->stream, head, P, A, labels, targets, inv, beta, dhead,
-                       partial_ws);
+    hipLaunchKernelGGL(rpn_loss_kernel, dim3((unsigned)blocks), dim3(kB), 0, ctx->stream, head, P, A, labels, targets, inv, num_sampled_dev,
+                       beta, dhead, partial_ws);
     check_launch("rpn_loss");
-    hipLaunchKernelGGL(rpn_loss_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial_ws, (int)blocks, (double)inv, loss2_dev);
+    hipLaunchKernelGGL(rpn_loss_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, partial_ws, (int)blocks, (double)inv, loss2_dev,
+                       num_sampled_dev);
     check_launch("rpn_loss_finish");
 }
 

@@ -4,12 +4,15 @@ Not in the reference (it contains no detector; torchvision is absent): a builder
 pipeline (He et al. 2017) from the models and kernels of this package -- ``ResNet50FPN`` backbone, one ``RPNHead`` shared by
 the five pyramid levels (``accumulate_gradients``), ``anchor_match`` / ``rpn_loss`` / ``decode_boxes`` / ``nms``,
 multi-level ``roi_align``, ``BoxHead`` with ``fastrcnn_loss``, ``MaskHead``.  Every contraction, loss and gather runs on
-the GPU; this class is the host-side bookkeeping between them (anchor grids, the random samplers, level assignment, score
-thresholds, mask pasting).  ``train_step`` keeps every feature map, RoI feature, activation and gradient in HBM and calls
-the C-ABI on device pointers; what crosses to the host is the box bookkeeping (RPN head outputs for the top-k, labels of the
-batched matcher, the sampled index sets, five loss scalars).  ``predict`` is the plain host-array form.  Conventions where implementations differ: box-coder
-weights 1 in both stages, four anchors per pixel (aspect ratios 0.5, 1, 2 and a 1.5x square), level assignment
-``k = floor(k0 + log2(sqrt(area) / s0))`` with ``(k0, s0) = (4, image_size / 2)``.
+the GPU.  ``train_step`` keeps every feature map, RoI feature, activation and gradient in HBM AND does the box bookkeeping
+between the stages there too (round 4; ``csrc/detect_sample.hip``): the two samplers (counter-based: element i of image b
+draws Philox4x32-10(counter (i, b, stream, step), key seed) and a class keeps its smallest draws), the per-level top-k of the
+objectness scores, decode + clip, per-level NMS, the post-NMS selection, matching, the compact RoI lists and their pyramid
+levels, multi-level RoIAlign both ways in one launch each.  What crosses PCIe inside a step: the ground-truth boxes going up,
+two integers (RoI and foreground counts, read back under the RPN head's backward pass) and the loss scalars coming down.
+``predict`` is the plain host-array form.  Conventions where implementations differ: box-coder weights 1 in both stages,
+four anchors per pixel (aspect ratios 0.5, 1, 2 and a 1.5x square), level assignment
+``k = clip(floor(4 + log2(sqrt(area) / (image_size / 2))), 2, 5)`` evaluated as three area comparisons.
 
     det = MaskRCNN(num_classes=2)
     losses = det.train_step(images_nhwc, [{"boxes": (g, 4), "labels": (g,), "masks": (g, H, W)}, ...])
@@ -85,7 +88,9 @@ class MaskRCNN:
         self.rpn = RPNHead(fpn_channels, 4, 1, device=device)
         self.box = BoxHead(fpn_channels, 7, representation_size, num_classes, device=device)
         self.mask = MaskHead(fpn_channels, 1, 4, device=device)
-        self.rng = np.random.default_rng(seed)
+        self.seed = int(np.random.SeedSequence(seed).generate_state(2, np.uint32).view(np.uint64)[0]) if seed is None else int(seed)
+        self.sample_step = 0              # the samplers' step counter (advanced by train_step)
+        self.keep_trace = False           # train_step downloads its discrete decisions into last_trace (tests; costs a few syncs)
         self.pre_nms, self.post_nms, self.rpn_nms, self.rpn_batch, self.roi_batch = 200, 100, 0.7, 256, 128
         self.score_thresh, self.det_nms, self.max_det = 0.05, 0.5, 20
         self.grad_sync = 0                # data parallel over this many ranks (> 1): all-reduce (mean) of the four gradient sets
@@ -102,10 +107,18 @@ class MaskRCNN:
     def _anchors(self, h, w):
         return [_level_anchors(h // s, w // s, s, 2.0 * s) for s in _STRIDES]
 
+    @staticmethod
+    def _level_thresholds(size):
+        half = np.float32(size) / np.float32(2.0)
+        return tuple(float(np.float32(c * half) * np.float32(c * half)) for c in (0.5, 1.0, 2.0))
+
     def _levels(self, boxes, size):
-        area = np.maximum((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), 1e-6)
-        k = np.floor(4 + np.log2(np.sqrt(area) / (size / 2.0) + 1e-9))
-        return np.clip(k, 2, 5).astype(int) - 2                     # index into P2..P5
+        """Index into P2..P5: clip(floor(4 + log2(sqrt(area) / (size / 2))), 2, 5) - 2 as three comparisons of the float32
+        area (no log2 / sqrt whose last bit could differ between host and device)."""
+        boxes = np.asarray(boxes, np.float32)
+        area = np.maximum((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), np.float32(1e-6))
+        t1, t2, t3 = (np.float32(t) for t in self._level_thresholds(size))
+        return (area >= t1).astype(int) + (area >= t2).astype(int) + (area >= t3).astype(int)
 
     def _roi_align(self, feats, rois, out, size):
         """Multi-level RoIAlign: every RoI on its pyramid level; rois (R, 5) = (image, x1, y1, x2, y2)."""
@@ -205,30 +218,57 @@ class MaskRCNN:
                         "rfi_mask": masks.any(0) if len(masks) else np.zeros((h, w), bool)})
         return out
 
-    # ---- one optimisation step
-    # Every feature map, RoI feature, head activation and gradient stays in HBM (device buffers cached per input shape,
-    # C-ABI calls on device pointers); what crosses to the host is the small integer / box bookkeeping: RPN head outputs
-    # for top-k + NMS, anchor / RoI labels from the matcher, the sampled index sets, five loss scalars.
-    def _buffers(self, n, h, w):
+    # ---- one optimisation step: everything between the input batch and the loss scalars happens in HBM
+    def _buffers(self, n, h, w, gmax):
         key = (n, h, w)
-        if getattr(self, "_buf_key", None) == key:
-            return self._buf
+        b = getattr(self, "_buf", None)
+        if getattr(self, "_buf_key", None) == key and b.gcap >= gmax:
+            return b
         ctx, F = self.backbone.ctx, self.F
         b = type("Buffers", (), {})()
+        b.gcap = max(8, 2 * gmax)
         b.x = ctx.empty((n, h, w, self.backbone.in_channels), np.float32)
         shapes = [(n, h // s, w // s, F) for s in _STRIDES]
         b.shapes = shapes
         b.feats = [ctx.empty(sh, np.float32) for sh in shapes]
         b.dfe = [ctx.empty(sh, np.float32) for sh in shapes]
-        b.tmp = [ctx.empty(sh, np.float32) for sh in shapes[:4]]
         b.pf = (C.c_void_p * 5)(*[f.ptr for f in b.feats])
         b.pdf = (C.c_void_p * 5)(*[f.ptr for f in b.dfe])
+        b.pf4 = (C.c_void_p * 4)(*[f.ptr for f in b.feats[:4]])
+        b.pdf4 = (C.c_void_p * 4)(*[f.ptr for f in b.dfe[:4]])
         b.rpn_out = [ctx.empty((sh[0], sh[1], sh[2], 20), np.float32) for sh in shapes]
         b.rpn_dout = [ctx.empty((sh[0], sh[1], sh[2], 20), np.float32) for sh in shapes]
         b.rpn_lab = [ctx.empty((sh[0] * sh[1] * sh[2] * 4,), np.int8) for sh in shapes]
         b.rpn_tgt = [ctx.empty((sh[0] * sh[1] * sh[2] * 4, 4), np.float32) for sh in shapes]
+        b.p_lab = (C.c_void_p * 5)(*[a.ptr for a in b.rpn_lab])
+        b.p_tgt = (C.c_void_p * 5)(*[a.ptr for a in b.rpn_tgt])
+        # anchors of the five levels (one image), concatenated; the matcher's and the samplers' tensors
+        anchors = self._anchors(h, w)
+        b.acount = [len(a) for a in anchors]
+        b.aoff = np.concatenate([[0], np.cumsum(b.acount)]).astype(np.int32)
+        b.A = int(b.aoff[-1])
+        b.anchors = ctx.to_device(np.concatenate(anchors).astype(np.float32))
+        pow2 = lambda v: 1 << max(1, int(v - 1).bit_length())  # noqa: E731
+        b.gt, b.gt_count = ctx.empty((n, b.gcap, 4), np.float32), ctx.empty((n,), np.int32)
+        b.gt_labels, b.gt_base = ctx.empty((n, b.gcap), np.int32), ctx.empty((n,), np.int32)
+        b.best_ws = ctx.empty((n, b.gcap), np.float32)
+        b.m_lab, b.m_idx, b.m_tgt = ctx.empty((n, b.A), np.int8), ctx.empty((n, b.A), np.int32), ctx.empty((n, b.A, 4), np.float32)
+        b.stride_a = pow2(b.A)
+        b.keys_a = ctx.empty((n, b.stride_a), np.uint64)
+        b.n_sampled = ctx.empty((4,), np.int32)
+        b.stride_l = [max(2, pow2(c)) for c in b.acount]
+        b.keys_l = [ctx.empty((n, st), np.uint64) for st in b.stride_l]
+        K, L = self.pre_nms, 5
+        b.cand_boxes, b.cand_scores = ctx.empty((n, L, K, 4), np.float32), ctx.empty((n, L, K), np.float32)
+        b.cand_counts, b.keep = ctx.empty((n, L), np.int32), ctx.empty((n, L, K), np.uint8)
+        b.pmax = self.post_nms + b.gcap
+        b.props, b.pcount = ctx.empty((n, b.pmax, 4), np.float32), ctx.empty((n,), np.int32)
+        b.r_lab, b.r_idx, b.r_tgt = ctx.empty((n, b.pmax), np.int8), ctx.empty((n, b.pmax), np.int32), ctx.empty((n, b.pmax, 4), np.float32)
+        b.sel, b.nsel, b.npos = ctx.empty((n, self.roi_batch), np.int32), ctx.empty((n,), np.int32), ctx.empty((n,), np.int32)
         R, Rm = n * self.roi_batch, n * (self.roi_batch // 4)
         b.rois, b.rois_m, b.rois_g = ctx.empty((R, 5), np.float32), ctx.empty((Rm, 5), np.float32), ctx.empty((Rm, 5), np.float32)
+        b.roi_gt, b.roi_lvl, b.lvl_m = ctx.empty((R,), np.int32), ctx.empty((R,), np.int32), ctx.empty((Rm,), np.int32)
+        b.img_start, b.fg_start, b.counts = ctx.empty((n + 1,), np.int32), ctx.empty((n + 1,), np.int32), ctx.empty((4,), np.int32)
         b.roi7, b.roi7_grad = ctx.empty((R, 7, 7, F), np.float32), ctx.empty((R, 7, 7, F), np.float32)
         k1 = self.num_classes
         b.box_out, b.box_dout = ctx.empty((R, 5 * k1), np.float32), ctx.empty((R, 5 * k1), np.float32)
@@ -236,79 +276,12 @@ class MaskRCNN:
         b.roi14, b.roi14_grad = ctx.empty((Rm, 14, 14, F), np.float32), ctx.empty((Rm, 14, 14, F), np.float32)
         b.mask_t = ctx.empty((Rm, 28, 28), np.uint8)
         b.masks, b.masks_n, b.masks_of = None, 0, None
-        b.rpn_ws = [ctx.empty((int(lib.rfi_op_rpn_loss_ws_bytes()),), np.uint8) for _ in shapes]
-        b.rpn_loss2 = ctx.empty((len(shapes), 2), np.float32)
+        ws = int(lib.rfi_op_rpn_loss_ws_bytes())
+        b.rpn_ws = [ctx.empty((ws,), np.uint8) for _ in shapes]
+        b.box_ws = ctx.empty((ws,), np.uint8)
+        b.rpn_loss2, b.box_loss2 = ctx.empty((len(shapes), 2), np.float32), ctx.empty((2,), np.float32)
         self._buf_key, self._buf = key, b
         return b
-
-    def _rpn_match(self, all_anchors, targets):
-        """Matcher of the RPN targets (IoU 0.7 / 0.3, low-quality matches; one launch for the batch).
-        -> labels int8 (n, A) in {1, 0, -1}, regression targets (n, A, 4)."""
-        labels, _, tgts = ops.anchor_match_batched(all_anchors, [t["boxes"] for t in targets])
-        return labels, tgts
-
-    def _rpn_sample(self, labels):
-        """The random sampler on the matcher's labels (in place): rpn_batch anchors per image, at most half positive;
-        the others get -1 = not sampled."""
-        for i in range(len(labels)):
-            lab = labels[i]
-            pos, neg = np.flatnonzero(lab == 1), np.flatnonzero(lab == 0)
-            npos = min(len(pos), self.rpn_batch // 2)
-            lab[self.rng.permutation(pos)[npos:]] = -1
-            lab[self.rng.permutation(neg)[self.rpn_batch - npos:]] = -1
-        return labels
-
-    def _rpn_targets(self, all_anchors, targets):
-        labels, tgts = self._rpn_match(all_anchors, targets)
-        return self._rpn_sample(labels), tgts
-
-    def _roi_match(self, props, targets):
-        """Proposals (+ ground truth) against the ground truth at IoU 0.5 (one launch for the batch)."""
-        pmax = max(len(p) for p in props)
-        pb = np.zeros((len(props), pmax, 4), np.float32)
-        for i, p in enumerate(props):
-            pb[i, :len(p)] = p
-        return ops.anchor_match_batched(pb, [t["boxes"] for t in targets], 0.5, 0.5, False, anchor_counts=[len(p) for p in props])
-
-    def _roi_sample(self, props, targets, match):
-        """The RoI sampler: roi_batch per image with at most a quarter foreground.  -> rois (R, 5), class labels (R,),
-        regression targets (R, 4), matched ground-truth index (R,) (-1: background)."""
-        labs, midxs, tgs = match
-        rois, rlab, rtgt, rgt = [], [], [], []
-        for i, p in enumerate(props):
-            lab, midx, tg = labs[i, :len(p)], midxs[i, :len(p)], tgs[i, :len(p)]
-            pos, neg = np.flatnonzero(lab == 1), np.flatnonzero(lab == 0)
-            npos = min(len(pos), self.roi_batch // 4)
-            pos, neg = self.rng.permutation(pos)[:npos], self.rng.permutation(neg)[:self.roi_batch - npos]
-            keep = np.concatenate([pos, neg])
-            cls = np.zeros(len(keep), np.int32)
-            cls[:npos] = np.asarray(targets[i]["labels"], np.int32).reshape(-1)[midx[pos]]
-            rois.append(np.concatenate([np.full((len(keep), 1), i, np.float32), p[keep]], 1))
-            rlab.append(cls); rtgt.append(tg[keep]); rgt.append(np.where(np.arange(len(keep)) < npos, midx[keep], -1))
-        return np.concatenate(rois), np.concatenate(rlab), np.concatenate(rtgt).astype(np.float32), np.concatenate(rgt)
-
-    def _sample_rois(self, props, targets):
-        return self._roi_sample(props, targets, self._roi_match(props, targets))
-
-    def _roi_align_dev(self, b, rois_dev, lv, out_dev, res, backward=False, grad_dev=None):
-        """Multi-level RoIAlign on device buffers; the RoIs are SORTED by level, so level k is one contiguous slice of the
-        RoI list and of the output.  backward: RoI-feature gradients -> added to the level's feature gradient."""
-        ctx, F = self.backbone.ctx, self.F
-        off = 0
-        for k in range(4):
-            cnt = int((lv == k).sum())
-            if cnt:
-                n, hk, wk, _ = b.shapes[k]
-                rp = C.c_void_p(rois_dev.ptr + off * 20)
-                fp = C.c_void_p((grad_dev if backward else out_dev).ptr + off * res * res * F * 4)
-                if backward:          # (gather form: the level's RoIs are in image order -- the level sort is stable; no atomics)
-                    check(lib.rfi_op_roi_align_backward_sorted(ctx.handle, fp, n, hk, wk, F, rp, cnt, 1.0 / _STRIDES[k], res, res, 2, 0,
-                                                               C.c_void_p(b.tmp[k].ptr)))
-                    check(lib.rfi_op_add_inplace(ctx.handle, C.c_void_p(b.dfe[k].ptr), C.c_void_p(b.tmp[k].ptr), n * hk * wk * F))
-                else:
-                    check(lib.rfi_op_roi_align(ctx.handle, C.c_void_p(b.feats[k].ptr), n, hk, wk, F, rp, cnt, 1.0 / _STRIDES[k],
-                                               res, res, 2, 0, fp))
-            off += cnt
 
     def train_step(self, images, targets, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, masks_resident=False):
         """One training step.  masks_resident=True: the caller promises that `targets` (the SAME list object as in the
@@ -319,43 +292,70 @@ class MaskRCNN:
         x = images if dev_in else np.ascontiguousarray(np.asarray(images, np.float32))
         n, h, w, _ = x.shape
         ctx, F, k1 = self.backbone.ctx, self.F, self.num_classes
+        H = ctx.handle
         P = lambda d: C.c_void_p(d.ptr)  # noqa: E731
         for m in (self.rpn, self.box, self.mask):
             m.train()
-        b = self._buffers(n, h, w)
+        gts = [np.asarray(t["boxes"], np.float32).reshape(-1, 4) for t in targets]
+        gcount = np.asarray([len(g) for g in gts], np.int32)
+        b = self._buffers(n, h, w, int(gcount.max()) if n else 0)
         if dev_in:
             b.x_in = x
         else:
             b.x.copy_from(x)
             b.x_in = b.x
-        # The order of the calls below overlaps the host's bookkeeping with the GPU: the matcher first (the GPU is idle
-        # anyway), then the backbone is enqueued and the host runs the anchor sampler under it; the RPN head's loss and
-        # backward passes are enqueued (no host round trip: rfi_op_rpn_loss_dev) BEHIND the proposal / matching launches, so
-        # they run while the host samples and sorts the RoIs.
-        anchors = self._anchors(h, w)
-        all_anchors = np.concatenate(anchors)
-        labels, tgts = self._rpn_match(all_anchors, targets)
+        G = b.gcap
+        # ---- up: the ground truth (boxes, class labels, counts) -- a few hundred bytes per image
+        gt = np.zeros((n, G, 4), np.float32)
+        gl = np.zeros((n, G), np.int32)
+        for i, (g, t) in enumerate(zip(gts, targets)):
+            gt[i, :len(g)] = g
+            gl[i, :len(g)] = np.asarray(t["labels"], np.int32).reshape(-1)
+        gbase = np.concatenate([[0], np.cumsum(gcount)]).astype(np.int32)
+        b.gt.copy_from(gt); b.gt_labels.copy_from(gl); b.gt_count.copy_from(gcount); b.gt_base.copy_from(gbase[:n])
+        b.n_sampled.zero_()
+        seed, step = self.seed & 0xFFFFFFFFFFFFFFFF, self.sample_step & 0xFFFFFFFF
+        self.sample_step += 1
+        # ---- RPN targets: matcher (IoU 0.7 / 0.3, low-quality matches) + sampler (256 per image, at most half positive)
+        check(lib.rfi_op_anchor_match_batched_ws(H, P(b.anchors), b.A, 0, None, P(b.gt), n, G, P(b.gt_count), 0.7, 0.3, 1, P(b.best_ws),
+                                                 P(b.m_lab), P(b.m_idx), P(b.m_tgt)))
+        check(lib.rfi_op_sample_keys(H, P(b.m_lab), n, b.A, None, seed, step, 0, P(b.keys_a), b.stride_a))
+        check(lib.rfi_op_segsort_u64(H, P(b.keys_a), n, b.stride_a))
+        check(lib.rfi_op_rpn_sample_apply(H, P(b.keys_a), n, b.A, b.stride_a, self.rpn_batch, self.rpn_batch // 2, P(b.m_lab), P(b.m_tgt),
+                                          5, b.aoff.ctypes.data_as(C.c_void_p), b.p_lab, b.p_tgt, P(b.n_sampled)))
+        # ---- backbone, RPN head on every level
         check(lib.rfi_backbone_forward(self.backbone._h, P(b.x_in), DEVICE, n, h, w, b.pf, DEVICE))
-        labels = self._rpn_sample(labels)
-        n_sampled = max(int((labels >= 0).sum()), 1)
-        losses = {"loss_objectness": 0.0, "loss_rpn_box_reg": 0.0}
-        rpn_out, off = [], 0
         for lvl in range(5):
-            cnt = len(anchors[lvl])
             _, hl, wl, _ = b.shapes[lvl]
-            b.rpn_lab[lvl].copy_from(labels[:, off:off + cnt].reshape(-1))
-            b.rpn_tgt[lvl].copy_from(tgts[:, off:off + cnt].reshape(-1, 4))
             check(lib.rfi_model_forward_nhwc(self.rpn._h, P(b.feats[lvl]), DEVICE, n, hl, wl, P(b.rpn_out[lvl]), DEVICE))
-            off += cnt
-        rpn_out = [b.rpn_out[lvl].numpy() for lvl in range(5)]
-        # RoI heads' inputs: proposals and their matches (GPU launches + host top-k), THEN the RPN head's own training work
-        props = self._proposals(rpn_out, anchors, n, h, w, extra=[t["boxes"] for t in targets])
-        match = self._roi_match(props, targets)
+        # ---- proposals: top pre_nms per level -> decode + clip -> per-level NMS -> best post_nms + ground truth
+        K = self.pre_nms
+        for lvl in range(5):
+            _, hl, wl, _ = b.shapes[lvl]
+            check(lib.rfi_op_topk_keys(H, P(b.rpn_out[lvl]), n, hl * wl, 4, P(b.keys_l[lvl]), b.stride_l[lvl]))
+            check(lib.rfi_op_segsort_u64(H, P(b.keys_l[lvl]), n, b.stride_l[lvl]))
+            check(lib.rfi_op_topk_decode(H, P(b.keys_l[lvl]), n, b.stride_l[lvl], hl * wl, 4, K, P(b.rpn_out[lvl]),
+                                         C.c_void_p(b.anchors.ptr + int(b.aoff[lvl]) * 16), float(h), float(w), 1e-2, P(b.cand_boxes),
+                                         P(b.cand_scores), P(b.cand_counts), 5, lvl))
+        check(lib.rfi_op_nms_batched(H, P(b.cand_boxes), P(b.cand_counts), n * 5, K, float(self.rpn_nms), P(b.keep)))
+        check(lib.rfi_op_proposals_select(H, P(b.cand_boxes), P(b.cand_scores), P(b.keep), n, 5, K, self.post_nms, P(b.gt), G,
+                                          P(b.gt_count), b.pmax, P(b.props), P(b.pcount)))
+        # ---- RoI targets: matcher at 0.5, sampler (128 per image, at most a quarter foreground), compact lists + levels
+        check(lib.rfi_op_anchor_match_batched_ws(H, P(b.props), b.pmax, b.pmax, P(b.pcount), P(b.gt), n, G, P(b.gt_count), 0.5, 0.5, 0,
+                                                 P(b.best_ws), P(b.r_lab), P(b.r_idx), P(b.r_tgt)))
+        check(lib.rfi_op_roi_sample(H, P(b.r_lab), P(b.pcount), n, b.pmax, self.roi_batch, self.roi_batch // 4, seed, step, 2, P(b.sel),
+                                    P(b.nsel), P(b.npos)))
+        t1, t2, t3 = self._level_thresholds(max(h, w))
+        check(lib.rfi_op_roi_compact(H, P(b.sel), P(b.nsel), P(b.npos), n, self.roi_batch, b.pmax, P(b.props), P(b.r_idx), P(b.r_tgt),
+                                     P(b.gt_labels), G, P(b.gt_base), t1, t2, t3, P(b.rois), P(b.box_lab), P(b.box_tgt), P(b.roi_gt),
+                                     P(b.roi_lvl), P(b.img_start), P(b.rois_m), P(b.rois_g), P(b.lvl_m), P(b.fg_start), P(b.counts)))
+        check(lib.rfi_readback_begin(H, P(b.counts), 8))         # (R, Rf) come down while the RPN head's backward passes run
+        # ---- the RPN head's own training work: loss level by level (global normaliser on the device), one shared head
         self.rpn.accumulate_gradients("begin")
         for lvl in (4, 0, 1, 2, 3):                              # (level 4 first: its forward pass was the last one above)
             _, hl, wl, _ = b.shapes[lvl]
-            check(lib.rfi_op_rpn_loss_dev(ctx.handle, P(b.rpn_out[lvl]), n * hl * wl, 4, P(b.rpn_lab[lvl]), P(b.rpn_tgt[lvl]), n_sampled,
-                                          1.0 / 9, P(b.rpn_dout[lvl]), P(b.rpn_ws[lvl]), C.c_void_p(b.rpn_loss2.ptr + 8 * lvl)))
+            check(lib.rfi_op_rpn_loss_devcount(H, P(b.rpn_out[lvl]), n * hl * wl, 4, P(b.rpn_lab[lvl]), P(b.rpn_tgt[lvl]), P(b.n_sampled),
+                                               1.0 / 9, P(b.rpn_dout[lvl]), P(b.rpn_ws[lvl]), C.c_void_p(b.rpn_loss2.ptr + 8 * lvl)))
             # (forward again: the head keeps the activations of ONE pass, and later passes overwrote this level's)
             if lvl != 4:
                 check(lib.rfi_model_forward_nhwc(self.rpn._h, P(b.feats[lvl]), DEVICE, n, hl, wl, P(b.rpn_out[lvl]), DEVICE))
@@ -363,47 +363,39 @@ class MaskRCNN:
             self.rpn.accumulate_gradients("add")
             check(lib.rfi_model_input_grad(self.rpn._h, P(b.dfe[lvl]), DEVICE))          # the first term of d loss / d P_l
         self.rpn.accumulate_gradients("end")
-        rois, rlab, rtgt, rgt = self._roi_sample(props, targets, match)                     # (host; the GPU is in the RPN passes)
-        lv = self._levels(rois[:, 1:], max(h, w))
-        order = np.argsort(lv, kind="stable")                    # level-major: a level is one slice of every RoI tensor
-        rois, rlab, rtgt, rgt, lv = rois[order], rlab[order], rtgt[order], rgt[order], lv[order]
-        R = len(rois)
-        self._upload(b.rois, rois); self._upload(b.box_lab, rlab.astype(np.int32)); self._upload(b.box_tgt, rtgt)
-        self._roi_align_dev(b, b.rois, lv, b.roi7, 7)
-        check(lib.rfi_model_forward_nhwc(self.box._h, P(b.roi7), DEVICE, R, 1, 1, P(b.box_out), DEVICE))
-        lc, lr_ = C.c_float(), C.c_float()
-        check(lib.rfi_op_fastrcnn_loss(ctx.handle, P(b.box_out), R, k1, P(b.box_lab), P(b.box_tgt), 1.0 / 9, P(b.box_dout),
-                                       C.byref(lc), C.byref(lr_)))
-        check(lib.rfi_model_backward_dlogits(self.box._h, P(b.roi7), DEVICE, P(b.box_dout), DEVICE, R, 1, 1))
-        check(lib.rfi_model_input_grad(self.box._h, P(b.roi7_grad), DEVICE))
-        self._roi_align_dev(b, b.rois, lv, None, 7, backward=True, grad_dev=b.roi7_grad)
-        losses["loss_classifier"], losses["loss_box_reg"] = lc.value, lr_.value
-        # mask branch on the foreground RoIs: targets = the matched ground-truth mask, RoIAligned to 28 x 28 at 0.5
-        fg = np.flatnonzero(rlab > 0)
-        losses["loss_mask"] = 0.0
-        if len(fg):
-            gcount = [len(t["boxes"]) for t in targets]
-            gbase = np.concatenate([[0], np.cumsum(gcount)])
+        cnt2 = (C.c_int32 * 2)()
+        check(lib.rfi_readback_end(H, cnt2, 8))
+        R, Rf = int(cnt2[0]), int(cnt2[1])
+        losses = {"loss_objectness": 0.0, "loss_rpn_box_reg": 0.0, "loss_classifier": 0.0, "loss_box_reg": 0.0, "loss_mask": 0.0}
+        h0, w0 = h // 4, w // 4
+        # ---- box head on the sampled RoIs (multi-level RoIAlign: one launch each way)
+        if R:
+            check(lib.rfi_op_roi_align_ml(H, b.pf4, n, h0, w0, F, 0.25, P(b.rois), P(b.roi_lvl), P(b.counts), R, 7, 7, 2, P(b.roi7)))
+            check(lib.rfi_model_forward_nhwc(self.box._h, P(b.roi7), DEVICE, R, 1, 1, P(b.box_out), DEVICE))
+            check(lib.rfi_op_fastrcnn_loss_dev(H, P(b.box_out), R, k1, P(b.box_lab), P(b.box_tgt), 1.0 / 9, P(b.box_dout), P(b.box_ws),
+                                               P(b.box_loss2)))
+            check(lib.rfi_model_backward_dlogits(self.box._h, P(b.roi7), DEVICE, P(b.box_dout), DEVICE, R, 1, 1))
+            check(lib.rfi_model_input_grad(self.box._h, P(b.roi7_grad), DEVICE))
+            check(lib.rfi_op_roi_align_ml_backward(H, b.pdf4, n, h0, w0, F, 0.25, P(b.roi7_grad), P(b.rois), P(b.roi_lvl), P(b.img_start), R,
+                                                   7, 7, 2))
+        # ---- mask branch on the foreground RoIs: targets = the matched ground-truth mask, RoIAligned to 28 x 28 at 0.5
+        if Rf:
             if b.masks is None or b.masks_n < gbase[-1]:
                 b.masks, b.masks_n, b.masks_of = ctx.empty((int(gbase[-1]), h, w), np.uint8), int(gbase[-1]), None
             if not (masks_resident and b.masks_of is targets):   # (resident only on the caller's word AND for the same list object)
                 self._upload(b.masks, np.concatenate([np.asarray(t["masks"], np.uint8).reshape(-1, h, w) for t in targets]))
                 b.masks_of = targets
-            rm = rois[fg]
-            rg = np.concatenate([(gbase[rm[:, 0].astype(int)] + rgt[fg])[:, None].astype(np.float32), rm[:, 1:]], 1)
-            self._upload(b.rois_m, rm); self._upload(b.rois_g, rg)
-            Rf = len(fg)
-            self._roi_align_dev(b, b.rois_m, lv[fg], b.roi14, 14)
-            check(lib.rfi_op_mask_targets(ctx.handle, P(b.masks), int(gbase[-1]), h, w, P(b.rois_g), Rf, 28, 28, 2, P(b.mask_t)))
-            lm = C.c_float()
-            check(lib.rfi_train_forward_backward(self.mask._h, P(b.roi14), DEVICE, P(b.mask_t), DEVICE, Rf, 14, 14, C.byref(lm)))
+            check(lib.rfi_op_roi_align_ml(H, b.pf4, n, h0, w0, F, 0.25, P(b.rois_m), P(b.lvl_m), C.c_void_p(b.counts.ptr + 4), Rf, 14, 14, 2,
+                                          P(b.roi14)))
+            check(lib.rfi_op_mask_targets(H, P(b.masks), int(gbase[-1]), h, w, P(b.rois_g), Rf, 28, 28, 2, P(b.mask_t)))
+            check(lib.rfi_train_forward_backward(self.mask._h, P(b.roi14), DEVICE, P(b.mask_t), DEVICE, Rf, 14, 14, None))
             check(lib.rfi_model_input_grad(self.mask._h, P(b.roi14_grad), DEVICE))
-            self._roi_align_dev(b, b.rois_m, lv[fg], None, 14, backward=True, grad_dev=b.roi14_grad)
-            losses["loss_mask"] = lm.value
+            check(lib.rfi_op_roi_align_ml_backward(H, b.pdf4, n, h0, w0, F, 0.25, P(b.roi14_grad), P(b.rois_m), P(b.lvl_m), P(b.fg_start), Rf,
+                                                   14, 14, 2))
         check(lib.rfi_backbone_backward(self.backbone._h, P(b.x_in), DEVICE, n, h, w, b.pdf, DEVICE))
         norms = {}
         for name, m in zip(("backbone", "rpn", "box", "mask"), self.models()):
-            if m is self.mask and not len(fg):
+            if m is self.mask and not Rf:
                 # no foreground RoI on THIS rank.  Alone (grad_sync == 1) the mask head skips its step; in a data-parallel job
                 # the other ranks enter the all-reduce of its gradients, so this rank must too -- with zero gradients -- and
                 # then apply the same averaged update (a rank that skipped would hang the collective or leave the replicas
@@ -412,16 +404,32 @@ class MaskRCNN:
                     continue
                 m.accumulate_gradients("begin")
                 m.accumulate_gradients("end")                    # grads = 0
+            if m is self.box and not R:
+                continue
             if self.grad_sync > 1:
                 m.allreduce_gradients()
             norms[name] = m.apply_gradients(lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
                                             grad_scale=1.0 / max(self.grad_sync, 1))
+        # ---- down: the loss scalars
         l2 = b.rpn_loss2.numpy()
         losses["loss_objectness"], losses["loss_rpn_box_reg"] = float(l2[:, 0].sum(dtype=np.float32)), float(l2[:, 1].sum(dtype=np.float32))
+        if R:
+            bl = b.box_loss2.numpy()
+            losses["loss_classifier"], losses["loss_box_reg"] = float(bl[0]), float(bl[1])
+        if Rf:
+            losses["loss_mask"] = float(self.mask.last_loss()[0])
         losses["loss"] = float(sum(losses.values()))
-        # the discrete decisions and gradient norms of the step (tests replay them through oracle/mask_rcnn_ref.py)
-        self.last_trace = {"rpn_labels": labels, "rpn_targets": tgts, "proposals": props, "rois": rois, "roi_labels": rlab,
-                           "roi_targets": rtgt, "roi_gt": rgt, "roi_levels": lv, "grad_norms": norms}
+        self.last_trace = {"grad_norms": norms, "num_rois": R, "num_foreground": Rf}
+        if self.keep_trace:
+            # the discrete decisions of the step (tests replay them through oracle/mask_rcnn_ref.py)
+            pc = b.pcount.numpy()
+            pr = b.props.numpy()
+            self.last_trace.update({
+                "rpn_labels": np.concatenate([b.rpn_lab[l].numpy().reshape(n, -1) for l in range(5)], 1),
+                "rpn_targets": np.concatenate([b.rpn_tgt[l].numpy().reshape(n, -1, 4) for l in range(5)], 1),
+                "proposals": [pr[i, :pc[i]].copy() for i in range(n)], "rois": b.rois.numpy()[:R], "roi_labels": b.box_lab.numpy()[:R],
+                "roi_targets": b.box_tgt.numpy()[:R], "roi_gt": b.roi_gt.numpy()[:R], "roi_levels": b.roi_lvl.numpy()[:R],
+                "num_sampled": int(b.n_sampled.numpy()[0])})
         return losses
 
     @staticmethod

@@ -84,6 +84,7 @@ def test_assembled_step_against_the_oracle(widths):
     from rfi_toolbox_amd.models import MaskRCNN
     torch.manual_seed(3)
     det = MaskRCNN(2, 3, *widths, seed=7)
+    det.keep_trace = True
     ref = MaskRCNNRef(2, 3, *widths).load(_states(det))
     x, targets = _batch(np.random.default_rng(1))
     got = det.train_step(x, targets, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)        # (lr 0: the weights stay what the oracle holds)
@@ -95,15 +96,17 @@ def test_assembled_step_against_the_oracle(widths):
     for k, v in wtr["grad_norms"].items():
         assert abs(tr["grad_norms"][k] - v) <= 3e-3 * v, (k, tr["grad_norms"][k], v)
     # discrete decisions: a free oracle run from the same seed takes the same ones
-    free, ftr = ref.step(x, targets, rng=np.random.default_rng(7), grads=False)
+    free, ftr = ref.step(x, targets, sampler=(det.seed, det.sample_step - 1), grads=False)
     assert np.array_equal(ftr["rpn_labels"], tr["rpn_labels"])
+    assert tr["num_sampled"] == int((ftr["rpn_labels"] >= 0).sum())
     np.testing.assert_allclose(ftr["rpn_targets"], tr["rpn_targets"], rtol=1e-5, atol=1e-6)
     assert [len(p) for p in ftr["proposals"]] == [len(p) for p in tr["proposals"]]
     for a, b in zip(ftr["proposals"], tr["proposals"]):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-3)
-    order = np.argsort(ftr["roi_levels"], kind="stable")                                  # the device step keeps its RoIs level-major
-    np.testing.assert_allclose(ftr["rois"][order], tr["rois"], rtol=0, atol=2e-3)
-    assert np.array_equal(ftr["roi_labels"][order], tr["roi_labels"]) and np.array_equal(ftr["roi_gt"][order], tr["roi_gt"])
+    np.testing.assert_allclose(ftr["rois"], tr["rois"], rtol=0, atol=2e-3)               # image-major, positives of an image first
+    assert np.array_equal(ftr["roi_labels"], tr["roi_labels"]) and np.array_equal(ftr["roi_gt"], tr["roi_gt"])
+    assert np.array_equal(ftr["roi_levels"], tr["roi_levels"])
+    np.testing.assert_allclose(ftr["roi_targets"], tr["roi_targets"], rtol=1e-4, atol=1e-5)
     for k in free:
         assert abs(got[k] - free[k]) <= 5e-4 * max(1.0, abs(free[k])), (k, got[k], free[k])
 
@@ -176,10 +179,11 @@ def test_assembled_step_is_bitwise_reproducible():
     from rfi_toolbox_amd.models import MaskRCNN
     torch.manual_seed(3)
     det = MaskRCNN(2, 3, 16, 64, 128, seed=7)
+    det.keep_trace = True
     x, targets = _batch(np.random.default_rng(1), n=4)
     runs = []
     for _ in range(4):
-        det.rng = np.random.default_rng(11)
+        det.sample_step = 11
         losses = det.train_step(x, targets, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)
         runs.append((losses, dict(det.last_trace["grad_norms"]), det.last_trace["rois"].copy()))
     for losses, norms, rois in runs[1:]:
@@ -204,7 +208,7 @@ def test_data_parallel_step_on_a_rank_without_foreground():
             torch.manual_seed(4)
             det = MaskRCNN(2, 3, 16, 64, 128, seed=9)
             det.grad_sync = max(world, 1)
-            det.rng = np.random.default_rng(3)
+            det.sample_step = 3
             losses = det.train_step(x, targets, lr=1e-3)
             res.append((losses, dict(det.last_trace["grad_norms"]), {k: v.clone() for k, v in det.mask.state_dict().items()}))
         assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
