@@ -62,12 +62,12 @@ __device__ __forceinline__ int lower_bound(const u64* s, int n, u64 v) {      //
 }
 
 // ---------------------------------------------------------------- segmented sort: one workgroup per segment
-__global__ __launch_bounds__(kB) void segsort_kernel(u64* __restrict__ keys, int stride) {
+__global__ __launch_bounds__(1024) void segsort_kernel(u64* __restrict__ keys, int stride) {
     extern __shared__ u64 s_keys[];
     u64* seg = keys + (size_t)blockIdx.x * stride;
-    for (int i = threadIdx.x; i < stride; i += kB) s_keys[i] = seg[i];
+    for (int i = threadIdx.x; i < stride; i += blockDim.x) s_keys[i] = seg[i];
     bitonic_sort(s_keys, stride);
-    for (int i = threadIdx.x; i < stride; i += kB) seg[i] = s_keys[i];
+    for (int i = threadIdx.x; i < stride; i += blockDim.x) seg[i] = s_keys[i];
 }
 
 // ---------------------------------------------------------------- sampler keys: class << 48 | random << 16 | index
@@ -328,7 +328,8 @@ int pow2_at_least(int n) {
 void launch_segsort_u64(rfi_ctx* ctx, unsigned long long* keys, int n_segs, int stride) {
     RFI_REQUIRE(n_segs > 0 && stride >= 2 && stride <= 8192 && (stride & (stride - 1)) == 0, "segsort: segments of 2 .. 8192 keys, a power of two");
     ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)n_segs * stride * 16);
-    hipLaunchKernelGGL(segsort_kernel, dim3(n_segs), dim3(kB), (size_t)stride * 8, ctx->stream, keys, stride);
+    const int threads = stride >= 2048 ? 1024 : (stride >= 512 ? 256 : 64);      // (a compare-exchange pair per thread and stage)
+    hipLaunchKernelGGL(segsort_kernel, dim3(n_segs), dim3(threads), (size_t)stride * 8, ctx->stream, keys, stride);
     check_launch("segsort");
 }
 

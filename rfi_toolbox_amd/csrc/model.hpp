@@ -227,7 +227,13 @@ struct rfi_model {
     int out_scale = 1;
     bool ext_dlogits = false;         // backward from caller-provided dlogits (rfi_model_backward_dlogits)
     std::vector<int> mkY, mkG;
-    int mkU = -1, mkGU = -1, mkGx = -1;
+    int mkU = -1, mkGU = -1, mkGx = -1, head_wd = -1, head_w3 = -1, head_wd3 = -1;
+    // the 1x1 head as a GEMM on the matrix cores (conv kernels forward / input gradient, weight-gradient kernel) instead of the
+    // per-pixel VALU kernels written for one output channel: where it has enough outputs (the RPN head's 5 A = 20)
+    bool head_on_mfma() const {
+        static const bool off = getenv("RFI_HEAD_VALU") != nullptr;       // A/B runs
+        return !off && (arch == 3 || arch == 4) && out_ch >= 8 && out_ch % 4 == 0 && in_ch % 4 == 0 && (compute_x3 || compute_bf16);
+    }
     void build_mask();
     void prepare_mask(int n, int h, int w);
     void forward_mask(const float* x_dev, int n, int h, int w);

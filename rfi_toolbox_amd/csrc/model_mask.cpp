@@ -132,7 +132,7 @@ void rfi_model::prepare_mask(int n, int h, int w) {
         mkY.assign(L, -1); mkG.assign(L, -1);
         for (int i = 0; i < L; ++i) { mkY[i] = new_buf(); mkG[i] = new_buf(); }
         mkU = new_buf(); mkGU = new_buf(); mkGx = new_buf();
-        logits = new_buf(); dlogits = new_buf();
+        logits = new_buf(); dlogits = new_buf(); head_wd = new_buf(); head_w3 = new_buf(); head_wd3 = new_buf();
         x_stage = new_buf(); x_stage2 = new_buf(); x_pad = new_buf(); out_stage = new_buf();
         ws_red = new_buf(); ws_slab = new_buf(); lab_stage = new_buf();
     }
@@ -172,6 +172,19 @@ void rfi_model::prepare_mask(int n, int h, int w) {
         b.tap_stride = (int64_t)C * C;
         slab_need = std::max(slab_need, wgrad_slab_floats(b, IMPL_AUTO));
     }
+    if (head_on_mfma()) {
+        WgradArgs c;                                  // the 1x1 head's weight gradient
+        c.N = n; c.H = out_scale * h; c.W = out_scale * w; c.Hx = c.H; c.Wx = c.W;
+        c.Cx = C; c.Cy = out_ch;
+        c.xop.pstride = C; c.yop.pstride = out_ch;
+        c.R = 1; c.S = 1; c.pad = 0;
+        c.tap_stride = (int64_t)C * out_ch;
+        c.bf16x3 = true;
+        slab_need = std::max(slab_need, wgrad_slab_floats(c, IMPL_AUTO));
+    }
+    bufs[head_wd].ensure(ctx, (size_t)out_ch * C + 16);
+    bufs[head_w3].ensure(ctx, weights_x3_floats(1, out_ch, C) + 16);
+    bufs[head_wd3].ensure(ctx, weights_x3_floats(1, C, out_ch) + 16);
     bufs[ws_slab].ensure(ctx, slab_need + 16);
     pN = n; pH = h; pW = w;
 }
@@ -232,6 +245,26 @@ void rfi_model::forward_mask(const float* x_dev, int n, int h, int w) {
         launch_conv(ctx, a);
     }
     const ConvBN& cl = convs[L - 1];                  // (its scale = 1 / shift = 0 vectors serve the ReLU of U as well)
+    if (head_on_mfma()) {             // a wide 1x1 head (the RPN's 5 A outputs) is a GEMM: the conv kernels, not the per-pixel VALU kernel
+        ConvArgs a;
+        a.x = View{arch == 3 ? buf(mkU) : buf(mkY[L - 1]), C};
+        a.N = n; a.H = out_scale * h; a.W = out_scale * w; a.Hin = a.H; a.Win = a.W;
+        a.Cin = C; a.Cout = out_ch;
+        a.w = params + head_w_off;
+        if (use_w3()) {               // the pre-split records of this small filter are rebuilt per pass (one 5-us launch, no allocation)
+            launch_weights_to_x3(ctx, a.w, 1, out_ch, C, buf(head_w3));
+            a.w3 = buf(head_w3);
+        }
+        a.bias = params + head_b_off;
+        a.y = MutView{buf(logits), out_ch};
+        a.Hout = a.H; a.Wout = a.W;
+        a.R = 1; a.S = 1; a.pad = 0;
+        a.xf = relu_of(cl);
+        a.bf16 = compute_bf16;
+        a.bf16x3 = compute_x3;
+        launch_conv(ctx, a);
+        return;
+    }
     launch_head_fwd(ctx, arch == 3 ? buf(mkU) : buf(mkY[L - 1]), M4, C, cl.scale(), cl.shift(), params + head_w_off, params + head_b_off,
                     out_ch, buf(logits));
 }
@@ -245,6 +278,45 @@ void rfi_model::backward_mask(const float* x_dev, const uint8_t* labels_dev, int
         else launch_loss_bwd(ctx, buf(logits), labels_dev, M4 * out_ch, d_sums, buf(dlogits));
     }
     const ConvBN& cl = convs[L - 1];
+    if (head_on_mfma()) {
+        // da = dlogits . W (a 1x1 conv with the transposed filter), dW = dlogits^T . act (the 1x1 weight gradient), db = column sums
+        float* const hin = arch == 3 ? buf(mkU) : buf(mkY[L - 1]);
+        float* const da = arch == 3 ? buf(mkGU) : buf(mkG[L - 1]);
+        launch_weight_to_dgrad(ctx, params + head_w_off, 1, out_ch, C, 0, buf(head_wd));
+        ConvArgs a;
+        a.x = View{buf(dlogits), out_ch};
+        a.N = n; a.H = out_scale * h; a.W = out_scale * w; a.Hin = a.H; a.Win = a.W;
+        a.Cin = out_ch; a.Cout = C;
+        a.w = buf(head_wd);
+        if (use_w3()) {
+            launch_weights_to_x3(ctx, a.w, 1, C, out_ch, buf(head_wd3));
+            a.w3 = buf(head_wd3);
+        }
+        a.y = MutView{da, C};
+        a.Hout = a.H; a.Wout = a.W;
+        a.R = 1; a.S = 1; a.pad = 0;
+        a.bf16 = compute_bf16;
+        a.bf16x3 = compute_x3;
+        launch_conv(ctx, a);
+        launch_channel_sum(ctx, View{buf(dlogits), out_ch}, M4, out_ch, buf(ws_red), grads + head_b_off);
+        WgradArgs wa;
+        wa.xop = View{hin, C};
+        wa.xf_x = relu_of(cl);
+        wa.yop = View{buf(dlogits), out_ch};
+        wa.N = n; wa.H = out_scale * h; wa.W = out_scale * w; wa.Hx = wa.H; wa.Wx = wa.W;
+        wa.Cx = C; wa.Cy = out_ch;
+        wa.R = 1; wa.S = 1; wa.pad = 0;
+        wa.dw = grads + head_w_off;
+        wa.tap_stride = (int64_t)C * out_ch;
+        wa.sy = C; wa.sx = 1;
+        wa.slab = buf(ws_slab);
+        wa.slab_floats = bufs[ws_slab].n;
+        wa.bf16 = compute_bf16;
+        wa.bf16x3 = compute_x3;
+        side_begin();
+        launch_wgrad(ctx, wa);
+        side_end();
+    } else
     launch_head_bwd(ctx, arch == 3 ? buf(mkU) : buf(mkY[L - 1]), M4, C, cl.scale(), cl.shift(), params + head_w_off, out_ch, buf(dlogits),
                     arch == 3 ? buf(mkGU) : buf(mkG[L - 1]), buf(ws_red), grads + head_w_off, grads + head_b_off);
     // transposed conv: dU = dUa * (U > 0); bias, weight and input gradients
