@@ -1312,6 +1312,7 @@ size_t channel_sum_ws_floats(int64_t M, int C) {
 void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out, bool finish) {
     ChanGeom g = geom_rows(M, C);
     const bool vec = g.V == 4 && v.pstride % 4 == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0;
+    RFI_REQUIRE(finish || vec, "channel_sum: deferred finishing needs the vector path (C % 4 == 0, an aligned view)");
     if (!vec && g.V == 4) g = geom_rows(M, C, false);   // unaligned view: scalar lanes
     {
         ProfScope ps(ctx, FAM_REDUCE, 0, (double)M * C * 4);
@@ -1508,6 +1509,8 @@ int launch_head_bwd(rfi_ctx* ctx, YRef yr, int64_t M, int C, const float* scale,
                                       reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
                                       reinterpret_cast<uintptr_t>(w)) & 15) && yr.stride(C) % 4 == 0;
     RFI_REQUIRE(vec || !yr.bf16, "head_bwd: a bfloat16 input needs C % 4 == 0");
+    // finish = false leaves the records for a batched finisher whose table was filled with the VECTOR kernel's record geometry
+    RFI_REQUIRE(finish || vec, "head_bwd: deferred finishing needs the vector path (C % 4 == 0, 16-byte aligned tensors)");
     RFI_REQUIRE(!da16 || (vec && Cout == 1 && !(reinterpret_cast<uintptr_t>(da16) & 7)), "head_bwd: a bfloat16 gradient tensor needs C % 4 == 0 and one output channel");
     const float* y = static_cast<const float*>(yr.p);
     ChanGeom g = geom_rows(M, C, vec);     // scalar kernel: one channel per lane; vector kernel: four

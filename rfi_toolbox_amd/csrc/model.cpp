@@ -483,7 +483,7 @@ void rfi_model::refresh_dgrad_weights() {
         // layers whose filters the wave-specialised kernels read (ws_by_w) need no records: launch_conv drops
         // ConvArgs::w3 for them, and a shape those kernels decline (maps under 8 x 8) gets a temporary split copy
         static const bool all_x3 = getenv("RFI_NO_WS") != nullptr || getenv("RFI_NO_GW") != nullptr;     // A/B runs
-        if (x3_descs && x3_for_ws_P != ws_P) {
+        if (x3_descs && (x3_for_ws_P != ws_P || x3_for_shape != pH * 65536 + pW)) {
             ctx->release(x3_descs);
             x3_descs = nullptr;
         }
@@ -493,20 +493,26 @@ void rfi_model::refresh_dgrad_weights() {
             std::vector<X3Desc> h;
             x3_skips_ws_layers = !all_x3 && ws_P == 3 && arch == 0;
             x3_reads_wd = false;
-            auto add = [&](const float* src, float* dst, int taps, int cout, int cin) {
-                if (x3_skips_ws_layers && ws_by_w.count(src)) return;
+            x3_skipped.clear();
+            // a layer is left out only if the wave-specialised kernels cannot decline it at the prepared shape: its maps are at
+            // least 8 x 8 (conv_ws_eligible) -- a declined launch on a missing record would allocate a temporary copy and
+            // synchronise the stream inside launch_conv.  (pH == 0: nothing prepared yet, keep everything)
+            auto add = [&](const float* src, float* dst, int taps, int cout, int cin, int level = 0) {
+                const bool small_map = pH == 0 || (level > 0 && ((pH >> (level - 1)) < 8 || (pW >> (level - 1)) < 8));
+                if (x3_skips_ws_layers && ws_by_w.count(src) && !small_map) { x3_skipped.insert(src); return; }
                 if (src < params || src >= params + n_flat) x3_reads_wd = true;
                 h.push_back(X3Desc{src, dst, (int64_t)taps * cout, cin, (cin + 15) / 16});
                 x3_bytes += (double)taps * cout * cin * 4 + (double)weights_x3_floats(taps, cout, cin) * 4;
             };
             for (auto& c : convs) {
-                add(params + c.w_off, c.w3, c.R * c.R, c.cout, c.cin_p);
-                add(c.wd, c.wd3, c.R * c.R, c.cin_p, c.cout);
+                add(params + c.w_off, c.w3, c.R * c.R, c.cout, c.cin_p, c.level);
+                add(c.wd, c.wd3, c.R * c.R, c.cin_p, c.cout, c.level);
             }
             for (auto& u : ups) {
                 add(params + u.w_off, u.w3, 4, u.cout, u.cin);
                 add(u.wd, u.wd3, 4, u.cin, u.cout);
             }
+            x3_for_shape = pH * 65536 + pW;
             x3_n = (int)h.size();
             x3_descs = ctx->alloc((h.size() + 1) * sizeof(X3Desc));
             if (x3_n) RFI_CHECK_HIP(hipMemcpyAsync(x3_descs, h.data(), h.size() * sizeof(X3Desc), hipMemcpyHostToDevice, ctx->stream));

@@ -133,7 +133,7 @@ struct rfi_model {
         const rfi::bf16_t* p = it == ws_by_w.end() || ws_P != ws_need() ? nullptr : it->second;
         a.wB3 = ws_P == 3 ? p : nullptr;
         a.wB1 = ws_P == 1 ? p : nullptr;
-        if (a.wB3 && x3_skips_ws_layers) a.w3 = nullptr;      // (no pre-split records are kept for this layer)
+        if (a.wB3 && x3_skipped.count(a.w)) a.w3 = nullptr;   // (no pre-split records are kept for this layer)
     }
     // the plain U-Net keeps no pre-split (3 x bf16) filter records for the layers the wave-specialised kernels cover: at its
     // shapes they never decline.  The other models (detector backbone on 4 x 4 maps, heads) keep every record up to date, so a
@@ -163,6 +163,8 @@ struct rfi_model {
     void* x3_descs = nullptr;         // device table of the batched rebuild
     int x3_n = 0;
     int x3_for_ws_P = -1;             // the ws_P the record list was built for (layers with ws copies are left out)
+    int x3_for_shape = -1;            // ... and the prepared H, W (a layer whose maps fall under 8 x 8 keeps its records)
+    std::unordered_set<const float*> x3_skipped;      // filters whose records are NOT kept up to date (ws_set clears ConvArgs::w3 for them)
     double x3_bytes = 0;
     int64_t adam_step = 0;
     bool wd_dirty = true;

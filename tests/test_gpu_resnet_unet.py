@@ -193,3 +193,34 @@ def test_algorithmic_flops():
     want += 2 * hw * f
     assert fwd == pytest.approx(want, rel=1e-12)
     assert step == pytest.approx(3 * fwd - 2 * 128 * 128 * 27 * f, rel=1e-12)
+
+
+def test_benched_combination_width64_bf16_1024():
+    """BASELINE configs[2] exactly as `bench.py --workload resnet1024` runs it: UNetResNet18(3, 1, 64), bf16 operands,
+    ONE 1024 x 1024 x 3 sample.  The loss and the logits against the oracle in the same arithmetic (forward only: the
+    float32-tensor bf16 mode of this model rounds operands, not outputs), every gradient finite, and two passes bit-identical
+    (the slab reductions, BatchNorm sums and the side-stream overlap at this size)."""
+    f, n, s = 64, 1, 1024
+    st = _perturbed_state(f, 41)
+    x, y, xo, yo = _inputs(n, s, 42)
+    with torch.no_grad():
+        lg32 = rref.forward(st, xo, training=True)
+        with unet_ref.bf16_operands():
+            lgb = rref.forward(st, xo, training=True)
+        want_loss = float(unet_ref.segmentation_loss(lgb, yo))
+    m = UNetResNet18(3, 1, f).load_state_dict(st).train().set_compute_dtype("bfloat16")
+    loss = m.forward_backward(x, y)
+    assert loss == pytest.approx(want_loss, rel=3e-3)
+    want = lgb.permute(0, 2, 3, 1).reshape(-1).numpy()
+    w32 = lg32.permute(0, 2, 3, 1).reshape(-1).numpy()
+    got = m.debug_tensor("logits")
+    d_same, d_arith = np.abs(got - want).max(), np.abs(w32 - want).max()
+    assert d_same <= max(0.6 * d_arith, 3e-3 * float(np.abs(want).max())), (d_same, d_arith)
+    names = [k for k in unet_ref.param_names(st)]
+    g1 = {k: m.grad(k).copy() for k in names}
+    assert all(np.isfinite(v).all() for v in g1.values())
+    assert sum(float(np.abs(v).sum()) for v in g1.values()) > 0
+    loss2 = m.forward_backward(x, y)
+    assert loss2 == loss
+    for k in names:
+        assert np.array_equal(m.grad(k), g1[k]), k

@@ -32,4 +32,9 @@ for dt, suffix in (("f32", ""), ("bf16", "_bf16"), ("cnn3", "_cnn3"), ("unet1024
     if os.path.isdir(md):
         subprocess.check_call([sys.executable, os.path.join(here, "summarize_mfma.py"), md,
                                os.path.join(dst, f"{tag}_mfma_util{suffix}.json")], stdout=subprocess.DEVNULL)
+    # summaries written on the GPU box by tools/profile_round.sh (the raw counter tables do not travel back)
+    for kind, name in (("traffic", "traffic"), ("mfma_util", "mfma_util")):
+        f = os.path.join(src, f"{kind}_{dt}.json")
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(dst, f"{tag}_{name}{suffix}.json"))
 print("\n".join(sorted(os.listdir(dst))))

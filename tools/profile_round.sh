@@ -23,6 +23,11 @@ pmc3() {   # $1 = output tag, rest = bench arguments: FETCH / WRITE / matrix-pip
   RFI_NO_OVERLAP=1 $T 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_$tag" -- $B $Q "$@" > "$O/pmc_fetch_$tag.log" 2>&1
   RFI_NO_OVERLAP=1 $T 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_$tag" -- $B $Q "$@" > "$O/pmc_write_$tag.log" 2>&1
   RFI_NO_OVERLAP=1 $T 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$O/pmc_mfma_$tag" -- $B $Q "$@" > "$O/pmc_mfma_$tag.log" 2>&1
+  # the per-dispatch counter tables are tens of megabytes each and gpurun_out/ travels back only up to 64 MiB: summarise
+  # here (HBM bytes per launch with the guide's gfx950 corrections; matrix-pipe busy share), keep the summaries only
+  python3 $R/tools/summarize_pmc.py "$O/pmc_fetch_$tag" "$O/pmc_write_$tag" "$O/traffic_$tag.json" > /dev/null
+  python3 $R/tools/summarize_mfma.py "$O/pmc_mfma_$tag" "$O/mfma_util_$tag.json" > /dev/null
+  rm -rf "$O/pmc_fetch_$tag" "$O/pmc_write_$tag" "$O/pmc_mfma_$tag"
   echo "pmc $tag done"
 }
 if [ "$PART" = main ]; then
@@ -45,6 +50,7 @@ else
     pmc3 $wl --workload $wl
   done
 fi
-# keep what travels back small: the per-dispatch traces are large
-find "$O" -name "*kernel_trace.csv" -size +20M -delete
+# keep what travels back small: the per-dispatch traces are large (the statistics tables next to them stay)
+find "$O" -name "*kernel_trace.csv" -delete
+find "$O" -name "*agent_info.csv" -delete
 du -sh "$O"
