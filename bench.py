@@ -29,6 +29,7 @@ import numpy as np  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.0     # v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0
+SUSTAINED_3XBF16_TFLOPS = 272.8    # measured (tools/mfma_shape.hip): float32 work the MFMA + LDS loop sustains under the power cap
 # `roofline.peak` is the peak of the INSTRUCTION the dominant kernel issues, in units of the algorithmic FLOPs it
 # is credited with: the default float32 path issues six v_mfma_f32_32x32x16_bf16 per 32x32x16 block product
 # (3 x bf16 splitting), so its ceiling is 2516 / 6 = 419.3 TFLOP/s of float32 work.
@@ -390,6 +391,12 @@ def roofline_of(launches, fam_serial, profile_steps, dtype, workload, peak_tf):
                 launches_mfma_bound=n_f, launches_hbm_bound=len(rows) - n_f)
     if dtype in ("f32", "f32planes"):    # secondary: the same float32 work against what the native float32 MFMA could do
         roof["vs_native_f32_mfma_peak_157.3"] = round(fl / t_meas / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+        # ... and against what the matrix cores SUSTAIN for this instruction stream under the chip's power cap: the kernels'
+        # consumer loop alone (LDS fragment reads + six MFMAs per block product, random data, nothing else on the chip) --
+        # tools/mfma_shape.hip, profiles/r4_mfma_shape.txt: 1,637 TFLOP/s of bf16 MFMA at 1.71 GHz = 272.8 of float32 work.
+        # A static figure measured once (round 4), not by this run; `peak` stays the datasheet-clock number
+        roof["vs_sustained_mfma_rate_272.8"] = round(fl / t_meas / 1e12 / SUSTAINED_3XBF16_TFLOPS, 4)
+        roof["sustained_rate_source"] = "static: profiles/r4_mfma_shape.txt (tools/mfma_shape.hip, shape 32 without partner waves)"
     if not roof["frac"] <= 1.0 or not roof["frac_of_mfma_peak"] <= 1.0:
         raise SystemExit(f"roofline fraction {roof['frac']} > 1: wrong peak for the instruction stream")
     # HBM bytes per launch of the dominant family: NOT measured by this run (bench.py cannot sit under the profiler
@@ -539,11 +546,10 @@ def cpu_baseline_maskrcnn(size, gpu_batch, seconds_cap=25.0):
     ref = MaskRCNNRef(2, 3, 64, 256, 1024)
     batch = 2
     x, targets = synthetic_instances(batch, size, 0)
-    rng = np.random.default_rng(0)
     t_all0, times = time.perf_counter(), []
     for i in range(1 + 6):
         t0 = time.perf_counter()
-        ref.step(x, targets, rng=rng)
+        ref.step(x, targets, sampler=(0, i))
         if i >= 1:
             times.append(time.perf_counter() - t0)
         if time.perf_counter() - t_all0 > seconds_cap and len(times) >= 2:

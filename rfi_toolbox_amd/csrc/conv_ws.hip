@@ -46,6 +46,7 @@ struct WsDev {
     float* y;                         // [N][H][W][y_ps] float32
     int y_ps;
     double* stats;                    // [gridDim.x][Cout][2] fp64 (sum y, sum y^2) records, or null
+    int wide_epi;                     // 64-channel blocks: 16-byte output stores through an LDS transpose (y_ps % 4 == 0, 16-byte aligned y)
     int diag;                         // RFI_WS_DIAG (timing experiments, wrong results): 1 no halo loads after the first, 2 no filter DMA, 4 no MFMAs
     int prio;                         // RFI_WS_PRIO (tuning): 0 none, 1 consumers at priority 2, 2 producers at priority 1
     unsigned long long* stamps;       // RFI_DIAG_STAMPS build: per-wave cycle sums
@@ -67,7 +68,12 @@ struct WsCfg {
     static constexpr int HALO_ITEMS = (HP * 4 + 255) / 256;          // float4 loads per producer thread and item
     static constexpr int B_OFF = (ADB ? 2 : 1) * A_BYTES;
     static constexpr int STAT_OFF = B_OFF + 2 * B_BYTES;
-    static constexpr int LDS_BYTES = STAT_OFF + 4 * NTL * 64 * 2 * 8;   // + per consumer lane and n-block (sum, sumsq)
+    static constexpr int STAT_BYTES = 4 * NTL * 64 * 2 * 8;            // per consumer lane and n-block (sum, sumsq): written once, at the end
+    // the immediate epilogue (NTL >= 2) transposes half blocks through a per-wave scratch of 16 pixel rows x 36 floats into
+    // 16-byte stores; the scratch aliases the statistics area (free until the kernel's last lines)
+    static constexpr int EPI_WAVE_BYTES = 16 * 36 * 4;
+    static constexpr bool WIDE_OK = STAT_OFF + 4 * EPI_WAVE_BYTES <= 160 * 1024;       // (not beside the 4 x 10 x 10 halo of the 8 x 8 tiles)
+    static constexpr int LDS_BYTES = STAT_OFF + ((STAT_BYTES > 4 * EPI_WAVE_BYTES || !WIDE_OK) ? STAT_BYTES : 4 * EPI_WAVE_BYTES);
     static_assert(TB * TH * TW == 256, "a tile is 256 output pixels");
     static_assert(32 % TW == 0 || TW % 32 == 0, "a 32-pixel block covers whole rows or a part of one");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -465,15 +471,40 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                         f32x2 s1v[NTL], s2v[NTL];
 #pragma unroll
                         for (int nt = 0; nt < NTL; ++nt) s1v[nt] = s2v[nt] = f32x2{0.0f, 0.0f};
+                        // WIDE: the values leave through this wave's LDS scratch as 16-byte stores of 4 channels of one pixel (a
+                        // wave store = 8 pixels x 128 bytes): 16 store instructions per tile and lane instead of 64 -- the epilogue
+                        // is bound by store ISSUE (~70 cycles each).  Same values, same statistics arithmetic, another route out
+                        const bool wide = C::WIDE_OK && d.wide_epi;
+                        float* const s_ep = reinterpret_cast<float*>(smem + C::STAT_OFF + cw * C::EPI_WAVE_BYTES);
 #pragma unroll
                         for (int e = 0; e < E; e += 2) {
                             const int nt = e / 32, mt = (e >> 4) & 1, r = e & 15;
                             const f32x2 v = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{bias[nt], bias[nt]};
+                            if (wide) {
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const int p = cw * 64 + mt * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2);
-                                const int b = p / (TH * TW), rr = p % (TH * TW);
-                                d.y[tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps) + lane_off[nt]] = v[k];
+                                for (int k = 0; k < 2; ++k) {
+                                    const int rh = (r + k) & 7;                       // register of the half block: rows 0..15 of the scratch
+                                    s_ep[((rh & 3) + 8 * (rh >> 2) + 4 * lh) * 36 + li] = v[k];
+                                }
+                                if ((r & 7) == 6) {                                 // the half block is complete: 2 x (16-byte read, 16-byte store)
+                                    const int half = r >> 3;
+#pragma unroll
+                                    for (int ps = 0; ps < 2; ++ps) {
+                                        const int pl = ps * 8 + (lane >> 3);
+                                        const f32x4 q = *reinterpret_cast<const f32x4*>(s_ep + pl * 36 + (lane & 7) * 4);
+                                        const int p = cw * 64 + mt * 32 + half * 16 + pl;
+                                        const int b = p / (TH * TW), rr = p % (TH * TW);
+                                        *reinterpret_cast<f32x4*>(d.y + tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps) +
+                                                                  (unsigned)(n0 + nt * 32 + (lane & 7) * 4)) = q;
+                                    }
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const int p = cw * 64 + mt * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2);
+                                    const int b = p / (TH * TW), rr = p % (TH * TW);
+                                    d.y[tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps) + lane_off[nt]] = v[k];
+                                }
                             }
                             s1v[nt] += v;
                             s2v[nt] = __builtin_elementwise_fma(v, v, s2v[nt]);
@@ -641,6 +672,8 @@ void launch_conv_ws(rfi_ctx* ctx, ConvArgs& a, const bf16_t* wB, int P) {
     d.prio = prio;
     static const int diag = getenv("RFI_WS_DIAG") ? atoi(getenv("RFI_WS_DIAG")) : 0;
     d.diag = diag;
+    static const bool no_wide = getenv("RFI_WS_NARROW_EPI") != nullptr;          // A/B runs: dword stores from the accumulators
+    d.wide_epi = !no_wide && a.y.pstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.y.p) & 15) == 0;
     const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cout * 9 * a.Cin;
     std::string label;
     if (ctx->profiling)
