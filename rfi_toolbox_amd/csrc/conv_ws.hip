@@ -474,13 +474,16 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                         // WIDE: the values leave through this wave's LDS scratch as 16-byte stores of 4 channels of one pixel (a
                         // wave store = 8 pixels x 128 bytes): 16 store instructions per tile and lane instead of 64 -- the epilogue
                         // is bound by store ISSUE (~70 cycles each).  Same values, same statistics arithmetic, another route out
-                        const bool wide = C::WIDE_OK && d.wide_epi;
+                        // (compile-time for the float32 64-channel blocks only: in the 128-channel bf16-operand kernels the second
+                        // route costs registers -- 336 bytes of scratch per lane, measured 2 % slower on the ResNet-encoder model)
+                        constexpr bool WIDE_CT = C::WIDE_OK && NTL == 2 && P == 3;
+                        const bool wide = WIDE_CT && d.wide_epi;
                         float* const s_ep = reinterpret_cast<float*>(smem + C::STAT_OFF + cw * C::EPI_WAVE_BYTES);
 #pragma unroll
                         for (int e = 0; e < E; e += 2) {
                             const int nt = e / 32, mt = (e >> 4) & 1, r = e & 15;
                             const f32x2 v = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{bias[nt], bias[nt]};
-                            if (wide) {
+                            if (WIDE_CT && wide) {
 #pragma unroll
                                 for (int k = 0; k < 2; ++k) {
                                     const int rh = (r + k) & 7;                       // register of the half block: rows 0..15 of the scratch

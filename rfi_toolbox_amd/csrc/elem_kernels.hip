@@ -431,6 +431,9 @@ __global__ void channel_sum_kernel(const float* __restrict__ v_, int pstride, in
 }
 
 // ------------------------------------------------------------------ pool
+// SKIP / POOL: which of the two outputs this launch writes (both: one pass; the model may split them over two streams -- the
+// pooled tensor feeds the next conv at once, the skip is not read before the decoder)
+template <bool SKIP, bool POOL>
 __global__ void bn_relu_pool_kernel(const float* __restrict__ y, int N, int H, int W, int C,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     float* __restrict__ skip, int skip_ps, float* __restrict__ pooled, float slope) {
@@ -451,10 +454,10 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ y, int N, int H, i
             const int64_t pix = ((int64_t)n * H + (2 * py + (k >> 1))) * W + (2 * px + (k & 1));
             float a = y[pix * C + c] * sc + sh;
             a = act_f(a, slope);
-            skip[pix * skip_ps + c] = a;
+            if constexpr (SKIP) skip[pix * skip_ps + c] = a;
             best = (k == 0 || a > best) ? a : best;
         }
-        pooled[i] = best;
+        if constexpr (POOL) pooled[i] = best;
     }
 }
 
@@ -1209,12 +1212,12 @@ void launch_bn_stats(rfi_ctx* ctx, const float* y, int64_t M, int C, float* part
 void launch_bn_finalize(rfi_ctx* ctx, const float* partial, int64_t M, int C, const float* gamma,
                           const float* beta, float* running_mean, float* running_var,
                           int ema_repeats, float* mean, float* invstd, float* scale, float* shift,
-                          float* var_out, int records) {
+                          float* var_out, int records, hipEvent_t done) {
     ChanGeom g = geom_rows(M, C);
     ProfScope ps(ctx, FAM_BN);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0, ctx->stream,
-                       reinterpret_cast<const double*>(partial), records > 0 ? records : g.rblocks, C, (double)M, gamma, beta,
-                       running_mean, running_var, ema_repeats, mean, invstd, scale, shift, var_out);
+    hipExtLaunchKernelGGL(bn_finalize_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0, ctx->stream, nullptr, done, 0,
+                          reinterpret_cast<const double*>(partial), records > 0 ? records : g.rblocks, C, (double)M, gamma, beta,
+                          running_mean, running_var, ema_repeats, mean, invstd, scale, shift, var_out);
     check_launch("bn_finalize");
 }
 
@@ -1337,13 +1340,21 @@ void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_w
 void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
                          const float* scale, const float* shift, MutView skip, float* pooled, float slope) {
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    RFI_REQUIRE(skip.p || pooled, "bn_relu_pool: nothing to write");
     {
-        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * 8 + (double)total * 4);
-        hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
-                           N, H, W, C, scale, shift, skip.p, skip.pstride, pooled, slope);
+        ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (skip.p ? 8 : 4) + (pooled ? (double)total * 4 : 0.0));
+        if (skip.p && pooled)
+            hipLaunchKernelGGL((bn_relu_pool_kernel<true, true>), dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
+                               N, H, W, C, scale, shift, skip.p, skip.pstride, pooled, slope);
+        else if (pooled)      // (skip null: the pooled tensor only)
+            hipLaunchKernelGGL((bn_relu_pool_kernel<false, true>), dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
+                               N, H, W, C, scale, shift, nullptr, 0, pooled, slope);
+        else                  // (pooled null: the skip only)
+            hipLaunchKernelGGL((bn_relu_pool_kernel<true, false>), dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y,
+                               N, H, W, C, scale, shift, skip.p, skip.pstride, nullptr, slope);
         check_launch("bn_relu_pool");
     }
-    if ((H & 1) || (W & 1)) {
+    if (skip.p && ((H & 1) || (W & 1))) {
         ProfScope ps(ctx, FAM_ELEMWISE);
         hipLaunchKernelGGL(bn_relu_edge_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(kBlock), 0,
                            ctx->stream, y, N, H, W, C, scale, shift, skip.p, skip.pstride, slope);

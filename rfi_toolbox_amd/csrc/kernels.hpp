@@ -162,7 +162,8 @@ void launch_bn_stats(rfi_ctx* ctx, const float* y, int64_t M, int C, float* part
 void launch_bn_finalize(rfi_ctx* ctx, const float* partial_ws, int64_t M, int C, const float* gamma,
                         const float* beta, float* running_mean, float* running_var,
                         int ema_repeats, float* mean, float* invstd, float* scale, float* shift,
-                        float* var_out, int records = 0);   // records > 0: partials came from a conv epilogue
+                        float* var_out, int records = 0,    // records > 0: partials came from a conv epilogue
+                        hipEvent_t done = nullptr);          // completes with the kernel (a stop event: other streams may wait for scale / shift)
 // eval mode: scale/shift from running statistics
 void launch_bn_eval_coeffs(rfi_ctx* ctx, int C, const float* gamma, const float* beta,
                            const float* running_mean, const float* running_var, float* scale,
@@ -201,7 +202,8 @@ void launch_finish_channel_sums_batched(rfi_ctx* ctx, const FinishSumDesc* descs
 // costs the next kernel ~6.5 us of idle queue (rocprofv3 kernel trace, tools/trace_gaps.py)
 
 // ---------------------------------------------------------------- pool / head / loss
-// a = relu(y*scale+shift) -> skip view (full res) and 2x2 max-pooled p
+// a = relu(y*scale+shift) -> skip view (full res) and 2x2 max-pooled p; skip.p == null or pooled == null: that output is left
+// out (two launches on two streams: model.cpp)
 void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
                          const float* scale, const float* shift, MutView skip, float* pooled, float slope = 0.0f);
 // da[n,y,x,c] = dskip[n,y,x,c] + (argmax of the 2x2 window of a == (y,x) ? dpool : 0)

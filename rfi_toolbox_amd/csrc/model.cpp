@@ -59,6 +59,7 @@ rfi_model::~rfi_model() {
     if (d_sums) ctx->release(d_sums);
     if (d_scalars) ctx->release(d_scalars);
     if (wd_ready) (void)hipEventDestroy(wd_ready);
+    for (hipEvent_t e : skip_done) if (e) (void)hipEventDestroy(e);
 }
 
 // ------------------------------------------------------------------------------------ build
@@ -623,7 +624,7 @@ namespace {
 
 struct Shape { int N, H, W; };
 
-void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y, bool train) {
+void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y, bool train, hipEvent_t coeffs_done = nullptr) {
     ConvArgs a;
     a.x = in;
     a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
@@ -650,14 +651,14 @@ void run_conv_bn(rfi_model* m, ConvBN& c, View in, InXform xf, Shape s, float* Y
         if (a.stats_records == 0) launch_bn_stats(m->ctx, Y, M, c.cout, ws);   // direct-kernel fallback
         launch_bn_finalize(m->ctx, ws, M, c.cout, m->params + c.g_off, m->params + c.be_off,
                            c.running_mean(), c.running_var(), c.ema_repeats, c.mean(), c.invstd(),
-                           c.scale(), c.shift(), nullptr, a.stats_records);
+                           c.scale(), c.shift(), nullptr, a.stats_records, coeffs_done);
         c.nbt += c.ema_repeats;
     } else {
         launch_bn_eval_coeffs(m->ctx, c.cout, m->params + c.g_off, m->params + c.be_off, c.running_mean(),
                               c.running_var(), c.scale(), c.shift());
+        if (coeffs_done) RFI_CHECK_HIP(hipEventRecord(coeffs_done, m->ctx->stream));
     }
 }
-
 
 
 }  // namespace
@@ -688,9 +689,28 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         ConvBN& c2 = convs[2 * (l - 1) + 1];
         run_conv_bn(this, c1, cur, InXform{}, s, buf(encY1[l]), train_mode);
         if (l == 1) side_rebuild_wd();
-        run_conv_bn(this, c2, View{buf(encY1[l]), c1.cout}, bn_xf(c1), s, buf(encY2[l]), train_mode);
-        launch_bn_relu_pool(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
-                            MutView{buf(concat[l]) + c2.cout, 2 * c2.cout}, buf(pool[l]), act_slope);
+        // The pooled tensor feeds the next conv at once; the skip (the activated output in the decoder's concat buffer) is not
+        // read before the decoder.  RFI_POOL_SPLIT=1: the main stream writes the pooled tensor only (a quarter of the bytes)
+        // and the skip is written on the side stream under the next level's matrix-bound convs.  OFF by default: measured
+        // 6.69 against 6.64 ms per step (round 4, two interleaved pairs) -- the second read of Y and the skip write next to
+        // the convs cost them more than the 45 us the main stream saves
+        static const bool no_split = getenv("RFI_POOL_SPLIT") == nullptr;
+        const bool split_pool = !no_split && train_mode && ctx->overlap && ctx->stream == ctx->main_stream && !(s.H & 1) && !(s.W & 1);      // (training passes: the backward pass's side_join recycles the events)
+        const hipEvent_t coeffs = split_pool ? next_fork_event() : nullptr;
+        run_conv_bn(this, c2, View{buf(encY1[l]), c1.cout}, bn_xf(c1), s, buf(encY2[l]), train_mode, coeffs);
+        const MutView skip{buf(concat[l]) + c2.cout, 2 * c2.cout};
+        if (split_pool && coeffs) {
+            launch_bn_relu_pool(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), MutView{}, buf(pool[l]), act_slope);
+            if ((int)skip_done.size() <= l) skip_done.resize(l + 1, nullptr);
+            if (!skip_done[l]) RFI_CHECK_HIP(hipEventCreateWithFlags(&skip_done[l], hipEventDisableTiming));
+            side_begin_after(coeffs);             // (the side stream waits for c2's scale / shift only)
+            struct Back { rfi_ctx* c; ~Back() { c->stream = c->main_stream; } } back{ctx};
+            launch_bn_relu_pool(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), skip, nullptr, act_slope);
+            RFI_CHECK_HIP(hipEventRecord(skip_done[l], ctx->side_stream));
+            skip_pending |= 1u << l;
+        } else {
+            launch_bn_relu_pool(ctx, buf(encY2[l]), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), skip, buf(pool[l]), act_slope);
+        }
         cur = View{buf(pool[l]), c2.cout};
     }
     {
@@ -726,6 +746,10 @@ void rfi_model::forward(const float* x_dev, int n, int h, int w, bool train_mode
         launch_conv(ctx, a);
         ConvBN& c1 = convs[IB + 2 + 2 * k];
         ConvBN& c2 = convs[IB + 2 + 2 * k + 1];
+        if (skip_pending & (1u << l)) {           // the skip half of concat[l] was written on the side stream
+            RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, skip_done[l], 0));
+            skip_pending &= ~(1u << l);
+        }
         run_conv_bn(this, c1, View{buf(concat[l]), 2 * u.cout}, InXform{}, s, buf(decY1[l]), train_mode);
         run_conv_bn(this, c2, View{buf(decY1[l]), c1.cout}, bn_xf(c1), s, buf(decY2[l]), train_mode);
         prevY = buf(decY2[l]);

@@ -147,6 +147,8 @@ struct rfi_model {
     // stream runs the forward pass; the backward pass waits for wd_ready
     hipEvent_t wd_ready = nullptr;
     bool wd_pending = false;
+    std::vector<hipEvent_t> skip_done;      // per encoder level: the skip half of concat[l] is written (side stream, forward pass)
+    unsigned skip_pending = 0;              // levels whose skip write the main stream has not waited for yet
     bool wd_side_todo = false;        // the side half of a split rebuild has not been enqueued yet
     void side_rebuild_wd();
     bool x3_reads_wd = false;         // the batched 3 x bf16 record rebuild reads dgrad-layout filters
