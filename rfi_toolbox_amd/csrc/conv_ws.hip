@@ -479,38 +479,49 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsDev d) {
                         constexpr bool WIDE_CT = C::WIDE_OK && NTL == 2 && P == 3;
                         const bool wide = WIDE_CT && d.wide_epi;
                         float* const s_ep = reinterpret_cast<float*>(smem + C::STAT_OFF + cw * C::EPI_WAVE_BYTES);
+                        if (WIDE_CT && wide) {
+                            // quarter blocks (4 accumulator registers = 8 pixels x 32 channels) alternate between the two halves
+                            // of the scratch: the 16-byte read of quarter qi - 1 is issued in front of quarter qi's arithmetic
+                            // and LDS writes and its global store behind them, so no LDS round trip is waited for
+                            constexpr int NQ = 8 * NTL;
+                            const int pl = lane >> 3, c4 = (lane & 7) * 4;
+                            f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                        for (int e = 0; e < E; e += 2) {
-                            const int nt = e / 32, mt = (e >> 4) & 1, r = e & 15;
-                            const f32x2 v = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{bias[nt], bias[nt]};
-                            if (WIDE_CT && wide) {
+                            for (int qi = 0; qi <= NQ; ++qi) {
+                                if (qi > 0) rq = *reinterpret_cast<const f32x4*>(s_ep + ((qi - 1) & 1) * 288 + pl * 36 + c4);
+                                if (qi < NQ) {
+                                    const int nt = qi >> 3, mt = (qi >> 2) & 1, r0 = (qi & 3) * 4;
 #pragma unroll
-                                for (int k = 0; k < 2; ++k) {
-                                    const int rh = (r + k) & 7;                       // register of the half block: rows 0..15 of the scratch
-                                    s_ep[((rh & 3) + 8 * (rh >> 2) + 4 * lh) * 36 + li] = v[k];
-                                }
-                                if ((r & 7) == 6) {                                 // the half block is complete: 2 x (16-byte read, 16-byte store)
-                                    const int half = r >> 3;
-#pragma unroll
-                                    for (int ps = 0; ps < 2; ++ps) {
-                                        const int pl = ps * 8 + (lane >> 3);
-                                        const f32x4 q = *reinterpret_cast<const f32x4*>(s_ep + pl * 36 + (lane & 7) * 4);
-                                        const int p = cw * 64 + mt * 32 + half * 16 + pl;
-                                        const int b = p / (TH * TW), rr = p % (TH * TW);
-                                        *reinterpret_cast<f32x4*>(d.y + tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps) +
-                                                                  (unsigned)(n0 + nt * 32 + (lane & 7) * 4)) = q;
+                                    for (int k = 0; k < 4; k += 2) {
+                                        const f32x2 v = f32x2{acc[mt][nt][r0 + k], acc[mt][nt][r0 + k + 1]} + f32x2{bias[nt], bias[nt]};
+                                        s_ep[(qi & 1) * 288 + (k + 4 * lh) * 36 + li] = v[0];
+                                        s_ep[(qi & 1) * 288 + (k + 1 + 4 * lh) * 36 + li] = v[1];
+                                        s1v[nt] += v;
+                                        s2v[nt] = __builtin_elementwise_fma(v, v, s2v[nt]);
                                     }
                                 }
-                            } else {
+                                if (qi > 0) {
+                                    const int pq = qi - 1, nt = pq >> 3, mt = (pq >> 2) & 1;
+                                    const int p = cw * 64 + mt * 32 + (pq & 3) * 8 + pl;
+                                    const int b = p / (TH * TW), rr = p % (TH * TW);
+                                    *reinterpret_cast<f32x4*>(d.y + tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps) +
+                                                              (unsigned)(n0 + nt * 32 + c4)) = rq;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < E; e += 2) {
+                                const int nt = e / 32, mt = (e >> 4) & 1, r = e & 15;
+                                const f32x2 v = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{bias[nt], bias[nt]};
 #pragma unroll
                                 for (int k = 0; k < 2; ++k) {
                                     const int p = cw * 64 + mt * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2);
                                     const int b = p / (TH * TW), rr = p % (TH * TW);
                                     d.y[tile_off + (unsigned)(((b * d.H + rr / TW) * d.W + rr % TW) * d.y_ps) + lane_off[nt]] = v[k];
                                 }
+                                s1v[nt] += v;
+                                s2v[nt] = __builtin_elementwise_fma(v, v, s2v[nt]);
                             }
-                            s1v[nt] += v;
-                            s2v[nt] = __builtin_elementwise_fma(v, v, s2v[nt]);
                         }
 #pragma unroll
                         for (int nt = 0; nt < NTL; ++nt) {
