@@ -721,8 +721,8 @@ def main():
         args.dtype = "bf16" if args.workload in ("unet1024", "resnet1024") else "f32"    # (configs[2] names bf16)
     if args.workload == "maskrcnn" and args.dtype in ("bf16", "f32planes"):
         args.dtype = {"bf16": "bf16regs", "f32planes": "f32"}[args.dtype]      # (the detector's models hold float32 tensors)
-    if args.workload.startswith("resnet") and args.dtype in ("bf16", "f32planes"):
-        # the plane data flow exists for the plain U-Net only: this model's bf16 mode rounds operands in registers
+    if args.workload.startswith("resnet") and (args.dtype == "f32planes" or (args.dtype == "bf16" and args.features % 16)):
+        # this model has the bfloat16 data flow only, for widths in whole 16-channel chunks: else operands rounded in registers
         args.dtype = {"bf16": "bf16regs", "f32planes": "f32"}[args.dtype]
 
     from rfi_toolbox_amd import distributed as D

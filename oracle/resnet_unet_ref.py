@@ -107,57 +107,91 @@ def entries(in_channels=3, out_channels=1, init_features=64):
 
 # ------------------------------------------------------------------ functional forward on a state_dict
 class _ConvBF16S(torch.autograd.Function):
-    """bf16-operand convolution with a stride (see unet_ref._ConvBF16)."""
+    """bf16-operand convolution with a stride (see unet_ref._ConvBF16).  ``unet_ref.bf16_operands(round_outputs=True)`` (the
+    library's bfloat16 data flow, widths in whole 16-channel chunks): the output and -- ``round_dx`` -- the input gradient
+    are stored as bfloat16 tensors."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding):
+    def forward(ctx, x, w, stride, padding, round_dx=False):
         ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, padding)
-        return F.conv2d(unet_ref._bf(x), unet_ref._bf(w), None, stride=stride, padding=padding)
+        ctx.cfg = (stride, padding, bool(round_dx))
+        y = F.conv2d(unet_ref._bf(x), unet_ref._bf(w), None, stride=stride, padding=padding)
+        return unet_ref._bf(y) if _storage16() else y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        stride, padding = ctx.cfg
+        stride, padding, round_dx = ctx.cfg
         dyb = unet_ref._bf(dy)
         dx = torch.nn.grad.conv2d_input(x.shape, unet_ref._bf(w), dyb, stride=stride, padding=padding)
         dw = torch.nn.grad.conv2d_weight(unet_ref._bf(x), w.shape, dyb, stride=stride, padding=padding)
-        return dx, dw, None, None
+        return (unet_ref._bf(dx) if round_dx else dx), dw, None, None, None
 
 
-def _conv(x, w, stride, padding):
+def _storage16():
+    """The bfloat16 data flow of the library's ResNet-encoder model: ``bf16_operands(round_outputs=True)`` and a width in
+    whole 16-channel chunks (else the library keeps float32 tensors and rounds operands only)."""
+    return unet_ref._BF16_OPERANDS and unet_ref._BF16_ROUND_OUTPUTS and _WIDTH_16
+
+
+_WIDTH_16 = False           # set by forward()
+
+
+class _StoreBF16(torch.autograd.Function):
+    """A tensor AND its gradient stored as bfloat16 (activations between blocks; the sums of gradient terms that meet there)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return unet_ref._bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return unet_ref._bf(g)
+
+
+def _conv(x, w, stride, padding, round_dx=False):
     if unet_ref._BF16_OPERANDS:
-        return _ConvBF16S.apply(x, w, stride, padding)
+        return _ConvBF16S.apply(x, w, stride, padding, round_dx and _storage16())
     return F.conv2d(x, w, None, stride=stride, padding=padding)
 
 
 def _block(h, st, p, training, bu, tape):
     stride = 2 if f"{p}.downsample.0.weight" in st else 1
-    y = _conv(h, st[f"{p}.conv1.weight"], stride, 1)
+    # bfloat16 flow: conv2's input gradient and conv1's are bfloat16 tensors; the block input's gradient (their sum with the
+    # shortcut's) is rounded where it is masked by the previous block's ReLU; the output is a bfloat16 tensor
+    y = _conv(h, st[f"{p}.conv1.weight"], stride, 1, round_dx=True)
     if tape is not None:
         tape[f"{p}.conv1.out"] = y
     y = torch.relu(unet_ref._bn(y, st, f"{p}.bn1", training, 1, bu, tape, f"{p}.bn1"))
-    y = _conv(y, st[f"{p}.conv2.weight"], 1, 1)
+    y = _conv(y, st[f"{p}.conv2.weight"], 1, 1, round_dx=True)
     if tape is not None:
         tape[f"{p}.conv2.out"] = y
     y = unet_ref._bn(y, st, f"{p}.bn2", training, 1, bu, tape, f"{p}.bn2")
     if stride == 2:
-        s = _conv(h, st[f"{p}.downsample.0.weight"], 2, 0)
+        s = _conv(h, st[f"{p}.downsample.0.weight"], 2, 0)       # (its input gradient leaves inside conv1's: one bfloat16 sum)
         if tape is not None:
             tape[f"{p}.downsample.0.out"] = s
         h = unet_ref._bn(s, st, f"{p}.downsample.1", training, 1, bu, tape, f"{p}.downsample.1")
-    out = torch.relu(y + h)
+    z = y + h
+    if _storage16():
+        z = _StoreBF16.apply(z)       # (rounding commutes with the ReLU and its mask: out and dz are the stored tensors)
+    out = torch.relu(z)
     if tape is not None:
         tape[f"{p}.out"] = out
     return out
 
 
 def forward(state, x_nchw, training=False, buffer_updates=None, tape=None):
+    global _WIDTH_16
     st, bu = state, buffer_updates
+    _WIDTH_16 = st["stem.0.weight"].shape[0] % 16 == 0
+    unet_ref._WIDTHS_16 = _WIDTH_16               # (the decoder half below is unet_ref's)
     h = _conv(x_nchw, st["stem.0.weight"], 1, 1)
     if tape is not None:
         tape["stem.0.out"] = h
     h = torch.relu(unet_ref._bn(h, st, "stem.1", training, 1, bu, tape, "stem.1"))
+    if _storage16():
+        h = _StoreBF16.apply(h)
     skips = []
     for lvl in range(1, 5):
         for b in range(2):
@@ -169,6 +203,8 @@ def forward(state, x_nchw, training=False, buffer_updates=None, tape=None):
         up = unet_ref._convt2x2(h, st[f"decoder{lvl}.up.weight"], st[f"decoder{lvl}.up.bias"])
         h = torch.cat([up, skips[lvl - 1]], dim=1)
         h = unet_ref._double_conv(h, st, f"decoder{lvl}.conv.conv", training, 1, bu, tape)
+    if _storage16() and unet_ref._BF16_ROUND_GRADS and h.requires_grad and st["final_conv.weight"].shape[0] == 1:
+        h.register_hook(unet_ref._bf)     # the gradient the 1x1 head sends into the last DoubleConv (as unet_ref.forward)
     return F.conv2d(h, st["final_conv.weight"], st["final_conv.bias"])
 
 

@@ -675,6 +675,8 @@ int rfi_model_set_compute_dtype(rfi_model* m, int dtype) {
         m->compute_bf16 = dtype == 1 || dtype == 4;
         m->compute_x3 = dtype == 2 || dtype == 3;
         if (m->arch == 0) m->set_planes(dtype == 1 ? 1 : (dtype == 3 ? 3 : 0));
+        // the ResNet-encoder U-Net has the bfloat16 flow only, for widths in whole 16-channel chunks (else: dtype 4's kernels)
+        if (m->arch == 2) m->set_planes(dtype == 1 && m->feat % 16 == 0 ? 1 : 0);
     });
 }
 int rfi_model_set_loss(rfi_model* m, int kind, float alpha, float gamma) {
@@ -1511,6 +1513,35 @@ float* upload_lib_weight(rfi_ctx* ctx, Scratch& s, const float* dev_ref, size_t 
     RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return d;
 }
+
+// ---- the stride-2 layers on the plane kernels (bfloat16 flow of the ResNet-encoder model; impl 6): temporary plane copies
+struct PlaneTmp {                 // a zero-tailed bf16 tensor [pixels][chunks * 16]
+    bf16_t* p = nullptr;
+    int64_t ps = 0;
+    int nchunks = 0;
+    PlaneSeg seg() const { return PlaneSeg{p, ps, nchunks}; }
+};
+PlaneTmp plane_tmp(rfi_ctx* ctx, Scratch& s, int64_t pixels, int C) {
+    PlaneTmp t;
+    t.nchunks = plane_chunks(C);
+    t.ps = (int64_t)t.nchunks * 16;
+    const size_t bytes = (size_t)pixels * t.ps * 2 + 64;
+    t.p = reinterpret_cast<bf16_t*>(s.get((bytes + 3) / 4));
+    RFI_CHECK_HIP(hipMemsetAsync(t.p, 0, bytes, ctx->stream));
+    return t;
+}
+PlaneTmp planes_of(rfi_ctx* ctx, Scratch& s, const float* x, int64_t pixels, int C) {
+    PlaneTmp t = plane_tmp(ctx, s, pixels, C);
+    launch_act_split(ctx, View{x, C}, pixels, C, InXform{}, 1, t.p, t.ps);
+    return t;
+}
+bf16_t* wb_of(rfi_ctx* ctx, Scratch& s, const float* src, int taps, int Cout, int Cin, int seg0, int seg1) {
+    const size_t e = wb_elems(taps, Cout, seg0, seg1, 1);
+    bf16_t* wb = reinterpret_cast<bf16_t*>(s.get((e * 2 + 64 + 3) / 4));
+    RFI_CHECK_HIP(hipMemsetAsync(wb, 0, e * 2 + 64, ctx->stream));
+    launch_weights_to_wb_one(ctx, WBDesc{src, wb, taps, Cout, Cin, {seg0, seg1}, 1});
+    return wb;
+}
 }  // namespace
 
 int rfi_op_conv3x3(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w, int cin,
@@ -1598,6 +1629,23 @@ int rfi_op_conv_s2(rfi_ctx* ctx, int impl, int ksize, const float* x, int n, int
         RFI_REQUIRE(ksize == 3 || ksize == 1, "conv_s2: kernel size 3 or 1");
         ctx->activate();
         Scratch s(ctx);
+        if (impl == IMPL_PLANES_BF16) {           // the strided contraction on the full-resolution planes, bfloat16 output
+            RFI_REQUIRE(cout % 4 == 0, "conv_s2 on planes: cout % 4 == 0");
+            const int64_t Mo = (int64_t)n * (h / 2) * (w / 2);
+            const PlaneTmp xp = planes_of(ctx, s, x, (int64_t)n * h * w, cin);
+            const float* wl = ksize == 3 ? upload_lib_weight(ctx, s, w_oihw, (size_t)9 * cin * cout, false, cout, cin, 3) : w_oihw;
+            PlaneTmp yp = plane_tmp(ctx, s, Mo, cout);
+            PConvArgs a;
+            a.x[0] = xp.seg(); a.nseg = 1; a.P = 1;
+            a.N = n; a.H = h / 2; a.W = w / 2; a.Hin = h; a.Win = w; a.Hout = h / 2; a.Wout = w / 2;
+            a.R = ksize; a.S = 2; a.pad = ksize == 3 ? 1 : 0;
+            a.Cout = cout;
+            a.wB = wb_of(ctx, s, wl, ksize * ksize, cout, cin, cin, 0);
+            a.y16 = yp.p; a.y_pstride = (int)yp.ps;
+            launch_pconv(ctx, a);
+            launch_planes_to_f32(ctx, yp.p, yp.ps, Mo, cout, 1, y, cout);
+            return;
+        }
         float* xs = s.get((size_t)n * h * w * cin);
         launch_s2d(ctx, x, n, h, w, cin, xs);
         ConvArgs a;
@@ -1623,6 +1671,31 @@ int rfi_op_conv_s2_dgrad(rfi_ctx* ctx, int impl, int ksize, const float* dy, int
         RFI_REQUIRE(ksize == 3 || ksize == 1, "conv_s2_dgrad: kernel size 3 or 1");
         ctx->activate();
         Scratch s(ctx);
+        if (impl == IMPL_PLANES_BF16) {           // four 2x2 contractions of dY, one per parity class of the input pixel
+            RFI_REQUIRE(cin % 4 == 0, "conv_s2_dgrad on planes: cin % 4 == 0");
+            const int64_t Mo = (int64_t)n * (h / 2) * (w / 2), Mi = (int64_t)n * h * w;
+            const PlaneTmp dyp = planes_of(ctx, s, dy, Mo, cout);
+            const float* w3 = ksize == 3 ? upload_lib_weight(ctx, s, w_oihw, (size_t)9 * cin * cout, false, cout, cin, 3) : nullptr;
+            float* cls = s.get(s2_class_floats(cout, cin));
+            launch_w_s2_classes(ctx, w3, ksize == 1 ? w_oihw : nullptr, cout, cin, cls);     // (a 1x1 layer: the second K segment of class 0)
+            PlaneTmp dxp = plane_tmp(ctx, s, Mi, cin);
+            bf16_t* dx16 = dxp.p;                 // dense [Mi][cin] bfloat16 (cin % 16 != 0: rows of cin elements inside the allocation)
+            for (int c = 0; c < 4; ++c) {
+                PConvArgs a;
+                a.x[0] = dyp.seg();
+                if (c == 0) a.x[1] = dyp.seg();
+                a.nseg = c == 0 ? 2 : 1; a.P = 1;
+                a.N = n; a.H = h / 2; a.W = w / 2; a.Hin = h / 2; a.Win = w / 2;
+                a.R = 2; a.S = 1; a.pad = 0;
+                a.Cout = cin;
+                a.wB = wb_of(ctx, s, cls + s2_class_offset(c, cout, cin), 4, cin, c == 0 ? 2 * cout : cout, cout, c == 0 ? cout : 0);
+                a.y16 = dx16; a.y_pstride = cin;
+                a.Hout = h; a.Wout = w; a.osy = 2; a.osx = 2; a.ooy = c >> 1; a.oox = c & 1;
+                launch_pconv(ctx, a);
+            }
+            launch_planes_to_f32(ctx, dx16, cin, Mi, cin, 1, dx, cin);
+            return;
+        }
         ConvArgs a;
         a.N = n; a.H = h / 2; a.W = w / 2; a.Hin = h / 2; a.Win = w / 2; a.Cin = cout;
         a.x = View{dy, cout};
@@ -1656,6 +1729,32 @@ int rfi_op_conv_s2_wgrad(rfi_ctx* ctx, int impl, int ksize, const float* x, cons
         RFI_REQUIRE(ksize == 3 || ksize == 1, "conv_s2_wgrad: kernel size 3 or 1");
         ctx->activate();
         Scratch s(ctx);
+        if (impl == IMPL_PLANES_BF16) {           // the strided weight gradient on the full-resolution planes
+            const PlaneTmp xp = planes_of(ctx, s, x, (int64_t)n * h * w, cin);
+            const PlaneTmp dyp = planes_of(ctx, s, dy, (int64_t)n * (h / 2) * (w / 2), cout);
+            PWgradArgs a;
+            a.xop[0] = xp.seg(); a.nseg = 1; a.seg_c[0] = cin;
+            a.yop = dyp.seg(); a.Cy = cout; a.P = 1;
+            a.N = n; a.H = h / 2; a.W = w / 2; a.Hx = h; a.Wx = w;
+            a.R = ksize; a.S = 2; a.pad = ksize == 3 ? 1 : 0;
+            a.tap_stride = (int64_t)cin * cout; a.sy = cin; a.sx = 1;
+            const size_t numel = (size_t)ksize * ksize * cin * cout;
+            a.dw = s.get(numel);
+            a.slab_floats = pwgrad_slab_floats(a);
+            a.slab = s.get(a.slab_floats);
+            launch_pwgrad(ctx, a);
+            if (ksize == 1) {
+                RFI_CHECK_HIP(hipMemcpyAsync(dw_oihw, a.dw, numel * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                return;
+            }
+            std::vector<float> lib(numel), ref(numel);
+            RFI_CHECK_HIP(hipMemcpyAsync(lib.data(), a.dw, numel * 4, hipMemcpyDeviceToHost, ctx->stream));
+            RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            from_lib_conv(lib.data(), cout, cin, 3, ref.data());
+            RFI_CHECK_HIP(hipMemcpyAsync(dw_oihw, ref.data(), numel * 4, hipMemcpyHostToDevice, ctx->stream));
+            RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            return;
+        }
         float* xs = s.get((size_t)n * h * w * cin);
         launch_s2d(ctx, x, n, h, w, cin, xs);
         WgradArgs a;

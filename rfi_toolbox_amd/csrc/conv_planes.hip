@@ -601,14 +601,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
 
 template <int R, int S, int TH, int TW, int WM, int WN, int MT, int NTL, int P, int G, int PAD = 1, bool BWD = false, int OM = -1, bool DB = false>
 void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
-    if constexpr (OM >= 0 && !DB && P == 1 && R == 3) {      // double-buffered staging from 3 K chunks (bf16 flow; RFI_PCONV_DB=0: off)
+    if constexpr (OM >= 0 && !DB && P == 1 && R == 3 && S == 1) {      // double-buffered staging from 3 K chunks (bf16 flow; RFI_PCONV_DB=0: off)
         static const int db = getenv("RFI_PCONV_DB") ? atoi(getenv("RFI_PCONV_DB")) : 3;
         if (db > 0 && d.nkc >= db) return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, BWD, OM, true>(ctx, d);
     }
     if constexpr (OM < 0) {                           // pick the epilogue variant of this launch
         const int om = d.a.y16 ? 2 : d.a.round_y ? 1 : 0;
         const bool b = d.a.bwd_y16 != nullptr;
-        if constexpr (P == 1) {
+        if constexpr (R != 3 || S != 1) {            // the ResNet-style encoder's other shapes: bfloat16 in, bfloat16 out, no extras
+            RFI_REQUIRE(P == 1 && om == 2 && !b, "pconv: strided / 1x1 / 2x2 contractions exist for the bfloat16 flow only (bfloat16 output)");
+            return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, false, 2>(ctx, d);
+        } else if constexpr (P == 1) {
             RFI_REQUIRE(!(b && om == 1), "pconv: the BatchNorm-backward epilogue writes float32 or bfloat16 tensors");
             if (om == 2) return b ? launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, true, 2>(ctx, d)
                                   : launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, false, 2>(ctx, d);
@@ -682,6 +685,17 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
 // kernel sits at 1.0-1.2 PFLOP/s of executed bf16 MFMA on the deep layers (the float32-by-3xbf16 arithmetic: x 1/6),
 // which is where the best known hand-scheduled GEMM of the CDNA4 guide ends on random data (1.32-1.34 PFLOP/s at a
 // sustained 1.9 GHz); the 32-channel layers are bound by HBM (6 B per activation element in, 4 B out).
+// 3x3 stride 2, 1x1 stride 2 (on the full-resolution input: the halo tile simply has the stride) and the 2x2 stride-1
+// contractions of a stride-2 layer's input gradient (one per output parity class)
+template <int R, int S>
+void dispatch_other(rfi_ctx* ctx, PConvDev& d) {
+    const PConvArgs& a = d.a;
+    if (a.Cout >= 64 && a.W >= 32) return launch_cfg<R, S, 8, 32, 4, 1, 2, 2, 1, 1, 1>(ctx, d);
+    if (a.W >= 32) launch_cfg<R, S, 8, 32, 4, 1, 2, 1, 1, 2, 1>(ctx, d);
+    else if (a.W >= 16) launch_cfg<R, S, 16, 16, 4, 1, 2, 1, 1, 2, 1>(ctx, d);
+    else launch_cfg<R, S, 8, 8, 2, 2, 1, 1, 1, 2, 1>(ctx, d);
+}
+
 template <int P>
 void dispatch(rfi_ctx* ctx, PConvDev& d) {
     const PConvArgs& a = d.a;
@@ -704,7 +718,10 @@ void dispatch(rfi_ctx* ctx, PConvDev& d) {
 
 void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
     RFI_REQUIRE(a.P == 1 || a.P == 3, "pconv: planes must be 1 or 3");
-    RFI_REQUIRE(a.R == 3 && a.S == 1 && a.pad == 1, "pconv: 3x3 stride-1 convolutions only");
+    const bool plain = a.R == 3 && a.S == 1 && a.pad == 1;
+    const bool s2 = a.R == 3 && a.S == 2 && a.pad == 1, p2 = a.R == 1 && a.S == 2 && a.pad == 0, c2 = a.R == 2 && a.S == 1 && a.pad == 0;
+    RFI_REQUIRE(plain || ((s2 || p2 || c2) && a.P == 1),
+                "pconv: 3x3 stride 1 pad 1; bfloat16 flow also 3x3 stride 2 pad 1, 1x1 stride 2, 2x2 stride 1 pad 0");
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cout > 0 && a.nseg >= 1 && a.nseg <= 2, "pconv: empty shape");
     PConvDev d;
     d.a = a;
@@ -717,23 +734,27 @@ void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
         RFI_REQUIRE(bytes + 64 < ((int64_t)1 << 32), "pconv: input tensor too large for 32-bit byte offsets");
         d.x_zero[s] = (unsigned)bytes;                 // every plane tensor is allocated with a zeroed 64-byte tail
     }
-    const int64_t wbytes = (int64_t)wb_elems(9, a.Cout, 16 * a.x[0].nchunks, a.nseg > 1 ? 16 * a.x[1].nchunks : 0, a.P) * 2;
+    const int64_t wbytes = (int64_t)wb_elems(a.R * a.R, a.Cout, 16 * a.x[0].nchunks, a.nseg > 1 ? 16 * a.x[1].nchunks : 0, a.P) * 2;
     RFI_REQUIRE(wbytes + 64 < ((int64_t)1 << 32), "pconv: filter tensor too large");
     d.wb_zero = (unsigned)wbytes;                      // ... and so is every wB tensor
     static const int diag = getenv("RFI_PCONV_DIAG") ? atoi(getenv("RFI_PCONV_DIAG")) : 0;
     d.diag = diag;
     d.stamps = nullptr;
     RFI_REQUIRE((int64_t)a.N * a.Hout * a.Wout * a.y_pstride < (int64_t)1 << 31, "pconv: output too large for 32-bit offsets");
-    const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cout * 9 * 16.0 * d.nkc;
+    const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cout * (a.R * a.R) * 16.0 * d.nkc;
     std::string label;
     if (ctx->profiling)
         label = "pconv N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" + std::to_string(a.W) + " k" +
-                std::to_string(d.nkc * 16) + "->" + std::to_string(a.Cout) + (a.P == 3 ? " 3xbf16" : " bf16");
+                std::to_string(d.nkc * 16) + "->" + std::to_string(a.Cout) + (a.P == 3 ? " 3xbf16" : " bf16") +
+                (plain ? "" : " r" + std::to_string(a.R) + "s" + std::to_string(a.S));
     // algorithmic HBM bytes: the plane input (2 P bytes per value), the float32 output, the filters
     const double bytes = (double)a.N * a.Hin * a.Win * d.nkc * 16.0 * 2 * a.P + (a.y16 ? 2.0 : 4.0) * a.N * a.H * a.W * a.Cout +
                          (a.bwd_y16 ? 2.0 * a.N * a.H * a.W * a.Cout : 0.0) + (double)wbytes;     // (+ the bf16 Y of the BatchNorm-backward epilogue)
     ProfScope ps(ctx, FAM_CONV_MFMA, flops, bytes, label);
-    if (a.P == 3) dispatch<3>(ctx, d);
+    if (s2) dispatch_other<3, 2>(ctx, d);
+    else if (p2) dispatch_other<1, 2>(ctx, d);
+    else if (c2) dispatch_other<2, 1>(ctx, d);
+    else if (a.P == 3) dispatch<3>(ctx, d);
     else dispatch<1>(ctx, d);
     a.stats = d.a.stats;
     a.stats_records = d.a.stats_records;

@@ -52,7 +52,7 @@ rfi_model::~rfi_model() {
     if (dbias_pool) ctx->release(dbias_pool);
     if (dbias_descs) ctx->release(dbias_descs);
     if (ws_descs) ctx->release(ws_descs);
-    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool, grad_acc})   // (rs_wpool: arch 2 and 5)
+    for (float* p : {params, grads, adam_m, adam_v, chan_pool, wd_pool, w3_pool, rs_wpool, rs_cls_pool, grad_acc})   // (rs_wpool: arch 2 and 5)
         if (p) ctx->release(p);
     if (relayout_descs) ctx->release(relayout_descs);
     if (x3_descs) ctx->release(x3_descs);
@@ -70,7 +70,8 @@ void rfi_model::build() {
         planesP = std::string(e) == "bf16" ? 1 : (std::string(e) == "f32planes" ? 3 : 0);
     }
     if (const char* e = getenv("RFI_BN_FUSE")) fuse_bn_bwd = e[0] == '1';
-    if (arch != 0) planesP = 0;                       // the plane data flow exists for the plain U-Net only
+    if (arch != 0 && !(arch == 2 && planesP == 1 && feat % 16 == 0)) planesP = 0;     // the plane data flow: the plain U-Net; the
+                                                                                      // ResNet-encoder U-Net's bfloat16 flow
     if (arch == 1) return build_cnn3();
     if (arch == 3 || arch == 4) return build_mask();
     if (arch == 5) return build_backbone();
@@ -227,6 +228,7 @@ void rfi_model::set_planes(int P) {
     if (wb_descs) { ctx->release(wb_descs); wb_descs = nullptr; }
     planesP = P;
     wd_dirty = true;
+    pN = 0;                                       // (prepare() again: the two flows of the ResNet-encoder model own different tensors)
 }
 
 void rfi_model::reset_channel_state() {
@@ -403,7 +405,7 @@ void rfi_model::prepare(int n, int h, int w) {
         RFI_CHECK_HIP(hipMemcpyAsync(dbias_descs, hd.data(), hd.size() * sizeof(FinishSumDesc), hipMemcpyHostToDevice, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // hd goes out of scope
     }
-    if (arch == 2) prepare_resnet(n, h, w);
+    if (arch == 2 && !planesP) prepare_resnet(n, h, w);
     pN = n; pH = h; pW = w;
 }
 
@@ -522,8 +524,8 @@ void rfi_model::refresh_dgrad_weights() {
         if (x3_n) launch_weights_to_x3_batched(ctx, static_cast<const X3Desc*>(x3_descs), x3_n, x3_bytes);
         x3_fresh = true;
     }
-    if (arch == 2) refresh_resnet_weights();               // 2x2 forms of the stride-2 filters
-    if (planesP && arch == 0) refresh_plane_weights();     // B-operand-order filters of the plane kernels
+    if (arch == 2 && !planesP) refresh_resnet_weights();   // 2x2 forms of the stride-2 filters
+    if (planesP) refresh_plane_weights();                  // B-operand-order filters of the plane kernels
     wd_dirty = false;
 }
 

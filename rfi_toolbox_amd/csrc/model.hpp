@@ -279,6 +279,20 @@ struct rfi_model {
     bool g16_flow = false;
     std::vector<int> g16A, g16B, g16pool;       // g16A: dA of the second convs where an elementwise kernel produces it (head, max-pool backward)
     int g16BottB = -1;
+    // ResNet-style encoder on the bf16 flow (arch 2, feat % 16 == 0; model_planes.cpp): indices into pl.  Every block owns its
+    // raw conv outputs, its activation planes and its dY planes (the side stream's weight gradients read them until side_join)
+    struct ResPlanes {
+        int Y1 = -1, Y2 = -1, Yd = -1, A1 = -1, A = -1, dY1 = -1, dY2 = -1, dYd = -1;
+        rfi::bf16_t* wBcls[4] = {nullptr, nullptr, nullptr, nullptr};     // stride 2: input-gradient filters per parity class
+        float* cls = nullptr;                                             // ... and their float32 table (launch_w_s2_classes)
+    };
+    std::vector<ResPlanes> rpb;
+    int rpStemY = -1, rpA0 = -1, rpdY0 = -1, rp_dA1 = -1, rp_dX = -1;
+    int rp_dz[2] = {-1, -1};
+    float* rs_cls_pool = nullptr;
+    bool resnet_planes() const { return arch == 2 && planesP == 1; }
+    void forward_resnet_planes(rfi::PlaneSeg& cur, int n, int h, int w, bool train_mode);
+    void backward_resnet_planes(int n, int h, int w);
     rfi::bf16_t* wb_pool = nullptr;
     void* wb_descs = nullptr;
     int wb_n = 0;

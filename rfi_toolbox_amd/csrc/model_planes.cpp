@@ -44,7 +44,8 @@ void PlaneBuf::free() {
 }  // namespace rfi
 
 void rfi_model::prepare_planes(int n, int h, int w) {
-    const int P = planesP, D = depth;
+    const int P = planesP, D = depth, IB = i_bott;
+    const bool rs = arch == 2;                     // ResNet-style encoder: its own tensors instead of the U-Net encoder's
     if (pl.empty()) {
         auto mk = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) { pl.emplace_back(); v[l] = (int)pl.size() - 1; } };
         mk(pA1e); mk(pSkip); mk(pPool); mk(pUp); mk(pA1d); mk(pdYa); mk(pdYb); mk(pdYaE); mk(pdYbE);
@@ -58,14 +59,15 @@ void rfi_model::prepare_planes(int n, int h, int w) {
     for (int l = 1; l <= D; ++l) {
         const int64_t M = (int64_t)n * (h >> (l - 1)) * (w >> (l - 1));
         const int C = feat << (l - 1);
-        for (int i : {pA1e[l], pSkip[l], pUp[l], pA1d[l], pdYa[l], pdYb[l], pdYaE[l], pdYbE[l]}) pl[i].ensure(ctx, M, C, P);
-        pl[pPool[l]].ensure(ctx, M / 4, C, P);
+        for (int i : {pSkip[l], pUp[l], pA1d[l], pdYa[l], pdYb[l]}) pl[i].ensure(ctx, M, C, P);
+        if (!rs) for (int i : {pA1e[l], pdYaE[l], pdYbE[l]}) pl[i].ensure(ctx, M, C, P);
+        if (!rs || l == D) pl[pPool[l]].ensure(ctx, M / 4, C, P);
         bufs[upf[l]].ensure(ctx, (size_t)M * C);
     }
     const int64_t Mb = (int64_t)n * (h >> D) * (w >> D);
     for (int i : {pA1b, pdYbottA, pdYbottB}) pl[i].ensure(ctx, Mb, feat << D, P);
     static const bool no_y16 = getenv("RFI_NO_Y16") != nullptr;                 // A/B runs: float32 conv outputs
-    y16_flow = P == 1 && feat % 4 == 0 && !no_y16;
+    y16_flow = P == 1 && feat % 4 == 0 && (!no_y16 || rs);
     if (y16_flow) {
         if (yB1 < 0) {
             auto mk1 = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) { pl.emplace_back(); v[l] = (int)pl.size() - 1; } };
@@ -75,13 +77,14 @@ void rfi_model::prepare_planes(int n, int h, int w) {
         }
         for (int l = 1; l <= D; ++l) {
             const int64_t M = (int64_t)n * (h >> (l - 1)) * (w >> (l - 1));
-            for (int i : {yE1[l], yE2[l], yD1[l]}) pl[i].ensure(ctx, M, feat << (l - 1), 1);
+            pl[yD1[l]].ensure(ctx, M, feat << (l - 1), 1);
+            if (!rs) for (int i : {yE1[l], yE2[l]}) pl[i].ensure(ctx, M, feat << (l - 1), 1);
         }
         pl[yB1].ensure(ctx, Mb, feat << D, 1);
         pl[yD2top].ensure(ctx, M1, feat, 1);
     }
     static const bool no_g16 = getenv("RFI_NO_G16") != nullptr;                 // A/B runs: float32 gradient tensors
-    g16_flow = y16_flow && feat % 16 == 0 && !no_g16;
+    g16_flow = y16_flow && feat % 16 == 0 && (!no_g16 || rs);
     if (g16_flow) {
         if (g16BottB < 0) {
             auto mk1 = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) { pl.emplace_back(); v[l] = (int)pl.size() - 1; } };
@@ -90,30 +93,54 @@ void rfi_model::prepare_planes(int n, int h, int w) {
         }
         for (int l = 1; l <= D; ++l) {
             const int64_t M = (int64_t)n * (h >> (l - 1)) * (w >> (l - 1));
-            pl[g16A[l]].ensure(ctx, M, feat << (l - 1), 1);
+            if (!rs || l == 1) pl[g16A[l]].ensure(ctx, M, feat << (l - 1), 1);
             pl[g16B[l]].ensure(ctx, M, feat << (l - 1), 1);
-            pl[g16pool[l]].ensure(ctx, M / 4, feat << (l - 1), 1);
+            if (!rs || l == D) pl[g16pool[l]].ensure(ctx, M / 4, feat << (l - 1), 1);
         }
         pl[g16BottB].ensure(ctx, Mb, feat << D, 1);
+    }
+    if (rs) {
+        RFI_REQUIRE(P == 1 && y16_flow && g16_flow, "UNetResNet18 on the plane kernels: bfloat16 flow with init_features % 16 == 0 only");
+        auto one = [&]() { pl.emplace_back(); return (int)pl.size() - 1; };
+        if (rpStemY < 0) {
+            rpStemY = one(); rpA0 = one(); rpdY0 = one(); rp_dA1 = one(); rp_dX = one(); rp_dz[0] = one(); rp_dz[1] = one();
+            if (rpb.empty()) rpb.assign(blocks.size(), ResPlanes());
+            for (size_t bi = 0; bi < blocks.size(); ++bi) {
+                ResPlanes& r = rpb[bi];
+                const ResBlock& b = blocks[bi];
+                r.Y1 = one(); r.Y2 = one(); r.A1 = one(); r.dY1 = one(); r.dY2 = one();
+                // a stage's output is the decoder's skip tensor; the last stage's is pooled (and copied there) by one kernel
+                r.A = ((bi & 1) && b.level < D) ? pSkip[b.level] : one();
+                if (b.stride == 2) { r.Yd = one(); r.dYd = one(); }
+            }
+        }
+        for (int i : {rpStemY, rpA0, rpdY0, rp_dA1, rp_dX, rp_dz[0], rp_dz[1]}) pl[i].ensure(ctx, M1, feat, 1);   // (M C halves per level)
+        for (size_t bi = 0; bi < blocks.size(); ++bi) {
+            const ResBlock& b = blocks[bi];
+            const ResPlanes& r = rpb[bi];
+            const int64_t M = (int64_t)n * (h >> (b.level - 1)) * (w >> (b.level - 1));
+            for (int i : {r.Y1, r.Y2, r.A1, r.A, r.dY1, r.dY2}) pl[i].ensure(ctx, M, b.cout, 1);
+            if (b.stride == 2) for (int i : {r.Yd, r.dYd}) pl[i].ensure(ctx, M, b.cout, 1);
+        }
     }
     // weight-gradient slabs of the plane kernel
     size_t slab_need = 0;
     for (size_t ci = 0; ci < convs.size(); ++ci) {
-        int lvl;
-        if ((int)ci < 2 * D) lvl = (int)ci / 2 + 1;
-        else if ((int)ci < 2 * D + 2) lvl = D + 1;
-        else lvl = D - ((int)ci - (2 * D + 2)) / 2;
+        const ConvBN& c = convs[ci];
+        const int lvl = c.level;
         PWgradArgs a;
-        const bool two = (int)ci >= 2 * D + 2 && (((int)ci - (2 * D + 2)) & 1) == 0;      // decoder conv1: [up | skip]
+        const bool two = (int)ci >= IB + 2 && (((int)ci - (IB + 2)) & 1) == 0;      // decoder conv1: [up | skip]
         a.nseg = two ? 2 : 1;
-        a.seg_c[0] = two ? convs[ci].cin / 2 : convs[ci].cin;
-        a.seg_c[1] = two ? convs[ci].cin / 2 : 0;
+        a.seg_c[0] = two ? c.cin / 2 : c.cin;
+        a.seg_c[1] = two ? c.cin / 2 : 0;
         a.xop[0].nchunks = plane_chunks(a.seg_c[0]);
         a.xop[1].nchunks = two ? plane_chunks(a.seg_c[1]) : 0;
-        a.yop.nchunks = plane_chunks(convs[ci].cout);
-        a.Cy = convs[ci].cout;
-        a.N = n; a.H = h >> (lvl - 1); a.W = w >> (lvl - 1); a.Hx = a.H; a.Wx = a.W;
-        a.tap_stride = (int64_t)convs[ci].cin_p * convs[ci].cout;
+        a.yop.nchunks = plane_chunks(c.cout);
+        a.Cy = c.cout;
+        a.N = n; a.H = h >> (lvl - 1); a.W = w >> (lvl - 1); a.Hx = a.H * c.stride; a.Wx = a.W * c.stride;
+        a.R = c.R; a.S = c.stride; a.pad = c.R == 3 ? 1 : 0;
+        if (c.stride == 2 || c.R != 3) a.P = 1;
+        a.tap_stride = (int64_t)c.cin_p * c.cout;
         slab_need = std::max(slab_need, pwgrad_slab_floats(a));
     }
     if (bufs[ws_slab].n < slab_need + 16) bufs[ws_slab].ensure(ctx, slab_need + 16);
@@ -122,37 +149,69 @@ void rfi_model::prepare_planes(int n, int h, int w) {
 // filters of every 3x3 layer in MFMA B-operand order, both directions, rebuilt with the dgrad layouts after each
 // optimiser step by ONE batched launch
 void rfi_model::refresh_plane_weights() {
-    const int P = planesP, D = depth;
+    const int P = planesP, IB = i_bott;
+    auto two_seg = [&](size_t ci) { return (int)ci >= IB + 2 && (((int)ci - (IB + 2)) & 1) == 0; };      // decoder conv1: [up | skip]
+    auto has_wBd = [&](const ConvBN& c) { return c.R == 3 && c.stride == 1; };      // (the other shapes' input gradients: class tables)
+    if (arch == 2 && rpb.empty()) rpb.assign(blocks.size(), ResPlanes());
     if (!wb_pool) {
-        size_t need = 0;
+        size_t need = 0, cls_need = 0;
         for (size_t ci = 0; ci < convs.size(); ++ci) {
             const ConvBN& c = convs[ci];
-            const bool two = (int)ci >= 2 * D + 2 && (((int)ci - (2 * D + 2)) & 1) == 0;
-            need += wb_elems(9, c.cout, two ? c.cin / 2 : c.cin_p, two ? c.cin / 2 : 0, P) + 32;
-            need += wb_elems(9, c.cin_p, c.cout, 0, P) + 32;
+            const bool two = two_seg(ci);
+            need += wb_elems(c.R * c.R, c.cout, two ? c.cin / 2 : c.cin_p, two ? c.cin / 2 : 0, P) + 32;
+            if (has_wBd(c)) need += wb_elems(9, c.cin_p, c.cout, 0, P) + 32;
         }
+        for (auto& b : blocks)
+            if (b.stride == 2) {
+                need += wb_elems(4, b.cin, b.cout, b.cout, 1) + 32 + 3 * (wb_elems(4, b.cin, b.cout, 0, 1) + 32);
+                cls_need += s2_class_floats(b.cout, b.cin);
+            }
         wb_pool = static_cast<bf16_t*>(ctx->alloc(need * 2));
         RFI_CHECK_HIP(hipMemsetAsync(wb_pool, 0, need * 2, ctx->stream));       // the zero tails stay zero
+        if (cls_need && !rs_cls_pool) rs_cls_pool = static_cast<float*>(ctx->alloc(cls_need * sizeof(float)));
         std::vector<WBDesc> hd;
-        size_t o = 0;
+        size_t o = 0, co = 0;
         wb_bytes = 0;
         for (size_t ci = 0; ci < convs.size(); ++ci) {
             ConvBN& c = convs[ci];
-            const bool two = (int)ci >= 2 * D + 2 && (((int)ci - (2 * D + 2)) & 1) == 0;
+            const bool two = two_seg(ci);
+            const int taps = c.R * c.R;
             c.wBf = wb_pool + o;
-            const size_t ef = wb_elems(9, c.cout, two ? c.cin / 2 : c.cin_p, two ? c.cin / 2 : 0, P);
+            const size_t ef = wb_elems(taps, c.cout, two ? c.cin / 2 : c.cin_p, two ? c.cin / 2 : 0, P);
             o += ef + 32;
-            hd.push_back(WBDesc{params + c.w_off, c.wBf, 9, c.cout, c.cin_p, {two ? c.cin / 2 : c.cin_p, two ? c.cin / 2 : 0}, P});
+            hd.push_back(WBDesc{params + c.w_off, c.wBf, taps, c.cout, c.cin_p, {two ? c.cin / 2 : c.cin_p, two ? c.cin / 2 : 0}, P});
+            wb_bytes += 2.0 * ef + 4.0 * taps * c.cin_p * c.cout;
+            if (!has_wBd(c)) continue;
             c.wBd = wb_pool + o;
             const size_t ed = wb_elems(9, c.cin_p, c.cout, 0, P);
             o += ed + 32;
             hd.push_back(WBDesc{c.wd, c.wBd, 9, c.cin_p, c.cout, {c.cout, 0}, P});
-            wb_bytes += 2.0 * (ef + ed) + 8.0 * 9 * c.cin_p * c.cout;
+            wb_bytes += 2.0 * ed + 4.0 * 9 * c.cin_p * c.cout;
+        }
+        for (size_t bi = 0; bi < blocks.size(); ++bi) {
+            const ResBlock& b = blocks[bi];
+            if (b.stride != 2) continue;
+            ResPlanes& r = rpb[bi];
+            r.cls = rs_cls_pool + co;
+            co += s2_class_floats(b.cout, b.cin);
+            for (int c = 0; c < 4; ++c) {
+                r.wBcls[c] = wb_pool + o;
+                const size_t e = wb_elems(4, b.cin, b.cout, c == 0 ? b.cout : 0, 1);
+                o += e + 32;
+                hd.push_back(WBDesc{r.cls + s2_class_offset(c, b.cout, b.cin), r.wBcls[c], 4, b.cin, c == 0 ? 2 * b.cout : b.cout,
+                                    {b.cout, c == 0 ? b.cout : 0}, 1});
+                wb_bytes += 2.0 * e + 16.0 * b.cin * b.cout * (c == 0 ? 2 : 1);
+            }
         }
         wb_n = (int)hd.size();
         wb_descs = ctx->alloc(hd.size() * sizeof(WBDesc));
         RFI_CHECK_HIP(hipMemcpyAsync(wb_descs, hd.data(), hd.size() * sizeof(WBDesc), hipMemcpyHostToDevice, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // hd goes out of scope
+    }
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        const ResBlock& b = blocks[bi];
+        if (b.stride == 2)
+            launch_w_s2_classes(ctx, params + convs[b.c1].w_off, params + convs[b.cd].w_off, b.cout, b.cin, rpb[bi].cls);
     }
     launch_weights_to_wb(ctx, static_cast<const WBDesc*>(wb_descs), wb_n, wb_bytes);
 }
@@ -170,20 +229,22 @@ struct YT {
     YRef ref() const { return h ? YRef(h->p, h->pstride) : YRef(f); }
 };
 
+// (s: the OUTPUT grid; a stride-2 layer reads an input of twice that size)
 void run_pconv_bn(rfi_model* m, ConvBN& c, const PlaneSeg* in, int nseg, Shape s, YT Yt, bool train) {
     float* Y = Yt.f;
     PConvArgs a;
     a.x[0] = in[0];
     if (nseg > 1) a.x[1] = in[1];
     a.nseg = nseg; a.P = m->planesP;
-    a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
+    a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H * c.stride; a.Win = s.W * c.stride;
+    a.R = c.R; a.S = c.stride; a.pad = c.R == 3 ? 1 : 0;
     a.Cout = c.cout;
     a.wB = c.wBf;
     a.bias = m->params + c.b_off;
     if (Yt.h) { a.y16 = Yt.h->p; a.y_pstride = (int)Yt.h->pstride; }
     else { a.y = Y; a.y_pstride = c.cout; a.round_y = m->y16_flow; }
     a.Hout = s.H; a.Wout = s.W;
-    a.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
+    a.algo_flops = 2.0 * s.N * s.H * s.W * (double)(c.R * c.R) * c.cin * c.cout;
     float* ws = m->buf(m->ws_red);
     if (train) {
         a.stats = reinterpret_cast<double*>(ws);
@@ -217,14 +278,61 @@ void double_conv(rfi_model* m, ConvBN& c1, ConvBN& c2, const PlaneSeg* in, int n
 
 }  // namespace
 
+// ResNet-style encoder (model_resnet.cpp states the topology) on the bf16 flow.  Every tensor is bfloat16: raw conv outputs
+// (statistics from the conv epilogues), activations as the operands of the next contraction.  Stride-2 layers read the
+// full-resolution planes directly (the LDS halo tile has the stride): no space-to-depth copy.  A stage's output IS the
+// decoder's skip tensor.  cur <- the pooled output of the last stage.
+void rfi_model::forward_resnet_planes(PlaneSeg& cur, int n, int h, int w, bool train) {
+    const int D = depth;
+    {
+        ConvBN& c = convs[0];
+        YT y; y.h = &pl[rpStemY];
+        run_pconv_bn(this, c, &cur, 1, Shape{n, h, w}, y, train);
+        launch_act_split(ctx, View{nullptr, c.cout}, (int64_t)n * h * w, c.cout, bn_xf(c), 1, pl[rpA0].p, pl[rpA0].pstride, pl[rpStemY].p,
+                         pl[rpStemY].pstride);
+    }
+    const PlaneBuf* a_in = &pl[rpA0];
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        ResBlock& b = blocks[bi];
+        const ResPlanes& r = rpb[bi];
+        ConvBN& c1 = convs[b.c1];
+        ConvBN& c2 = convs[b.c2];
+        Shape s{n, h >> (b.level - 1), w >> (b.level - 1)};
+        const int64_t M = (int64_t)s.N * s.H * s.W;
+        const PlaneSeg in = seg_of(*a_in);
+        YT y1, y2; y1.h = &pl[r.Y1]; y2.h = &pl[r.Y2];
+        run_pconv_bn(this, c1, &in, 1, s, y1, train);
+        if (b.stride == 2) { YT yd; yd.h = &pl[r.Yd]; run_pconv_bn(this, convs[b.cd], &in, 1, s, yd, train); }
+        launch_act_split(ctx, View{nullptr, c1.cout}, M, c1.cout, bn_xf(c1), 1, pl[r.A1].p, pl[r.A1].pstride, pl[r.Y1].p, pl[r.Y1].pstride);
+        const PlaneSeg a1 = seg_of(pl[r.A1]);
+        run_pconv_bn(this, c2, &a1, 1, s, y2, train);
+        if (b.stride == 2) {
+            ConvBN& cd = convs[b.cd];
+            launch_bn_add_relu16(ctx, pl[r.Y2].p, pl[r.Y2].pstride, c2.scale(), c2.shift(), pl[r.Yd].p, pl[r.Yd].pstride, cd.scale(), cd.shift(),
+                                 M, b.cout, pl[r.A].p, pl[r.A].pstride);
+        } else {
+            launch_bn_add_relu16(ctx, pl[r.Y2].p, pl[r.Y2].pstride, c2.scale(), c2.shift(), a_in->p, a_in->pstride, nullptr, nullptr, M, b.cout,
+                                 pl[r.A].p, pl[r.A].pstride);
+        }
+        a_in = &pl[r.A];
+    }
+    // MaxPool2d(2) of the last stage (identity "BatchNorm": scale 1, shift 0; the values are >= 0), + its copy as the skip
+    const ResBlock& lb = blocks.back();
+    launch_bn_relu_pool_planes(ctx, nullptr, n, h >> (D - 1), w >> (D - 1), lb.cout, rs_ones, rs_zeros, 0.0f, 1, pl[pSkip[D]].p,
+                               pl[pSkip[D]].pstride, pl[pPool[D]].p, pl[pPool[D]].pstride, a_in->p, a_in->pstride);
+    cur = seg_of(pl[pPool[D]]);
+}
+
 void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool train_mode) {
     const int D = depth, P = planesP;
     prepare_planes(n, h, w);
     launch_act_split(ctx, View{x_dev, in_ch}, (int64_t)n * h * w, in_ch, InXform{}, P, pl[pXin].p, pl[pXin].pstride);
     PlaneSeg cur = seg_of(pl[pXin]);
+    const int IB = i_bott;
     // a raw conv output: the bfloat16 tensor pl[hi] when the bf16 flow is on (hi >= 0), else the float32 tensor bufs[fi]
     auto yt = [&](int fi, int hi) { YT y; if (y16_flow && hi >= 0) y.h = &pl[hi]; else y.f = buf(fi); return y; };
-    for (int l = 1; l <= D; ++l) {
+    if (arch == 2) forward_resnet_planes(cur, n, h, w, train_mode);
+    else for (int l = 1; l <= D; ++l) {
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
@@ -237,11 +345,11 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
     }
     {
         Shape s{n, h >> D, w >> D};
-        double_conv(this, convs[2 * D], convs[2 * D + 1], &cur, 1, s, yt(bottY1, y16_flow ? yB1 : -1), pl[pA1b],
+        double_conv(this, convs[IB], convs[IB + 1], &cur, 1, s, yt(bottY1, y16_flow ? yB1 : -1), pl[pA1b],
                     yt(bottY2, -1), train_mode);            // (read by the transposed conv: float32 tensor)
     }
     const float* prevY = buf(bottY2);
-    ConvBN* prevBN = &convs[2 * D + 1];
+    ConvBN* prevBN = &convs[IB + 1];
     for (int l = D; l >= 1; --l) {
         const int k = D - l;
         UpConv& u = ups[k];
@@ -274,8 +382,8 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
         const int64_t M = (int64_t)s.N * s.H * s.W;
         if (!direct)
             launch_act_split(ctx, View{buf(upf[l]), u.cout}, M, u.cout, InXform{}, P, pl[pUp[l]].p, pl[pUp[l]].pstride);
-        ConvBN& c1 = convs[2 * D + 2 + 2 * k];
-        ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
+        ConvBN& c1 = convs[IB + 2 + 2 * k];
+        ConvBN& c2 = convs[IB + 2 + 2 * k + 1];
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};      // cat([up, skip], dim=1) as two K-segments
         // (decoder l's second output feeds the next transposed conv -- float32 tensor -- except the last: the head)
         double_conv(this, c1, c2, in2, 2, s, yt(decY1[l], y16_flow ? yD1[l] : -1), pl[pA1d[l]],
@@ -315,19 +423,26 @@ struct GT {
 // `next` (with its raw bfloat16 output next_Y): the layer whose activated output dx is the gradient of -- its BatchNorm-
 // backward sums are then folded into the input-gradient conv's epilogue; returns the number of records left for it in
 // the workspace (0: none, the caller's next call runs bn_bwd_reduce).
+// slope_override: the activation slope of THIS layer's output instead of the model's (1: the output has no activation of its
+// own -- a residual branch, whose masked gradient dA already is dz).  Layers with a stride or other taps (ResNet-style
+// encoder): s is the OUTPUT grid, `in` the input of stride times that size, dx must be null (the caller runs the input
+// gradient by parity classes).
 int backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg* in, int nseg, Shape s,
-                      GT dx, PlaneBuf& dYp, int have_records = 0, ConvBN* next = nullptr, YRef next_Y = YRef((const float*)nullptr)) {
+                      GT dx, PlaneBuf& dYp, int have_records = 0, ConvBN* next = nullptr, YRef next_Y = YRef((const float*)nullptr),
+                      const float* slope_override = nullptr) {
     rfi_ctx* ctx = m->ctx;
     const int64_t M = (int64_t)s.N * s.H * s.W;
     float* ws = m->buf(m->ws_red);
+    const float slope = slope_override ? *slope_override : m->act_slope;
+    RFI_REQUIRE((c.R == 3 && c.stride == 1) || !dx, "backward_pconv_bn: strided / 1x1 layers have no single input-gradient launch");
     if (have_records > 0)           // the kernel that produced dA left the BatchNorm-backward sums in the workspace
         launch_bn_bwd_finalize_records(ctx, ws, have_records, M, c.cout, c.c1(), c.c2(), m->grads + c.g_off, m->grads + c.be_off);
     else
         launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(), c.c2(),
-                             m->grads + c.g_off, m->grads + c.be_off, m->act_slope);
+                             m->grads + c.g_off, m->grads + c.be_off, slope);
     const hipEvent_t dy_done = m->next_fork_event();         // completes with the kernel that writes dY
     launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
-                        m->params + c.g_off, c.c1(), c.c2(), ws, m->grads + c.b_off, m->act_slope, dYp.p, dYp.pstride,
+                        m->params + c.g_off, c.c1(), c.c2(), ws, c.has_bias ? m->grads + c.b_off : nullptr, slope, dYp.p, dYp.pstride,
                         m->planesP, dy_done);
     PWgradArgs wa;
     wa.xop[0] = in[0];
@@ -339,11 +454,12 @@ int backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg* 
     wa.yop = PlaneSeg{dYp.p, dYp.pstride, dYp.nchunks};
     wa.Cy = c.cout;
     wa.P = m->planesP;
-    wa.N = s.N; wa.H = s.H; wa.W = s.W; wa.Hx = s.H; wa.Wx = s.W;
+    wa.N = s.N; wa.H = s.H; wa.W = s.W; wa.Hx = s.H * c.stride; wa.Wx = s.W * c.stride;
+    wa.R = c.R; wa.S = c.stride; wa.pad = c.R == 3 ? 1 : 0;
     wa.dw = m->grads + c.w_off;
     wa.tap_stride = (int64_t)c.cin_p * c.cout;
     wa.sy = c.cin_p; wa.sx = 1;
-    wa.algo_flops = 2.0 * s.N * s.H * s.W * 9.0 * c.cin * c.cout;
+    wa.algo_flops = 2.0 * s.N * s.H * s.W * (double)(c.R * c.R) * c.cin * c.cout;
     wa.slab = m->buf(m->ws_slab);
     wa.slab_floats = m->bufs[m->ws_slab].n;
     {
@@ -370,7 +486,7 @@ int backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg* 
             a.bwd_yps = next_Y.stride(next->cout);
             a.bwd_scale = next->scale(); a.bwd_shift = next->shift();
             a.bwd_mean = next->mean(); a.bwd_invstd = next->invstd();
-            a.bwd_slope = m->act_slope;
+            a.bwd_slope = m->act_slope;                       // (`next` is a conv + BatchNorm + activation layer)
         }
         launch_pconv(ctx, a);
         return a.stats_records;
@@ -380,9 +496,92 @@ int backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg* 
 
 }  // namespace
 
+// Backward pass of the ResNet-style encoder on the bf16 flow.  Per BasicBlock (g = gradient w.r.t. the block's output, a sum of
+// up to three tensors that is never materialised):
+//   dz  = g * (a_out > 0)                                           one pass (relu_mask_sum16), read by both BatchNorm branches
+//   main branch     BN2 backward (identity activation) -> dY2 planes; conv2's weight gradient (side stream) and input gradient dA1
+//                   with BN1's backward sums folded into its epilogue; BN1 backward -> dY1 planes; conv1's weight gradient
+//   identity block  dX = conv1's input gradient; the block's input gradient is dX + dz (the next relu_mask_sum16 adds them)
+//   stride-2 block  projection: BNd backward of the same dz -> dYd planes, its weight gradient; the input gradient of conv1 AND
+//                   of the projection as four 2x2 contractions, one per parity class of the input pixel, written with output
+//                   stride 2 (class 0 takes the projection as a second K segment): no zero-stuffed tensor, no scatter pass
+void rfi_model::backward_resnet_planes(int n, int h, int w) {
+    const int D = depth;
+    const float one = 1.0f;
+    // gradient w.r.t. the last stage's output: skip gradient + max-pool routing of dpool (-> rp_dX, as "dX from above")
+    {
+        const ResBlock& lb = blocks.back();
+        const PlaneBuf& A = pl[rpb.back().A];
+        launch_pool_bwd_merge(ctx, YRef(A.p, A.pstride), n, h >> (D - 1), w >> (D - 1), lb.cout, rs_ones, rs_zeros,
+                              View{buf(dconcat[D]) + lb.cout, 2 * lb.cout}, YRef(pl[g16pool[D]].p, pl[g16pool[D]].pstride), nullptr, 0.0f,
+                              pl[rp_dX].p);
+    }
+    // (the scratch tensors rp_dA1 / rp_dX / rp_dz serve every level: dense [M][C] views of them)
+    auto view = [&](int idx, int C) { PlaneBuf v = pl[idx]; v.pstride = C; v.nchunks = C / 16; return v; };
+    const bf16_t* g0 = pl[rp_dX].p;               // the terms of g (dense bfloat16 [M][C]) ...
+    const bf16_t* g1 = nullptr;
+    View g2{};                                    // ... and the decoder's skip gradient (float32 view), at stage boundaries
+    for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
+        ResBlock& b = blocks[bi];
+        const ResPlanes& r = rpb[bi];
+        ConvBN& c1 = convs[b.c1];
+        ConvBN& c2 = convs[b.c2];
+        Shape s{n, h >> (b.level - 1), w >> (b.level - 1)};
+        const int64_t M = (int64_t)s.N * s.H * s.W;
+        const PlaneBuf& a_in = bi == 0 ? pl[rpA0] : pl[rpb[bi - 1].A];
+        PlaneBuf& dz = pl[rp_dz[bi & 1]];
+        launch_relu_mask_sum16(ctx, g0, b.cout, g1, b.cout, g2, pl[r.A].p, pl[r.A].pstride, M, b.cout, dz.p, b.cout);
+        const YRef dzr(dz.p, (int64_t)b.cout);
+        const PlaneSeg a1 = seg_of(pl[r.A1]);
+        PlaneBuf dA1v = view(rp_dA1, b.cout), dXv = view(rp_dX, b.cin);
+        const int rec1 = backward_pconv_bn(this, c2, dzr, YRef(pl[r.Y2].p, pl[r.Y2].pstride), &a1, 1, s, GT(dA1v), pl[r.dY2], 0, &c1,
+                                           YRef(pl[r.Y1].p, pl[r.Y1].pstride), &one);
+        const PlaneSeg in = seg_of(a_in);
+        const YRef dA1(pl[rp_dA1].p, (int64_t)b.cout);
+        if (b.stride == 1) {
+            backward_pconv_bn(this, c1, dA1, YRef(pl[r.Y1].p, pl[r.Y1].pstride), &in, 1, s, GT(dXv), pl[r.dY1], rec1);
+            g0 = pl[rp_dX].p; g1 = dz.p; g2 = View{};
+        } else {
+            ConvBN& cd = convs[b.cd];
+            backward_pconv_bn(this, c1, dA1, YRef(pl[r.Y1].p, pl[r.Y1].pstride), &in, 1, s, GT(nullptr), pl[r.dY1], rec1);
+            backward_pconv_bn(this, cd, dzr, YRef(pl[r.Yd].p, pl[r.Yd].pstride), &in, 1, s, GT(nullptr), pl[r.dYd], 0, nullptr,
+                              YRef((const float*)nullptr), &one);
+            for (int c = 0; c < 4; ++c) {
+                PConvArgs a;
+                a.x[0] = seg_of(pl[r.dY1]);
+                if (c == 0) a.x[1] = seg_of(pl[r.dYd]);
+                a.nseg = c == 0 ? 2 : 1; a.P = 1;
+                a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
+                a.R = 2; a.S = 1; a.pad = 0;
+                a.Cout = b.cin;
+                a.wB = r.wBcls[c];
+                a.y16 = pl[rp_dX].p; a.y_pstride = b.cin;
+                a.Hout = 2 * s.H; a.Wout = 2 * s.W;
+                a.osy = 2; a.osx = 2; a.ooy = c >> 1; a.oox = c & 1;
+                // (true work: 9 taps of conv1 + the projection over the M output pixels; the zero taps of the 2x2 forms are not counted)
+                a.algo_flops = c == 0 ? 2.0 * M * (9.0 * b.cin * b.cout + (double)b.cin * b.cout) : 0.0;
+                launch_pconv(ctx, a);
+            }
+            g0 = pl[rp_dX].p; g1 = nullptr;
+            g2 = View{buf(dconcat[b.level - 1]) + b.cin, 2 * b.cin};      // the previous stage's output is also a skip
+        }
+        bucket_ready(c1.w_off, (size_t)(bi + 1 < (int)blocks.size() ? convs[blocks[bi + 1].c1].w_off : convs[i_bott].w_off));
+    }
+    {                                             // stem: g = dX + dz of the first block, materialised once
+        ConvBN& c = convs[0];
+        Shape s{n, h, w};
+        const int64_t M = (int64_t)n * h * w;
+        PlaneBuf& g = pl[rp_dz[1]];               // (block 0 used rp_dz[0])
+        launch_relu_mask_sum16(ctx, g0, c.cout, g1, c.cout, View{}, nullptr, 0, M, c.cout, g.p, c.cout);
+        const PlaneSeg in = seg_of(pl[pXin]);
+        backward_pconv_bn(this, c, YRef(g.p, (int64_t)c.cout), YRef(pl[rpStemY].p, pl[rpStemY].pstride), &in, 1, s, GT(nullptr), pl[rpdY0]);
+        bucket_ready(0, convs[blocks[0].c1].w_off);
+    }
+}
+
 void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
     (void)x_dev;
-    const int D = depth;
+    const int D = depth, IB = i_bott;
     // every layer owns its dY plane tensor and the other side-stream inputs (forward planes, dconcat, raw conv outputs)
     // are not rewritten before side_join(): the main stream never has to wait for a weight gradient inside the pass
     static const int bound_env = getenv("RFI_SIDE_BOUND") ? atoi(getenv("RFI_SIDE_BOUND")) : 0;
@@ -399,7 +598,7 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     if (head_sigmoid) launch_sigmoid_bwd(ctx, buf(probs), M1 * out_ch, buf(dlogits));
     int head_records = 0;
     {
-        ConvBN& last = convs[2 * D + 2 + 2 * (D - 1) + 1];
+        ConvBN& last = convs[IB + 2 + 2 * (D - 1) + 1];
         head_records = launch_head_bwd(ctx, yr(decY2[1], y16_flow ? yD2top : -1), M1, feat, last.scale(), last.shift(), params + head_w_off, out_ch,
                                        buf(dlogits), buf(gA[1]), buf(ws_red) + bn_bwd_ws_floats(M1, feat), grads + head_w_off,
                                        grads + head_b_off, act_slope, last.mean(), last.invstd(), buf(ws_red),
@@ -409,8 +608,8 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         const int k = D - l;
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         Shape sin{n, h >> l, w >> l};
-        ConvBN& c1 = convs[2 * D + 2 + 2 * k];
-        ConvBN& c2 = convs[2 * D + 2 + 2 * k + 1];
+        ConvBN& c1 = convs[IB + 2 + 2 * k];
+        ConvBN& c2 = convs[IB + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         const PlaneSeg a1 = seg_of(pl[pA1d[l]]);
         const int rec1 = backward_pconv_bn(this, c2, gt(gA[l], g16_flow && out_ch == 1 && l == 1 ? g16A[1] : -1).ref(),
@@ -422,7 +621,7 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
                           rec1);
         // ConvTranspose: dUp = dconcat[..., 0:C]; the round-1 kernels on float32 tensors
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
-        ConvBN& prevBN = (l == D) ? convs[2 * D + 1] : convs[2 * D + 2 + 2 * (k - 1) + 1];
+        ConvBN& prevBN = (l == D) ? convs[IB + 1] : convs[IB + 2 + 2 * (k - 1) + 1];
         View dUp{buf(dconcat[l]), 2 * u.cout};
         launch_channel_sum(ctx, dUp, (int64_t)s.N * s.H * s.W, u.cout, buf(ws_red), grads + u.b_off);
         WgradArgs wa;
@@ -462,13 +661,14 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     {                                             // bottleneck
         Shape s{n, h >> D, w >> D};
         const PlaneSeg a1 = seg_of(pl[pA1b]), p4 = seg_of(pl[pPool[D]]);
-        const int rec1 = backward_pconv_bn(this, convs[2 * D + 1], buf(gBottA), buf(bottY2), &a1, 1, s, gt(gBottB, g16_flow ? g16BottB : -1),
-                                           pl[pdYbottA], 0, &convs[2 * D], yr(bottY1, y16_flow ? yB1 : -1));
-        backward_pconv_bn(this, convs[2 * D], gt(gBottB, g16_flow ? g16BottB : -1).ref(), yr(bottY1, y16_flow ? yB1 : -1), &p4, 1, s,
+        const int rec1 = backward_pconv_bn(this, convs[IB + 1], buf(gBottA), buf(bottY2), &a1, 1, s, gt(gBottB, g16_flow ? g16BottB : -1),
+                                           pl[pdYbottA], 0, &convs[IB], yr(bottY1, y16_flow ? yB1 : -1));
+        backward_pconv_bn(this, convs[IB], gt(gBottB, g16_flow ? g16BottB : -1).ref(), yr(bottY1, y16_flow ? yB1 : -1), &p4, 1, s,
                           gt(dpool[D], g16_flow ? g16pool[D] : -1), pl[pdYbottB], rec1);
-        bucket_ready(convs[2 * D].w_off, ups[0].w_off);
+        bucket_ready(convs[IB].w_off, ups[0].w_off);
     }
-    for (int l = D; l >= 1; --l) {                // encoders, deep to shallow
+    if (arch == 2) backward_resnet_planes(n, h, w);
+    else for (int l = D; l >= 1; --l) {           // encoders, deep to shallow
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];

@@ -36,6 +36,21 @@ void launch_act_split(rfi_ctx* ctx, View x, int64_t M, int C, InXform xf, int P,
 void launch_bn_relu_pool_planes(rfi_ctx* ctx, const float* y, int N, int H, int W, int C, const float* scale,
                                 const float* shift, float slope, int P, bf16_t* skip, int64_t skip_pstride,
                                 bf16_t* pooled, int64_t pooled_pstride, const bf16_t* y16 = nullptr, int64_t y16_pstride = 0);
+// ResNet-style encoder on the bf16 data flow (bfloat16 [pixel][>= C] tensors, 16-byte aligned rows, C % 8 == 0):
+// out = relu(y * scale + shift + shortcut), shortcut = s * s_scale + s_shift (a projection's raw output) or s (s_scale null)
+void launch_bn_add_relu16(rfi_ctx* ctx, const bf16_t* y, int64_t y_ps, const float* scale, const float* shift, const bf16_t* s, int64_t s_ps,
+                          const float* s_scale, const float* s_shift, int64_t M, int C, bf16_t* out, int64_t out_ps);
+// dz = (g0 + g1 + g2) * (a > 0): g1 / g2 (a float32 view) / the mask are optional
+void launch_relu_mask_sum16(rfi_ctx* ctx, const bf16_t* g0, int64_t p0, const bf16_t* g1, int64_t p1, View g2, const bf16_t* a, int64_t pa,
+                            int64_t M, int C, bf16_t* dz, int64_t pz);
+// input gradient of a 3x3 stride-2 pad-1 conv as four 2x2 stride-1 pad-0 contractions of dY, one per parity class
+// c = 2 py + px of the input pixel (written with output stride 2): float32 filters [class][tap t = 2 ty + tx][Cin][K] with
+// K = Cout (class 0: 2 Cout -- its second K segment is the 1x1 stride-2 projection `wp` [Cout][Cin], whose input gradient
+// lands on the same pixels; null: zeros; w3 may be null too).  Tap (ty, tx) of class (py, px) is filter tap r = py ? (ty ? 0 : 2) : (ty ? none : 1)
+// (and the same along x); taps without a filter entry are zero.  s2_class_floats: floats of the whole table.
+static inline size_t s2_class_floats(int Cout, int Cin) { return (size_t)20 * Cin * Cout; }
+static inline size_t s2_class_offset(int c, int Cout, int Cin) { return c == 0 ? 0 : (size_t)(8 + 4 * (c - 1)) * Cin * Cout; }
+void launch_w_s2_classes(rfi_ctx* ctx, const float* w3, const float* wp, int Cout, int Cin, float* dst);
 // planes -> fp32 (tests / debugging): sum of the pieces
 void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, int64_t M, int C, int P, float* out,
                           int out_pstride);

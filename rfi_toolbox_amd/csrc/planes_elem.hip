@@ -171,6 +171,81 @@ __global__ __launch_bounds__(256) void bn_relu_pool_planes_kernel(const float* _
     }
 }
 
+
+// ---- ResNet-style encoder on the bf16 data flow: bfloat16 [pixel][>= C] tensors with 16-byte aligned rows, C % 8 == 0
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __builtin_bit_cast(float, t[e] << 16);
+        v[2 * e + 1] = __builtin_bit_cast(float, t[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<u32x4*>(p) = u32x4{cvt_pair(v[0], v[1]), cvt_pair(v[2], v[3]), cvt_pair(v[4], v[5]), cvt_pair(v[6], v[7])};
+}
+// out = relu(y * sc + sh + shortcut), shortcut = s * ssc + ssh (a projection's raw output) or s itself (ssc == null)
+__global__ __launch_bounds__(256) void bn_add_relu16_kernel(const bf16_t* __restrict__ y, int64_t yp, const float* __restrict__ sc,
+                                                           const float* __restrict__ sh, const bf16_t* __restrict__ s, int64_t sp,
+                                                           const float* __restrict__ ssc, const float* __restrict__ ssh, int64_t M, int C,
+                                                           bf16_t* __restrict__ out, int64_t op) {
+    const int groups = C / 8;
+    const int64_t total = M * groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % groups) * 8;
+        const int64_t m = i / groups;
+        float v[8], u[8], a[8], b[8];
+        load8(y + m * yp + c0, v);
+        load8(s + m * sp + c0, u);
+        load8(sc + c0, a);
+        load8(sh + c0, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * a[e] + b[e];
+        if (ssc) {
+            load8(ssc + c0, a);
+            load8(ssh + c0, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = u[e] * a[e] + b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + u[e], 0.0f);
+        store8(out + m * op + c0, v);
+    }
+}
+// dz = (g0 + g1 + g2) * (a > 0)   (g1, g2, a optional; g2 a float32 view)
+__global__ __launch_bounds__(256) void relu_mask_sum16_kernel(const bf16_t* __restrict__ g0, int64_t p0, const bf16_t* __restrict__ g1, int64_t p1,
+                                                             const float* __restrict__ g2, int64_t p2, const bf16_t* __restrict__ a, int64_t pa,
+                                                             int64_t M, int C, bf16_t* __restrict__ dz, int64_t pz) {
+    const int groups = C / 8;
+    const int64_t total = M * groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % groups) * 8;
+        const int64_t m = i / groups;
+        float v[8], u[8];
+        load8(g0 + m * p0 + c0, v);
+        if (g1) {
+            load8(g1 + m * p1 + c0, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += u[e];
+        }
+        if (g2) {
+            load8(g2 + m * p2 + c0, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += u[e];
+        }
+        if (a) {
+            load8(a + m * pa + c0, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = u[e] > 0.0f ? v[e] : 0.0f;
+        }
+        store8(dz + m * pz + c0, v);
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void planes_to_f32_kernel(const bf16_t* __restrict__ in, int64_t ip, int64_t M, int C,
                                                             float* __restrict__ out, int op) {
@@ -183,6 +258,27 @@ __global__ __launch_bounds__(256) void planes_to_f32_kernel(const bf16_t* __rest
 #pragma unroll
         for (int p = P - 1; p >= 0; --p) s += __builtin_bit_cast(float, (unsigned)q[p * 16] << 16);   // small pieces first
         out[m * op + c] = s;
+    }
+}
+
+
+__global__ __launch_bounds__(256) void w_s2_classes_kernel(const float* __restrict__ w3, const float* __restrict__ wp, int Cout, int Cin,
+                                                          float* __restrict__ dst) {
+    const int64_t total = (int64_t)20 * Cin * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c0 = (int64_t)8 * Cin * Cout, per = (int64_t)4 * Cin * Cout;
+        const int c = i < c0 ? 0 : 1 + (int)((i - c0) / per);
+        const int64_t j = c == 0 ? i : (i - c0) % per;
+        const int K = c == 0 ? 2 * Cout : Cout;
+        const int k = (int)(j % K);
+        const int ci = (int)((j / K) % Cin);
+        const int t = (int)(j / ((int64_t)K * Cin));
+        const int py = c >> 1, px = c & 1, ty = t >> 1, tx = t & 1;
+        const int r = py ? (ty ? 0 : 2) : (ty ? -1 : 1), s = px ? (tx ? 0 : 2) : (tx ? -1 : 1);
+        float v = 0.0f;
+        if (k < Cout) { if (w3 && r >= 0 && s >= 0) v = w3[((int64_t)(r * 3 + s) * Cout + k) * Cin + ci]; }
+        else if (t == 0 && wp) v = wp[(int64_t)(k - Cout) * Cin + ci];
+        dst[i] = v;
     }
 }
 
@@ -263,6 +359,35 @@ void launch_bn_relu_pool_planes(rfi_ctx* ctx, const float* y, int N, int H, int 
     check_launch("bn_relu_pool_planes");
 }
 
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+void launch_bn_add_relu16(rfi_ctx* ctx, const bf16_t* y, int64_t y_ps, const float* scale, const float* shift, const bf16_t* s, int64_t s_ps,
+                          const float* s_scale, const float* s_shift, int64_t M, int C, bf16_t* out, int64_t out_ps) {
+    RFI_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && y_ps % 8 == 0 && s_ps % 8 == 0 && out_ps % 8 == 0 && al16(y) && al16(s) && al16(out) &&
+                    al16(scale) && al16(shift) && (!s_scale || (al16(s_scale) && al16(s_shift))),
+                "bn_add_relu16: channels in whole groups of 8, 16-byte aligned rows");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * 6);
+    int64_t blocks = cdiv(M * (C / 8), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_add_relu16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, y, y_ps, scale, shift, s, s_ps, s_scale, s_shift,
+                       M, C, out, out_ps);
+    check_launch("bn_add_relu16");
+}
+
+void launch_relu_mask_sum16(rfi_ctx* ctx, const bf16_t* g0, int64_t p0, const bf16_t* g1, int64_t p1, View g2, const bf16_t* a, int64_t pa,
+                            int64_t M, int C, bf16_t* dz, int64_t pz) {
+    RFI_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && p0 % 8 == 0 && (!g1 || p1 % 8 == 0) && (!g2.p || g2.pstride % 4 == 0) && (!a || pa % 8 == 0) &&
+                    pz % 8 == 0 && al16(g0) && al16(g1) && al16(g2.p) && al16(a) && al16(dz),
+                "relu_mask_sum16: channels in whole groups of 8, 16-byte aligned rows");
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * (4 + (g1 ? 2 : 0) + (g2.p ? 4 : 0) + (a ? 2 : 0)));
+    int64_t blocks = cdiv(M * (C / 8), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(relu_mask_sum16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g0, p0, g1, p1, g2.p, (int64_t)g2.pstride, a, pa,
+                       M, C, dz, pz);
+    check_launch("relu_mask_sum16");
+}
+
 void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, int64_t M, int C, int P, float* out,
                           int out_pstride) {
     const int64_t total = M * C;
@@ -272,6 +397,16 @@ void launch_planes_to_f32(rfi_ctx* ctx, const bf16_t* in, int64_t in_pstride, in
     if (P == 3) hipLaunchKernelGGL(planes_to_f32_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in, in_pstride, M, C, out, out_pstride);
     else hipLaunchKernelGGL(planes_to_f32_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in, in_pstride, M, C, out, out_pstride);
     check_launch("planes_to_f32");
+}
+
+
+void launch_w_s2_classes(rfi_ctx* ctx, const float* w3, const float* wp, int Cout, int Cin, float* dst) {
+    const int64_t total = (int64_t)20 * Cin * Cout;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)total * 4 + 40.0 * Cin * Cout);
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(w_s2_classes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w3, wp, Cout, Cin, dst);
+    check_launch("w_s2_classes");
 }
 
 void launch_weights_to_wb(rfi_ctx* ctx, const WBDesc* descs_dev, int n, double total_bytes) {

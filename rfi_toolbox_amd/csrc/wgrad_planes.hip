@@ -297,6 +297,7 @@ struct Plan { int nsplit; int64_t slab_stride; };
 // layers: their maps are small, so staging them three times costs less than two thirds of the slab traffic saves)
 template <int BYB, int BXB>
 int tap_groups(const PWgradArgs& a, int nkx) {
+    if (a.R != 3) return 1;
     static const int force = getenv("RFI_PWGRAD_TG") ? atoi(getenv("RFI_PWGRAD_TG")) : 0;     // A/B runs: 1 or 3
     if (force == 1 || force == 3) return force;
     const int chunks = (int)cdiv(plane_chunks(a.Cy), 2 * BYB) * (int)cdiv(nkx, 2 * BXB);
@@ -315,7 +316,9 @@ Plan plan_cfg(const PWgradArgs& a, int nkx) {
 template <int R, int S, int BYB, int BXB, int TH, int TW, int P, int TG = 0>
 void launch_cfg(rfi_ctx* ctx, PWgradDev& d) {
     if constexpr (TG == 0) {                          // pick the tap grouping of this launch
-        if (tap_groups<BYB, BXB>(d.a, d.nkx) == 3) return launch_cfg<R, S, BYB, BXB, TH, TW, P, 3>(ctx, d);
+        if constexpr (R == 3) {
+            if (tap_groups<BYB, BXB>(d.a, d.nkx) == 3) return launch_cfg<R, S, BYB, BXB, TH, TW, P, 3>(ctx, d);
+        }
         return launch_cfg<R, S, BYB, BXB, TH, TW, P, 1>(ctx, d);
     }
     constexpr int TGK = TG == 0 ? 1 : TG;
@@ -351,14 +354,14 @@ void launch_cfg(rfi_ctx* ctx, PWgradDev& d) {
 
 enum { SEL_PLAN = 0, SEL_LAUNCH = 1 };
 
-template <int P>
+template <int P, int R = 3, int S = 1>
 Plan select(rfi_ctx* ctx, PWgradDev& d, int what) {
     const PWgradArgs& a = d.a;
     const bool y2 = plane_chunks(a.Cy) > 2, x2 = d.nkx > 2;       // more than one 32-channel block
 #define RFI_PW(BYB_, BXB_, TH_, TW_)                                                  \
     do {                                                                              \
-        if (what == SEL_LAUNCH) launch_cfg<3, 1, BYB_, BXB_, TH_, TW_, P>(ctx, d);    \
-        return plan_cfg<3, 1, BYB_, BXB_, TH_, TW_>(a, d.nkx);                        \
+        if (what == SEL_LAUNCH) launch_cfg<R, S, BYB_, BXB_, TH_, TW_, P>(ctx, d);    \
+        return plan_cfg<R, S, BYB_, BXB_, TH_, TW_>(a, d.nkx);                        \
     } while (0)
     if (y2 && x2) RFI_PW(2, 2, 8, 8);
     if (y2) RFI_PW(2, 1, 8, 8);
@@ -366,6 +369,22 @@ Plan select(rfi_ctx* ctx, PWgradDev& d, int what) {
     if (a.W >= 16) RFI_PW(1, 1, 8, 16);
     RFI_PW(1, 1, 16, 8);
 #undef RFI_PW
+}
+
+// the shape classes of a launch: 3x3 stride 1 pad 1 (both arithmetics); bfloat16 flow also 3x3 stride 2 pad 1 and 1x1 stride 2
+// (the ResNet-style encoder's stage transitions, on the full-resolution Xop: the halo tile has the stride)
+int shape_class(const PWgradArgs& a) {
+    if (a.R == 3 && a.S == 1 && a.pad == 1) return 0;
+    if (a.P == 1 && a.R == 3 && a.S == 2 && a.pad == 1) return 1;
+    if (a.P == 1 && a.R == 1 && a.S == 2 && a.pad == 0) return 2;
+    return -1;
+}
+Plan select_any(rfi_ctx* ctx, PWgradDev& d, int what) {
+    switch (shape_class(d.a)) {
+        case 1: return select<1, 3, 2>(ctx, d, what);
+        case 2: return select<1, 1, 2>(ctx, d, what);
+        default: return d.a.P == 3 ? select<3>(ctx, d, what) : select<1>(ctx, d, what);
+    }
 }
 
 void fill_dev(const PWgradArgs& a, PWgradDev& d) {
@@ -390,20 +409,19 @@ void fill_dev(const PWgradArgs& a, PWgradDev& d) {
 size_t pwgrad_slab_floats(const PWgradArgs& a) {
     PWgradDev d;
     fill_dev(a, d);
-    const Plan p = select<3>(nullptr, d, SEL_PLAN);
+    const Plan p = select_any(nullptr, d, SEL_PLAN);
     return (size_t)p.nsplit * p.slab_stride;
 }
 
 void launch_pwgrad(rfi_ctx* ctx, const PWgradArgs& a) {
     RFI_REQUIRE(a.P == 1 || a.P == 3, "pwgrad: planes must be 1 or 3");
-    RFI_REQUIRE(a.R == 3 && a.S == 1 && a.pad == 1, "pwgrad: 3x3 stride-1 convolutions only");
+    RFI_REQUIRE(shape_class(a) >= 0, "pwgrad: 3x3 stride 1 pad 1; bfloat16 flow also 3x3 stride 2 pad 1 and 1x1 stride 2");
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cy > 0 && a.seg_c[0] > 0, "pwgrad: empty shape");
     RFI_REQUIRE(std::max(a.yop.nchunks, std::max(a.xop[0].nchunks, a.nseg > 1 ? a.xop[1].nchunks : 0)) * a.P * 2 <= 256,
                 "pwgrad: more than 42 (P = 3) / 128 (P = 1) chunks per operand segment");
     PWgradDev d;
     fill_dev(a, d);
-    if (a.P == 3) select<3>(ctx, d, SEL_LAUNCH);
-    else select<1>(ctx, d, SEL_LAUNCH);
+    select_any(ctx, d, SEL_LAUNCH);
 }
 
 // Bridge for callers that hold float32 NHWC tensors (the kernel-level C ABI)

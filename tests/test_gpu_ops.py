@@ -392,6 +392,43 @@ def test_stride2_convolutions(shape, ksize):
         assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, f"wgrad impl={impl}"
 
 
+IMPL_PBF16 = 6    # plane kernels, bfloat16 flow (the kernels of the bfloat16 compute mode)
+
+
+@pytest.mark.parametrize("shape", [sh for sh in S2_SHAPES if sh[3] % 4 == 0 and sh[4] % 4 == 0] + [(1, 64, 128, 64, 128), (1, 32, 64, 16, 64)])
+@pytest.mark.parametrize("ksize", [3, 1])
+def test_stride2_convolutions_on_the_plane_kernels(shape, ksize):
+    """The stage transitions of the ResNet-style encoder in the bfloat16 flow: the strided 3x3 / 1x1 contractions read the
+    full-resolution bf16 planes (no space-to-depth copy), the input gradient is four 2x2 contractions of dY (one per parity
+    class of the input pixel, the 1x1 layer's as a second K segment of class 0), the weight gradient strides its halo tile.
+    Against torch on the bf16-ROUNDED operands (products of two bf16 values are exact in float32: the differences are the
+    summation order and, for y / dx, the rounding of the stored result to bfloat16)."""
+    n, h, w, cin, cout = shape
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    g = torch.Generator().manual_seed(13 + hash(shape) % 1000)
+    x = bf(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = bf(torch.randn(cout, cin, ksize, ksize, generator=g) / (ksize * cin ** 0.5)).requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride=2, padding=ksize // 2)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    c = ctx()
+    dxd, dwd, ddy = c.to_device(nhwc(x.detach())), c.to_device(wt.detach().numpy()), c.to_device(nhwc(dy))
+    out = c.empty((n, h // 2, w // 2, cout))
+    check(lib.rfi_op_conv_s2(c.handle, IMPL_PBF16, ksize, P(dxd), n, h, w, cin, P(dwd), cout, P(out)))
+    want = nhwc(y.detach())
+    assert np.abs(out.numpy() - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-6, "fwd"
+    assert np.array_equal(out.numpy(), nhwc(bf(nchw(out.numpy())))), "the output holds bf16 values"
+    gx = c.empty((n, h, w, cin))
+    check(lib.rfi_op_conv_s2_dgrad(c.handle, IMPL_PBF16, ksize, P(ddy), n, h, w, cout, P(dwd), cin, P(gx)))
+    want = nhwc(x.grad)
+    assert np.abs(gx.numpy() - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-6, "dgrad"
+    if ksize == 1:
+        assert not gx.numpy()[:, 1::2].any() and not gx.numpy()[:, :, 1::2].any()      # pixels no output reads: exact zeros
+    gw = c.empty((cout, cin, ksize, ksize))
+    check(lib.rfi_op_conv_s2_wgrad(c.handle, IMPL_PBF16, ksize, P(dxd), P(ddy), n, h, w, cin, cout, P(gw)))
+    assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, "wgrad"
+
+
 @pytest.mark.parametrize("shape", [(1, 8, 32, 64, 64), (2, 4, 4, 64, 64), (1, 8, 32, 3136, 128), (250, 1, 1, 3136, 128), (1, 8, 32, 256, 1024),
                                    (1, 8, 32, 2048, 512), (1, 8, 32, 64, 32), (3, 5, 7, 32, 96)])
 @pytest.mark.parametrize("xform", [False, True])
