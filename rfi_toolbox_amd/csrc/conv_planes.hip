@@ -292,71 +292,107 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                                     a.bwd_y16 + (size_t)((ct.n * a.H + oy) * a.W + ox) * a.bwd_yps + co);
                         }
         }
+        if constexpr (VEC) {
+            // Quarter blocks (4 accumulator registers = 8 pixel rows x 32 channels) alternate between the two halves of the
+            // scratch: the 16-byte read of quarter qi - 1 is issued in front of quarter qi's LDS writes and its arithmetic and
+            // store behind them, so no LDS round trip is waited for (measured on the 64-channel layers at 1024 x 1024: the
+            // epilogue was 10 k of a tile's 26 k cycles with one exposed round trip per half block)
+            constexpr int NQ = NTL * MT * 4;
+            const int pl = lane >> 3, g4 = (lane & 7) * 4;
+            f32x4 p1[NTL], p2[NTL];
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) {
-            const int co0 = n0 + (wn * NTL + nt) * 32;
-            f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = p1;
+            for (int nt = 0; nt < NTL; ++nt) p1[nt] = p2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 rq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int oyb = ct.oy0 + ((wm * MT + mt) * 32) / TW;
-                const int oxb = ct.ox0 + ((wm * MT + mt) * 32) % TW;
-                if constexpr (VEC) {
-                    const int g4 = (lane & 7) * 4;
-                    const int co = co0 + g4;
-                    const f32x4 b4 = bias4[nt];
+            for (int qi = 0; qi <= NQ; ++qi) {
+                if (qi > 0) rq = *reinterpret_cast<const f32x4*>(s_ep + ((qi - 1) & 1) * 288 + pl * 36 + g4);
+                if (qi < NQ) {
+                    const int nt = qi / (MT * 4), mt = (qi / 4) % MT, q = qi & 3;
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {          // pixel rows 16 * half .. + 15 of the block
+                    for (int k = 0; k < 4; ++k) s_ep[(qi & 1) * 288 + (k + 4 * lh) * 36 + li] = ac[mt][nt][q * 4 + k];
+                }
+                if (qi > 0) {
+                    const int pq = qi - 1, nt = pq / (MT * 4), mt = (pq / 4) % MT, q = pq & 3;
+                    const int co = n0 + (wn * NTL + nt) * 32 + g4;
+                    f32x4 v = rq + bias4[nt];
+                    const int p0 = (wm * MT + mt) * 32 + q * 8;                  // first pixel of the row group (wave-uniform)
+                    const unsigned off = tbase + (unsigned)(p0 / TW) * row_st + (unsigned)(p0 % TW) * col_st + lane_off[nt];
+                    const int oy = ct.oy0 + (p0 + pl) / TW, ox = ct.ox0 + (p0 + pl) % TW;
+                    if (full || (co < a.Cout && oy < a.H && ox < a.W)) {
+                        if constexpr (OM >= 1) {                // the tensor holds bf16 values (RNE; NaN stays NaN)
+                            unsigned short qh[4];
 #pragma unroll
-                        for (int r = 0; r < 8; ++r)
-                            s_ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = ac[mt][nt][half * 8 + r];
+                            for (int e = 0; e < 4; ++e) {
+                                const __bf16 h = (__bf16)v[e];
+                                qh[e] = __builtin_bit_cast(unsigned short, h);
+                                v[e] = (float)h;
+                            }
+                            if constexpr (OM == 2) {
+                                u32x2 pk;
+                                pk[0] = (unsigned)qh[0] | ((unsigned)qh[1] << 16);
+                                pk[1] = (unsigned)qh[2] | ((unsigned)qh[3] << 16);
+                                *reinterpret_cast<u32x2*>(a.y16 + off) = pk;
+                            }
+                        }
+                        if constexpr (OM != 2) *reinterpret_cast<f32x4*>(a.y + off) = v;
+                        if (st_out) {
+                            if (BWD && bwd) {
+                                const u32x2 t = ypre[BWD ? mt : 0][BWD ? nt : 0][q >> 1][q & 1];
+                                const f32x4 yv = {__builtin_bit_cast(float, t[0] << 16), __builtin_bit_cast(float, t[0] & 0xffff0000u),
+                                                  __builtin_bit_cast(float, t[1] << 16), __builtin_bit_cast(float, t[1] & 0xffff0000u)};
+                                const f32x4 z = yv * bsc[BWD ? nt : 0] + bsh[BWD ? nt : 0], xh = (yv - bmu[BWD ? nt : 0]) * bis[BWD ? nt : 0];
+                                f32x4 dz;
 #pragma unroll
-                        for (int ps = 0; ps < 2; ++ps) {
-                            const int pl = ps * 8 + (lane >> 3);
-                            const int pp = half * 16 + pl;
-                            f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + pl * 36 + g4) + b4;
-                            const int p0 = (wm * MT + mt) * 32 + half * 16 + ps * 8;         // first pixel of the row group (wave-uniform)
-                            const unsigned off = tbase + (unsigned)(p0 / TW) * row_st + (unsigned)(p0 % TW) * col_st + lane_off[nt];
-                            const int oy = oyb + pp / TW, ox = oxb + pp % TW;
-                            if (full || (co < a.Cout && oy < a.H && ox < a.W)) {
-                                if constexpr (OM >= 1) {                // the tensor holds bf16 values (RNE; NaN stays NaN)
-                                    unsigned short q[4];
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const __bf16 h = (__bf16)v[e];
-                                        q[e] = __builtin_bit_cast(unsigned short, h);
-                                        v[e] = (float)h;
-                                    }
-                                    if constexpr (OM == 2) {
-                                        u32x2 pk;
-                                        pk[0] = (unsigned)q[0] | ((unsigned)q[1] << 16);
-                                        pk[1] = (unsigned)q[2] | ((unsigned)q[3] << 16);
-                                        *reinterpret_cast<u32x2*>(a.y16 + off) = pk;
-                                    }
-                                }
-                                if constexpr (OM != 2) *reinterpret_cast<f32x4*>(a.y + off) = v;
-                                if (st_out) {
-                                    if (BWD && bwd) {
-                                        const u32x2 t = ypre[BWD ? mt : 0][BWD ? nt : 0][half][ps];
-                                        const f32x4 yv = {__builtin_bit_cast(float, t[0] << 16), __builtin_bit_cast(float, t[0] & 0xffff0000u),
-                                                          __builtin_bit_cast(float, t[1] << 16), __builtin_bit_cast(float, t[1] & 0xffff0000u)};
-                                        const f32x4 z = yv * bsc[BWD ? nt : 0] + bsh[BWD ? nt : 0], xh = (yv - bmu[BWD ? nt : 0]) * bis[BWD ? nt : 0];
-                                        f32x4 dz;
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.0f ? v[e] : v[e] * a.bwd_slope;
-                                        p1 += dz;
-                                        p2 += dz * xh;
-                                    } else {
-                                        p1 += v;
-                                        p2 += v * v;
-                                    }
-                                }
+                                for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.0f ? v[e] : v[e] * a.bwd_slope;
+                                p1[nt] += dz;
+                                p2[nt] += dz * xh;
+                            } else {
+                                p1[nt] += v;
+                                p2[nt] += v * v;
                             }
                         }
                     }
-                } else {
-                    const int co = co0 + li;
-                    const bool cok = co < a.Cout;
-                    const float bv = bias1[nt];
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ac[mt][nt][r] = 0.0f;
+            if (st_out) {
+                // lanes l, l^8, l^16, l^32 hold the same 4 channels of different pixels: fold them
+                // (<= 128 fp32 terms per channel), then continue in fp64 in this wave's LDS slots
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int o = 8; o < 64; o <<= 1) {
+                            p1[nt][e] += __shfl_xor(p1[nt][e], o, 64);
+                            p2[nt][e] += __shfl_xor(p2[nt][e], o, 64);
+                        }
+                    }
+                    if (lane < 8) {
+                        double* dd = s_stat + ((wave * NTL + nt) * 32 + lane * 4) * 2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            dd[e * 2] += (double)p1[nt][e];
+                            dd[e * 2 + 1] += (double)p2[nt][e];
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                const int co = n0 + (wn * NTL + nt) * 32 + li;
+                const bool cok = co < a.Cout;
+                const float bv = bias1[nt];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int oyb = ct.oy0 + ((wm * MT + mt) * 32) / TW;
+                    const int oxb = ct.ox0 + ((wm * MT + mt) * 32) % TW;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int pp = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -365,28 +401,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                             a.y[(unsigned)(((ct.n * a.Hout + oy * a.osy + a.ooy) * a.Wout + a.oox) * a.y_pstride + co) +
                                 (unsigned)(ox * xs)] = ac[mt][nt][r] + bv;
                     }
-                }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ac[mt][nt][r] = 0.0f;
-            }
-            if (VEC && st_out) {
-                // lanes l, l^8, l^16, l^32 hold the same 4 channels of different pixels: fold them
-                // (<= 128 fp32 terms per channel), then continue in fp64 in this wave's LDS slots
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int o = 8; o < 64; o <<= 1) {
-                        p1[e] += __shfl_xor(p1[e], o, 64);
-                        p2[e] += __shfl_xor(p2[e], o, 64);
-                    }
-                }
-                if (lane < 8) {
-                    double* dd = s_stat + ((wave * NTL + nt) * 32 + lane * 4) * 2;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        dd[e * 2] += (double)p1[e];
-                        dd[e * 2 + 1] += (double)p2[e];
-                    }
+                    for (int r = 0; r < 16; ++r) ac[mt][nt][r] = 0.0f;
                 }
             }
         }
