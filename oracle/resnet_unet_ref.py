@@ -186,6 +186,7 @@ def forward(state, x_nchw, training=False, buffer_updates=None, tape=None):
     st, bu = state, buffer_updates
     _WIDTH_16 = st["stem.0.weight"].shape[0] % 16 == 0
     unet_ref._WIDTHS_16 = _WIDTH_16               # (the decoder half below is unet_ref's)
+    unet_ref._WIDTHS_32 = st["stem.0.weight"].shape[0] % 32 == 0
     h = _conv(x_nchw, st["stem.0.weight"], 1, 1)
     if tape is not None:
         tape["stem.0.out"] = h

@@ -223,8 +223,9 @@ class _ConvBF16(torch.autograd.Function):
 
 class _ConvT2x2BF16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, round_dx=False):
         ctx.save_for_backward(x, w)
+        ctx.round_dx = bool(round_dx)
         return F.conv_transpose2d(_bf(x), _bf(w), b, stride=2)
 
     @staticmethod
@@ -232,14 +233,17 @@ class _ConvT2x2BF16(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dyb = _bf(dy)
         dx = F.conv2d(dyb, _bf(w), None, stride=2)                               # adjoint of the scatter
+        if ctx.round_dx:                                   # the input gradient is stored as a bfloat16 tensor
+            dx = _bf(dx)
         dw = torch.nn.grad.conv2d_weight(dyb, w.shape, _bf(x), stride=2)         # [cin][cout][2][2]
-        return dx, dw, dy.sum(dim=(0, 2, 3))
+        return dx, dw, dy.sum(dim=(0, 2, 3)), None
 
 
 _BF16_OPERANDS = False
 _BF16_ROUND_OUTPUTS = False
 _BF16_ROUND_GRADS = False
 _WIDTHS_16 = False          # set by forward(): the model's first width is a multiple of 16 (then every width is)
+_WIDTHS_32 = False          # ... of 32
 
 
 class bf16_operands:
@@ -273,13 +277,15 @@ def _conv3x3(x, w, b, round_dx=False):
 
 
 def _convt2x2(x, w, b):
-    return _ConvT2x2BF16.apply(x, w, b) if _BF16_OPERANDS else F.conv_transpose2d(x, w, b, stride=2)
+    # (widths in whole 32-channel blocks: the library runs the transposed convs on its plane kernels -- their input gradient
+    # and the gradient of the decoder's [up | skip] input are then bfloat16 tensors)
+    return _ConvT2x2BF16.apply(x, w, b, _BF16_ROUND_GRADS and _WIDTHS_32) if _BF16_OPERANDS else F.conv_transpose2d(x, w, b, stride=2)
 
 
 def _double_conv(x, st, prefix, training, ema_repeats, buffer_updates, tape, negative_slope=0.0):
     for conv_idx, bn_idx in ((0, 1), (3, 4)):
         x = _conv3x3(x, st[f"{prefix}.{conv_idx}.weight"], st[f"{prefix}.{conv_idx}.bias"],
-                     round_dx=conv_idx == 3 or not prefix.startswith("decoder"))
+                     round_dx=conv_idx == 3 or not prefix.startswith("decoder") or _WIDTHS_32)
         if tape is not None:
             tape[f"{prefix}.{conv_idx}.out"] = x
         x = _bn(x, st, f"{prefix}.{bn_idx}", training, ema_repeats, buffer_updates, tape,
@@ -295,9 +301,10 @@ def forward(state, x_nchw, training=False, buffer_updates=None, tape=None, negat
     """Logits (N,out,H,W).  ``buffer_updates`` (dict) receives new BN buffers in train mode.
     ``negative_slope`` > 0: UNetDifferentActivation with LeakyReLU (models/unet.py:198-268);
     ``head_sigmoid``: UNetOverfit, which returns sigmoid(final_conv(.)) (models/unet.py:196)."""
-    global _WIDTHS_16
+    global _WIDTHS_16, _WIDTHS_32
     _, _, _, depth = infer_config(state)
     _WIDTHS_16 = state["encoder1.conv.conv.0.weight"].shape[0] % 16 == 0
+    _WIDTHS_32 = state["encoder1.conv.conv.0.weight"].shape[0] % 32 == 0
     skips = []
     h = x_nchw
     ns = negative_slope

@@ -990,6 +990,8 @@ int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t h
                     "debug_tensor: this conv output is stored as bfloat16 in the bfloat16 compute mode");
         RFI_REQUIRE(!(m->g16_flow && m->planesP == 1 && (base == "gB" || base == "dpool" || base == "gBottB" || base == "gA")),
                     "debug_tensor: this gradient tensor is stored as bfloat16 in the bfloat16 compute mode");
+        RFI_REQUIRE(!(m->convt_planes && m->planesP == 1 && (base == "decY2" || base == "bottY2" || base == "gBottA")),
+                    "debug_tensor: with the transposed convs on the plane kernels this tensor is stored as bfloat16");
         auto level = [&](const std::vector<int>& v, size_t chmul) {
             RFI_REQUIRE(idx >= 1 && idx <= D, "debug_tensor: level out of range");
             const size_t M = (size_t)m->pN * (m->pH >> (idx - 1)) * (m->pW >> (idx - 1));
@@ -1005,7 +1007,14 @@ int rfi_model_debug_tensor(rfi_model* m, const char* name, float* host, size_t h
         else if (base == "gA") level(!m->planesP && m->arch == 0 ? m->gAe : m->gA, 1);     // (as left by the encoder phase)
         else if (base == "gB") level(!m->planesP && m->arch == 0 ? m->gBe : m->gB, 1);
         else if (base == "concat") level(m->concat, 2);
-        else if (base == "dconcat") level(m->dconcat, 2);
+        else if (base == "dconcat") {
+            level(m->dconcat, 2);
+            if (m->convt_planes && m->planesP == 1 && host) {      // stored as bfloat16: its values as float32 (tools/race_probe.py watches it)
+                const PlaneBuf& g = m->pl[m->g16cat[idx]];
+                launch_planes_to_f32(m->ctx, g.p, g.pstride, (int64_t)(n / ((size_t)2 * (m->feat << (idx - 1)))), 2 * (m->feat << (idx - 1)), 1,
+                                     m->buf(m->dconcat[idx]), 2 * (m->feat << (idx - 1)));
+            }
+        }
         else if (base == "pool") { level(m->pool, 1); n /= 4; }
         else if (base == "dpool") { level(m->dpool, 1); n /= 4; }
         else if (base == "bottY1") { src = m->buf(m->bottY1); n = Mb * Cb; }
@@ -1791,6 +1800,25 @@ int rfi_op_convt2x2(rfi_ctx* ctx, int impl, const float* x, int n, int h, int w,
     return guarded([&] {
         ctx->activate();
         Scratch s(ctx);
+        if (impl == IMPL_PLANES_BF16) {           // ONE 1x1 contraction on planes: the four taps are 4 cout output channels
+            RFI_REQUIRE(cout % 32 == 0, "convt2x2 on planes: cout % 32 == 0");
+            const int64_t Mi = (int64_t)n * h * w;
+            const PlaneTmp xp = planes_of(ctx, s, x, Mi, cin);
+            const float* wl = upload_lib_weight(ctx, s, w_iohw, (size_t)4 * cin * cout, true, cin, cout, 2);      // [4][cout][cin]
+            PlaneTmp yp = plane_tmp(ctx, s, 4 * Mi, cout);
+            PConvArgs a;
+            a.x[0] = xp.seg(); a.nseg = 1; a.P = 1;
+            a.N = n; a.H = h; a.W = w; a.Hin = h; a.Win = w;
+            a.R = 1; a.S = 1; a.pad = 0;
+            a.Cout = 4 * cout; a.zblocks = cout / 32;
+            a.wB = wb_of(ctx, s, wl, 1, 4 * cout, cin, cin, 0);
+            a.bias = bias;
+            a.y16 = yp.p; a.y_pstride = (int)yp.ps;
+            a.Hout = 2 * h; a.Wout = 2 * w; a.osy = 2; a.osx = 2;
+            launch_pconv(ctx, a);
+            launch_planes_to_f32(ctx, yp.p, yp.ps, 4 * Mi, cout, 1, y, cout);
+            return;
+        }
         ConvArgs a;
         a.x = View{x, cin};
         a.N = n; a.H = h; a.W = w; a.Hin = h; a.Win = w; a.Cin = cin; a.Cout = cout;
@@ -1811,6 +1839,22 @@ int rfi_op_convt2x2_dgrad(rfi_ctx* ctx, int impl, const float* dy, int n, int h,
         float* wf = upload_lib_weight(ctx, s, w_iohw, (size_t)4 * cin * cout, true, cin, cout, 2);
         float* wd = s.get((size_t)4 * cin * cout);
         launch_weight_to_dgrad(ctx, wf, 4, cout, cin, 0, wd);
+        if (impl == IMPL_PLANES_BF16) {           // a 2x2 stride-2 contraction of dy on planes, bfloat16 out
+            RFI_REQUIRE(cin % 4 == 0, "convt2x2_dgrad on planes: cin % 4 == 0");
+            const int64_t Mi = (int64_t)n * h * w;
+            const PlaneTmp dyp = planes_of(ctx, s, dy, 4 * Mi, cout);
+            PlaneTmp dxp = plane_tmp(ctx, s, Mi, cin);
+            PConvArgs a;
+            a.x[0] = dyp.seg(); a.nseg = 1; a.P = 1;
+            a.N = n; a.H = h; a.W = w; a.Hin = 2 * h; a.Win = 2 * w; a.Hout = h; a.Wout = w;
+            a.R = 2; a.S = 2; a.pad = 0;
+            a.Cout = cin;
+            a.wB = wb_of(ctx, s, wd, 4, cin, cout, cout, 0);
+            a.y16 = dxp.p; a.y_pstride = (int)dxp.ps;
+            launch_pconv(ctx, a);
+            launch_planes_to_f32(ctx, dxp.p, dxp.ps, Mi, cin, 1, dx, cin);
+            return;
+        }
         ConvArgs a;               // (n,h,w) is the INPUT grid of the convT, dy is (n,2h,2w,cout)
         a.x = View{dy, cout};
         a.N = n; a.H = h; a.W = w; a.Hin = 2 * h; a.Win = 2 * w; a.Cin = cout; a.Cout = cin;
@@ -1835,9 +1879,23 @@ int rfi_op_convt2x2_wgrad(rfi_ctx* ctx, int impl, const float* x, const float* d
         a.sy = 1; a.sx = cin;
         const size_t numel = (size_t)4 * cin * cout;
         a.dw = s.get(numel);
+        if (impl == IMPL_PLANES_BF16) {           // the 2x2 stride-2 weight gradient on planes (Xop = the output gradient)
+            const PlaneTmp dyp = planes_of(ctx, s, dy, (int64_t)4 * n * h * w, cout);
+            const PlaneTmp xp = planes_of(ctx, s, x, (int64_t)n * h * w, cin);
+            PWgradArgs pa;
+            pa.xop[0] = dyp.seg(); pa.nseg = 1; pa.seg_c[0] = cout;
+            pa.yop = xp.seg(); pa.Cy = cin; pa.P = 1;
+            pa.N = n; pa.H = h; pa.W = w; pa.Hx = 2 * h; pa.Wx = 2 * w;
+            pa.R = 2; pa.S = 2; pa.pad = 0;
+            pa.dw = a.dw; pa.tap_stride = a.tap_stride; pa.sy = 1; pa.sx = cin;
+            pa.slab_floats = pwgrad_slab_floats(pa);
+            pa.slab = s.get(pa.slab_floats);
+            launch_pwgrad(ctx, pa);
+        } else {
         a.slab_floats = wgrad_slab_floats(a, impl);
         a.slab = s.get(a.slab_floats);
         launch_wgrad(ctx, a, impl);
+        }
         std::vector<float> lib(numel), ref(numel);
         RFI_CHECK_HIP(hipMemcpyAsync(lib.data(), a.dw, numel * 4, hipMemcpyDeviceToHost, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));

@@ -230,7 +230,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
         bias1[nt] = 0.0f;
         if (a.bias) {
             const int co = co0 + (lane & 7) * 4;
-            if (vec_out && co < a.Cout) bias4[nt] = *reinterpret_cast<const f32x4*>(a.bias + co);
+            const int cz = a.zblocks ? co % (32 * a.zblocks) : co;          // (tap groups share the bias)
+            if (vec_out && co < a.Cout) bias4[nt] = *reinterpret_cast<const f32x4*>(a.bias + cz);
             if (!vec_out && co0 + li < a.Cout) bias1[nt] = a.bias[co0 + li];
         }
         // opaque to the compiler from here on: otherwise it re-loads the (invariant) bias at every use instead of
@@ -264,7 +265,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
     const unsigned col_st = (unsigned)(a.osx * a.y_pstride), row_st = (unsigned)(a.osy * a.Wout * a.y_pstride);
     unsigned lane_off[NTL];
 #pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) lane_off[nt] = (unsigned)(lane >> 3) * col_st + (unsigned)(n0 + (wn * NTL + nt) * 32 + (lane & 7) * 4);
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int co = n0 + (wn * NTL + nt) * 32 + (lane & 7) * 4;
+        lane_off[nt] = (unsigned)(lane >> 3) * col_st + (unsigned)co;
+        if (a.zblocks) {                             // tap group z = 2 a + b of the transposed conv: pixel offset (a, b), channels of the group
+            const int z = co / (32 * a.zblocks), cz = co % (32 * a.zblocks);
+            lane_off[nt] = (unsigned)(lane >> 3) * col_st + (unsigned)((z >> 1) * a.Wout * a.y_pstride + (z & 1) * a.y_pstride + cz);
+        }
+    }
     auto epilogue = [&](const Tile& ct, f32x16 (&ac)[MT][NTL], float* s_ep, auto vec_tag) {
         constexpr bool VEC = decltype(vec_tag)::value;   // 16-byte row stores (vec_out) or the scalar fallback: one branch per tile
         const int xs = a.osx * a.y_pstride;
@@ -624,8 +632,13 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
     if constexpr (OM < 0) {                           // pick the epilogue variant of this launch
         const int om = d.a.y16 ? 2 : d.a.round_y ? 1 : 0;
         const bool b = d.a.bwd_y16 != nullptr;
-        if constexpr (R != 3 || S != 1) {            // the ResNet-style encoder's other shapes: bfloat16 in, bfloat16 out, no extras
-            RFI_REQUIRE(P == 1 && om == 2 && !b, "pconv: strided / 1x1 / 2x2 contractions exist for the bfloat16 flow only (bfloat16 output)");
+        if constexpr (R != 3 || S != 1) {            // the other shapes of the bfloat16 flow: bfloat16 in, bfloat16 out
+            RFI_REQUIRE(P == 1 && om == 2, "pconv: strided / 1x1 / 2x2 contractions exist for the bfloat16 flow only (bfloat16 output)");
+            if constexpr (R == 2 && S == 2) {        // (a transposed conv's input gradient feeds a BatchNorm layer: its backward sums)
+                if (b) return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, true, 2>(ctx, d);
+            } else {
+                RFI_REQUIRE(!b, "pconv: the BatchNorm-backward epilogue exists for 3x3 stride-1 and 2x2 stride-2 contractions");
+            }
             return launch_cfg<R, S, TH, TW, WM, WN, MT, NTL, P, G, PAD, false, 2>(ctx, d);
         } else if constexpr (P == 1) {
             RFI_REQUIRE(!(b && om == 1), "pconv: the BatchNorm-backward epilogue writes float32 or bfloat16 tensors");
@@ -736,8 +749,11 @@ void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
     RFI_REQUIRE(a.P == 1 || a.P == 3, "pconv: planes must be 1 or 3");
     const bool plain = a.R == 3 && a.S == 1 && a.pad == 1;
     const bool s2 = a.R == 3 && a.S == 2 && a.pad == 1, p2 = a.R == 1 && a.S == 2 && a.pad == 0, c2 = a.R == 2 && a.S == 1 && a.pad == 0;
-    RFI_REQUIRE(plain || ((s2 || p2 || c2) && a.P == 1),
-                "pconv: 3x3 stride 1 pad 1; bfloat16 flow also 3x3 stride 2 pad 1, 1x1 stride 2, 2x2 stride 1 pad 0");
+    const bool t1 = a.R == 1 && a.S == 1 && a.pad == 0, t2 = a.R == 2 && a.S == 2 && a.pad == 0;      // transposed conv: forward / input gradient
+    RFI_REQUIRE(plain || ((s2 || p2 || c2 || t1 || t2) && a.P == 1),
+                "pconv: 3x3 stride 1 pad 1; bfloat16 flow also 3x3 stride 2 pad 1, 1x1 stride 1 / 2, 2x2 stride 1 / 2 pad 0");
+    RFI_REQUIRE(!a.zblocks || (t1 && a.Cout == 128 * a.zblocks && a.osy == 2 && a.osx == 2 && a.y16),
+                "pconv: tap groups are the four taps of a ConvTranspose2d(k2, s2) with Cout % 32 == 0, bfloat16 output");
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cout > 0 && a.nseg >= 1 && a.nseg <= 2, "pconv: empty shape");
     PConvDev d;
     d.a = a;
@@ -770,6 +786,8 @@ void launch_pconv(rfi_ctx* ctx, PConvArgs& a) {
     if (s2) dispatch_other<3, 2>(ctx, d);
     else if (p2) dispatch_other<1, 2>(ctx, d);
     else if (c2) dispatch_other<2, 1>(ctx, d);
+    else if (t1) dispatch_other<1, 1>(ctx, d);
+    else if (t2) dispatch_other<2, 2>(ctx, d);
     else if (a.P == 3) dispatch<3>(ctx, d);
     else dispatch<1>(ctx, d);
     a.stats = d.a.stats;

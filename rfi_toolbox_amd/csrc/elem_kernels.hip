@@ -404,7 +404,7 @@ __global__ void finish_channel_sum_batched_kernel(const FinishSumDesc* __restric
 }
 
 template <int V>
-__global__ void channel_sum_kernel(const float* __restrict__ v_, int pstride, int64_t M, int C, int CL,
+__global__ void channel_sum_kernel(const void* __restrict__ v_, int v16, int pstride, int64_t M, int C, int CL,
                                    int64_t rows_per_block, double* __restrict__ partial) {
     __shared__ double red[V * kBlock];
     const int RL = kBlock / CL;
@@ -419,7 +419,7 @@ __global__ void channel_sum_kernel(const float* __restrict__ v_, int pstride, in
     if (c < C)
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             float x[V];
-            ldv<V>(v_ + r * pstride + c, x);
+            ldy<V>(v_, v16, r * pstride + c, x);
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[0][v] += (double)x[v];
         }
@@ -522,7 +522,7 @@ template <bool SUMS>
 __global__ __launch_bounds__(256) void pool_bwd_merge_vec_kernel(
     const void* __restrict__ y, int y16, int64_t yps, int N, int H, int W, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ dskip, int dskip_ps, const void* __restrict__ dpool, int dp16, float* __restrict__ da, float slope,
+    const void* __restrict__ dskip, int dskip16, int dskip_ps, const void* __restrict__ dpool, int dp16, float* __restrict__ da, float slope,
     double* __restrict__ records, unsigned short* __restrict__ da16) {
     // da16 != null: the merged gradient is stored as bfloat16 there (da unused) and the sums are those of the stored values
     __shared__ double red[SUMS ? 8 * kBlock : 1];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void pool_bwd_merge_vec_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float d[4];
-            ldv<4>(dskip + pixk[k] * dskip_ps + c, d);
+            ldy<4>(dskip, dskip16, pixk[k] * dskip_ps + c, d);
 #pragma unroll
             for (int v = 0; v < 4; ++v) d[v] += (k == arg[v] ? g[v] : 0.0f);
             if (da16) round_store_bf16x4(da16 + pixk[k] * C + c, d);
@@ -1312,20 +1312,22 @@ size_t channel_sum_ws_floats(int64_t M, int C) {
     (void)M;
     return (size_t)kMaxRowBlocks * C * 2;
 }
-void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out, bool finish) {
+void launch_channel_sum(rfi_ctx* ctx, YRef v, int64_t M, int C, float* partial_ws, float* out, bool finish) {
     ChanGeom g = geom_rows(M, C);
-    const bool vec = g.V == 4 && v.pstride % 4 == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0;
+    const int pstride = (int)v.stride(C);
+    const bool vec = g.V == 4 && pstride % 4 == 0 && (reinterpret_cast<uintptr_t>(v.p) & (v.bf16 ? 7 : 15)) == 0;
     RFI_REQUIRE(finish || vec, "channel_sum: deferred finishing needs the vector path (C % 4 == 0, an aligned view)");
+    RFI_REQUIRE(vec || !v.bf16, "channel_sum: a bfloat16 view needs C % 4 == 0 and 8-byte aligned rows");
     if (!vec && g.V == 4) g = geom_rows(M, C, false);   // unaligned view: scalar lanes
     {
-        ProfScope ps(ctx, FAM_REDUCE, 0, (double)M * C * 4);
+        ProfScope ps(ctx, FAM_REDUCE, 0, (double)M * C * (v.bf16 ? 2 : 4));
         if (g.V == 4)
             hipLaunchKernelGGL(channel_sum_kernel<4>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
-                               v.p, v.pstride, M, C, g.CL, g.rows_per_block,
+                               v.p, v.bf16, pstride, M, C, g.CL, g.rows_per_block,
                                reinterpret_cast<double*>(partial_ws));
         else
             hipLaunchKernelGGL(channel_sum_kernel<1>, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
-                           v.p, v.pstride, M, C, g.CL, g.rows_per_block,
+                           v.p, v.bf16, pstride, M, C, g.CL, g.rows_per_block,
                            reinterpret_cast<double*>(partial_ws));
         check_launch("channel_sum");
     }
@@ -1335,6 +1337,9 @@ void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_w
                            ctx->stream, reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, out);
         check_launch("finish_channel_sum");
     }
+}
+void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out, bool finish) {
+    launch_channel_sum(ctx, YRef(v.p, (int64_t)v.pstride), M, C, partial_ws, out, finish);
 }
 
 void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int C,
@@ -1362,14 +1367,14 @@ void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int 
     }
 }
 
-static bool pool_vec_ok(YRef y, int C, const float* scale, const float* shift, View dskip, YRef dpool_, const float* da) {
+static bool pool_vec_ok(YRef y, int C, const float* scale, const float* shift, YRef dskip, YRef dpool_, const float* da) {
     const void* dpool = dpool_.p;
-    return C % 4 == 0 && dskip.pstride % 4 == 0 && y.stride(C) % 4 == 0 &&
+    return C % 4 == 0 && dskip.stride(C) % 4 == 0 && y.stride(C) % 4 == 0 &&
            !((reinterpret_cast<uintptr_t>(y.p) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
               reinterpret_cast<uintptr_t>(dskip.p) | reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(da)) & 15);
 }
 int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C, const float* scale,
-                               const float* shift, const float* mean, const float* invstd, View dskip, YRef dpool,
+                               const float* shift, const float* mean, const float* invstd, YRef dskip, YRef dpool,
                                float* da, float slope, float* partial_ws, unsigned short* da16) {
     if (!pool_vec_ok(y, C, scale, shift, dskip, dpool, da16 ? reinterpret_cast<const float*>(da16) : da) || dpool.stride(C) != C ||
         (reinterpret_cast<uintptr_t>(da16) & 7) ||
@@ -1389,33 +1394,34 @@ int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
     if ((int64_t)grid * kBlock > total) return 0;   // (every thread must own at least one element)
     ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * (dpool.bf16 ? 8 : 16));
     hipLaunchKernelGGL(pool_bwd_merge_vec_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, y.p, y.bf16, y.stride(C), N, H, W,
-                       C, scale, shift, mean, invstd, dskip.p, dskip.pstride, dpool.p, dpool.bf16, da, slope, reinterpret_cast<double*>(partial_ws), da16);
+                       C, scale, shift, mean, invstd, dskip.p, dskip.bf16, (int)dskip.stride(C), dpool.p, dpool.bf16, da, slope, reinterpret_cast<double*>(partial_ws), da16);
     check_launch("pool_bwd_merge_sums");
     return records;
 }
 
 void launch_pool_bwd_merge(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
-                           const float* scale, const float* shift, View dskip, YRef dpool,
+                           const float* scale, const float* shift, YRef dskip, YRef dpool,
                            float* da, float slope, unsigned short* da16) {
     const bool vec = pool_vec_ok(y, C, scale, shift, dskip, dpool, da16 ? reinterpret_cast<const float*>(da16) : da) && dpool.stride(C) == C &&
                      !(reinterpret_cast<uintptr_t>(da16) & 7);
-    RFI_REQUIRE(vec || !(dpool.bf16 || da16), "pool_bwd_merge: bfloat16 gradient tensors need C % 4 == 0 and aligned tensors");
+    RFI_REQUIRE(vec || !(dpool.bf16 || da16 || dskip.bf16), "pool_bwd_merge: bfloat16 gradient tensors need C % 4 == 0 and aligned tensors");
+    RFI_REQUIRE(!dskip.bf16 || !((H & 1) || (W & 1)), "pool_bwd_merge: a bfloat16 skip gradient needs even H and W");
     RFI_REQUIRE(!da16 || !((H & 1) || (W & 1)), "pool_bwd_merge: a bfloat16 output needs even H and W");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
     {
         ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)N * H * W * C * (y.bf16 ? 10 : 12) + (double)total * (dpool.bf16 ? 2 : 4));
         if (vec)
             hipLaunchKernelGGL(pool_bwd_merge_vec_kernel<false>, dim3(grid_for(total / 4)), dim3(kBlock), 0, ctx->stream, y.p, y.bf16,
-                               y.stride(C), N, H, W, C, scale, shift, nullptr, nullptr, dskip.p, dskip.pstride, dpool.p, dpool.bf16, da, slope, nullptr, da16);
+                               y.stride(C), N, H, W, C, scale, shift, nullptr, nullptr, dskip.p, dskip.bf16, (int)dskip.stride(C), dpool.p, dpool.bf16, da, slope, nullptr, da16);
         else
             hipLaunchKernelGGL(pool_bwd_merge_kernel, dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream, y.p, y.bf16, y.stride(C),
-                               N, H, W, C, scale, shift, dskip.p, dskip.pstride, static_cast<const float*>(dpool.p), da, slope);
+                               N, H, W, C, scale, shift, static_cast<const float*>(dskip.p), (int)dskip.stride(C), static_cast<const float*>(dpool.p), da, slope);
         check_launch("pool_bwd_merge");
     }
     if ((H & 1) || (W & 1)) {
         ProfScope ps(ctx, FAM_ELEMWISE);
         hipLaunchKernelGGL(copy_edge_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(kBlock), 0,
-                           ctx->stream, N, H, W, C, dskip.p, dskip.pstride, da);
+                           ctx->stream, N, H, W, C, static_cast<const float*>(dskip.p), (int)dskip.stride(C), da);
         check_launch("copy_edge");
     }
 }

@@ -148,7 +148,9 @@ struct YRef {
     int64_t ps = 0;                   // elements between pixels; 0: C
     YRef(const float* f) : p(f) {}
     YRef(float* f) : p(f) {}
+    YRef(const float* f, int64_t pstride) : p(f), ps(pstride) {}
     YRef(const unsigned short* h, int64_t pstride) : p(h), bf16(1), ps(pstride) {}
+    YRef(View v) : p(v.p), ps(v.pstride) {}
     int64_t stride(int C) const { return ps ? ps : C; }
 };
 
@@ -208,7 +210,7 @@ void launch_bn_relu_pool(rfi_ctx* ctx, const float* y, int N, int H, int W, int 
                          const float* scale, const float* shift, MutView skip, float* pooled, float slope = 0.0f);
 // da[n,y,x,c] = dskip[n,y,x,c] + (argmax of the 2x2 window of a == (y,x) ? dpool : 0)
 void launch_pool_bwd_merge(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
-                           const float* scale, const float* shift, View dskip, YRef dpool,
+                           const float* scale, const float* shift, YRef dskip, YRef dpool,
                            float* da, float slope = 0.0f, unsigned short* da16 = nullptr);
 // da16 != null (bf16 data flow; C % 4 == 0): the merged gradient is stored as a dense bfloat16 [pixel][C] tensor there
 // instead of da, and the sums of launch_pool_bwd_merge_sums are those of the stored values (the same for launch_head_bwd)
@@ -216,7 +218,7 @@ void launch_pool_bwd_merge(rfi_ctx* ctx, YRef y, int N, int H, int W, int C,
 // partial_ws (bn_bwd_ws_floats) for launch_bn_bwd_finalize_records; returns the record count, or 0 when the shape does
 // not fit the scheme (nothing launched: call launch_pool_bwd_merge and the separate reduction instead)
 int launch_pool_bwd_merge_sums(rfi_ctx* ctx, YRef y, int N, int H, int W, int C, const float* scale,
-                               const float* shift, const float* mean, const float* invstd, View dskip, YRef dpool,
+                               const float* shift, const float* mean, const float* invstd, YRef dskip, YRef dpool,
                                float* da, float slope, float* partial_ws, unsigned short* da16 = nullptr);
 // logits[m,o] = b[o] + sum_c relu(y*scale+shift)[m,c] * w[o][c]
 void launch_head_fwd(rfi_ctx* ctx, YRef y, int64_t M, int C, const float* scale,
@@ -254,6 +256,7 @@ int launch_head_bwd(rfi_ctx* ctx, YRef y, int64_t M, int C, const float* scale,
 size_t head_bwd_ws_floats(int64_t M, int C, int Cout);
 // per-channel sum over pixels of a view (convT bias grad)
 void launch_channel_sum(rfi_ctx* ctx, View v, int64_t M, int C, float* partial_ws, float* out, bool finish = true);
+void launch_channel_sum(rfi_ctx* ctx, YRef v, int64_t M, int C, float* partial_ws, float* out, bool finish = true);      // (a bfloat16 view too)
 // finish = false (16-byte aligned views with C % 4 == 0 only): the per-block partials stay in partial_ws (bn_bwd_apply_records(M, C)
 // records, C doubles apart) for launch_finish_channel_sums_batched
 size_t channel_sum_ws_floats(int64_t M, int C);

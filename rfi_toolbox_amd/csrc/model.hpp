@@ -66,6 +66,8 @@ struct UpConv {
     float* wd = nullptr;                // dgrad layout [4][cin][cout]
     float* w3 = nullptr;                // 3 x bf16 records of both layouts
     float* wd3 = nullptr;
+    bf16_t* wBf = nullptr;              // plane kernels (bfloat16 flow): the four taps as ONE 1x1 contraction with 4 cout channels ...
+    bf16_t* wBd = nullptr;              // ... and the 2x2 stride-2 contraction of the input gradient
 };
 
 struct Entry {
@@ -293,6 +295,18 @@ struct rfi_model {
     bool resnet_planes() const { return arch == 2 && planesP == 1; }
     void forward_resnet_planes(rfi::PlaneSeg& cur, int n, int h, int w, bool train_mode);
     void backward_resnet_planes(int n, int h, int w);
+    // transposed convs on the plane kernels (bfloat16 flow, init_features % 32 == 0): the DoubleConv outputs they read are bfloat16
+    // (yB2, yD2[l]) and activated once into planes (pUpIn[l]: the forward operand AND the weight gradient's); the decoder's first
+    // conv writes its input gradient [up | skip] as bfloat16 (g16cat[l]) and the transposed conv's input gradient is bfloat16
+    // too (g16BottA, g16A[l + 1]), with the BatchNorm-backward sums of the layer below in its epilogue
+    bool convt_planes = false;
+    // the skip half (channels C .. 2 C - 1) of the gradient decoder l's first conv sends into its [up | skip] input
+    rfi::YRef skip_grad(int l, int C) {
+        if (convt_planes) return rfi::YRef(pl[g16cat[l]].p + C, pl[g16cat[l]].pstride);
+        return rfi::YRef(buf(dconcat[l]) + C, (int64_t)2 * C);
+    }
+    std::vector<int> yD2, pUpIn, g16cat;
+    int yB2 = -1, g16BottA = -1;
     rfi::bf16_t* wb_pool = nullptr;
     void* wb_descs = nullptr;
     int wb_n = 0;

@@ -99,6 +99,25 @@ void rfi_model::prepare_planes(int n, int h, int w) {
         }
         pl[g16BottB].ensure(ctx, Mb, feat << D, 1);
     }
+    static const bool no_ctp = getenv("RFI_NO_CONVT_PLANES") != nullptr;        // A/B runs: the round-1 transposed-conv kernels
+    convt_planes = g16_flow && feat % 32 == 0 && !no_ctp;
+    if (convt_planes) {
+        if (yB2 < 0) {
+            auto mk1 = [&](std::vector<int>& v) { v.assign(D + 1, -1); for (int l = 1; l <= D; ++l) { pl.emplace_back(); v[l] = (int)pl.size() - 1; } };
+            mk1(yD2); mk1(pUpIn); mk1(g16cat);
+            pl.emplace_back(); yB2 = (int)pl.size() - 1;
+            pl.emplace_back(); g16BottA = (int)pl.size() - 1;
+        }
+        for (int l = 1; l <= D; ++l) {
+            const int64_t M = (int64_t)n * (h >> (l - 1)) * (w >> (l - 1));
+            const int C = feat << (l - 1);
+            if (l > 1) { pl[yD2[l]].ensure(ctx, M, C, 1); pl[g16A[l]].ensure(ctx, M, C, 1); }
+            pl[pUpIn[l]].ensure(ctx, M / 4, 2 * C, 1);          // the input of decoder l's transposed conv: level l + 1, 2 C channels
+            pl[g16cat[l]].ensure(ctx, M, 2 * C, 1);
+        }
+        pl[yB2].ensure(ctx, Mb, feat << D, 1);
+        pl[g16BottA].ensure(ctx, Mb, feat << D, 1);
+    }
     if (rs) {
         RFI_REQUIRE(P == 1 && y16_flow && g16_flow, "UNetResNet18 on the plane kernels: bfloat16 flow with init_features % 16 == 0 only");
         auto one = [&]() { pl.emplace_back(); return (int)pl.size() - 1; };
@@ -143,6 +162,19 @@ void rfi_model::prepare_planes(int n, int h, int w) {
         a.tap_stride = (int64_t)c.cin_p * c.cout;
         slab_need = std::max(slab_need, pwgrad_slab_floats(a));
     }
+    if (convt_planes)
+        for (int k = 0; k < D; ++k) {
+            const int l = D - k;
+            PWgradArgs a;
+            a.nseg = 1; a.seg_c[0] = ups[k].cout;
+            a.xop[0].nchunks = plane_chunks(ups[k].cout);
+            a.yop.nchunks = plane_chunks(ups[k].cin);
+            a.Cy = ups[k].cin; a.P = 1;
+            a.N = n; a.H = h >> l; a.W = w >> l; a.Hx = a.H * 2; a.Wx = a.W * 2;
+            a.R = 2; a.S = 2; a.pad = 0;
+            a.tap_stride = (int64_t)ups[k].cin * ups[k].cout;
+            slab_need = std::max(slab_need, pwgrad_slab_floats(a));
+        }
     if (bufs[ws_slab].n < slab_need + 16) bufs[ws_slab].ensure(ctx, slab_need + 16);
 }
 
@@ -166,6 +198,8 @@ void rfi_model::refresh_plane_weights() {
                 need += wb_elems(4, b.cin, b.cout, b.cout, 1) + 32 + 3 * (wb_elems(4, b.cin, b.cout, 0, 1) + 32);
                 cls_need += s2_class_floats(b.cout, b.cin);
             }
+        if (P == 1)
+            for (auto& u : ups) need += wb_elems(1, 4 * u.cout, u.cin, 0, 1) + 32 + wb_elems(4, u.cin, u.cout, 0, 1) + 32;
         wb_pool = static_cast<bf16_t*>(ctx->alloc(need * 2));
         RFI_CHECK_HIP(hipMemsetAsync(wb_pool, 0, need * 2, ctx->stream));       // the zero tails stay zero
         if (cls_need && !rs_cls_pool) rs_cls_pool = static_cast<float*>(ctx->alloc(cls_need * sizeof(float)));
@@ -203,6 +237,18 @@ void rfi_model::refresh_plane_weights() {
                 wb_bytes += 2.0 * e + 16.0 * b.cin * b.cout * (c == 0 ? 2 : 1);
             }
         }
+        if (P == 1)
+            for (auto& u : ups) {                 // forward layout [4][cout][cin] = one 1x1 contraction with 4 cout channels; dgrad layout [4][cin][cout]
+                u.wBf = wb_pool + o;
+                const size_t ef = wb_elems(1, 4 * u.cout, u.cin, 0, 1);
+                o += ef + 32;
+                hd.push_back(WBDesc{params + u.w_off, u.wBf, 1, 4 * u.cout, u.cin, {u.cin, 0}, 1});
+                u.wBd = wb_pool + o;
+                const size_t ed = wb_elems(4, u.cin, u.cout, 0, 1);
+                o += ed + 32;
+                hd.push_back(WBDesc{u.wd, u.wBd, 4, u.cin, u.cout, {u.cout, 0}, 1});
+                wb_bytes += 2.0 * (ef + ed) + 32.0 * u.cin * u.cout;
+            }
         wb_n = (int)hd.size();
         wb_descs = ctx->alloc(hd.size() * sizeof(WBDesc));
         RFI_CHECK_HIP(hipMemcpyAsync(wb_descs, hd.data(), hd.size() * sizeof(WBDesc), hipMemcpyHostToDevice, ctx->stream));
@@ -346,15 +392,43 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
     {
         Shape s{n, h >> D, w >> D};
         double_conv(this, convs[IB], convs[IB + 1], &cur, 1, s, yt(bottY1, y16_flow ? yB1 : -1), pl[pA1b],
-                    yt(bottY2, -1), train_mode);            // (read by the transposed conv: float32 tensor)
+                    yt(bottY2, convt_planes ? yB2 : -1), train_mode);     // (read by the transposed conv: float32 tensor for the round-1 kernel)
     }
     const float* prevY = buf(bottY2);
+    const PlaneBuf* prevY16 = convt_planes ? &pl[yB2] : nullptr;
     ConvBN* prevBN = &convs[IB + 1];
     for (int l = D; l >= 1; --l) {
         const int k = D - l;
         UpConv& u = ups[k];
         Shape sin{n, h >> l, w >> l};
         Shape s{n, h >> (l - 1), w >> (l - 1)};
+        if (convt_planes) {
+            // ConvTranspose2d(k2, s2) on the plane kernels: the input activated once into planes, then ONE 1x1 contraction whose
+            // 4 cout output channels are the four taps -- each lands on its own pixel of the 2 x 2 block (PConvArgs::zblocks)
+            const int64_t Min = (int64_t)sin.N * sin.H * sin.W;
+            launch_act_split(ctx, View{nullptr, u.cin}, Min, u.cin, bn_xf(*prevBN), 1, pl[pUpIn[l]].p, pl[pUpIn[l]].pstride, prevY16->p,
+                             prevY16->pstride);
+            PConvArgs a;
+            a.x[0] = seg_of(pl[pUpIn[l]]);
+            a.nseg = 1; a.P = 1;
+            a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = sin.H; a.Win = sin.W;
+            a.R = 1; a.S = 1; a.pad = 0;
+            a.Cout = 4 * u.cout;
+            a.zblocks = u.cout / 32;
+            a.wB = u.wBf;
+            a.bias = params + u.b_off;
+            a.y16 = pl[pUp[l]].p; a.y_pstride = (int)pl[pUp[l]].pstride;
+            a.Hout = s.H; a.Wout = s.W; a.osy = 2; a.osx = 2;
+            a.algo_flops = 2.0 * Min * 4.0 * u.cin * u.cout;
+            launch_pconv(ctx, a);
+            ConvBN& c1 = convs[IB + 2 + 2 * k];
+            ConvBN& c2 = convs[IB + 2 + 2 * k + 1];
+            const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};
+            double_conv(this, c1, c2, in2, 2, s, yt(decY1[l], yD1[l]), pl[pA1d[l]], yt(decY2[l], l == 1 ? yD2top : yD2[l]), train_mode);
+            prevY16 = l == 1 ? &pl[yD2top] : &pl[yD2[l]];
+            prevBN = &c2;
+            continue;
+        }
         ConvArgs a;                               // ConvTranspose2d(k2,s2): the round-1 kernel, float32 tensors
         a.x = View{prevY, u.cin};
         a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = sin.H; a.Win = sin.W;
@@ -513,14 +587,13 @@ void rfi_model::backward_resnet_planes(int n, int h, int w) {
         const ResBlock& lb = blocks.back();
         const PlaneBuf& A = pl[rpb.back().A];
         launch_pool_bwd_merge(ctx, YRef(A.p, A.pstride), n, h >> (D - 1), w >> (D - 1), lb.cout, rs_ones, rs_zeros,
-                              View{buf(dconcat[D]) + lb.cout, 2 * lb.cout}, YRef(pl[g16pool[D]].p, pl[g16pool[D]].pstride), nullptr, 0.0f,
-                              pl[rp_dX].p);
+                              skip_grad(D, lb.cout), YRef(pl[g16pool[D]].p, pl[g16pool[D]].pstride), nullptr, 0.0f, pl[rp_dX].p);
     }
     // (the scratch tensors rp_dA1 / rp_dX / rp_dz serve every level: dense [M][C] views of them)
     auto view = [&](int idx, int C) { PlaneBuf v = pl[idx]; v.pstride = C; v.nchunks = C / 16; return v; };
     const bf16_t* g0 = pl[rp_dX].p;               // the terms of g (dense bfloat16 [M][C]) ...
     const bf16_t* g1 = nullptr;
-    View g2{};                                    // ... and the decoder's skip gradient (float32 view), at stage boundaries
+    YRef g2((const float*)nullptr);               // ... and the decoder's skip gradient (a view), at stage boundaries
     for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
         ResBlock& b = blocks[bi];
         const ResPlanes& r = rpb[bi];
@@ -540,7 +613,7 @@ void rfi_model::backward_resnet_planes(int n, int h, int w) {
         const YRef dA1(pl[rp_dA1].p, (int64_t)b.cout);
         if (b.stride == 1) {
             backward_pconv_bn(this, c1, dA1, YRef(pl[r.Y1].p, pl[r.Y1].pstride), &in, 1, s, GT(dXv), pl[r.dY1], rec1);
-            g0 = pl[rp_dX].p; g1 = dz.p; g2 = View{};
+            g0 = pl[rp_dX].p; g1 = dz.p; g2 = YRef((const float*)nullptr);
         } else {
             ConvBN& cd = convs[b.cd];
             backward_pconv_bn(this, c1, dA1, YRef(pl[r.Y1].p, pl[r.Y1].pstride), &in, 1, s, GT(nullptr), pl[r.dY1], rec1);
@@ -563,7 +636,7 @@ void rfi_model::backward_resnet_planes(int n, int h, int w) {
                 launch_pconv(ctx, a);
             }
             g0 = pl[rp_dX].p; g1 = nullptr;
-            g2 = View{buf(dconcat[b.level - 1]) + b.cin, 2 * b.cin};      // the previous stage's output is also a skip
+            g2 = skip_grad(b.level - 1, b.cin);   // the previous stage's output is also a skip
         }
         bucket_ready(c1.w_off, (size_t)(bi + 1 < (int)blocks.size() ? convs[blocks[bi + 1].c1].w_off : convs[i_bott].w_off));
     }
@@ -572,7 +645,7 @@ void rfi_model::backward_resnet_planes(int n, int h, int w) {
         Shape s{n, h, w};
         const int64_t M = (int64_t)n * h * w;
         PlaneBuf& g = pl[rp_dz[1]];               // (block 0 used rp_dz[0])
-        launch_relu_mask_sum16(ctx, g0, c.cout, g1, c.cout, View{}, nullptr, 0, M, c.cout, g.p, c.cout);
+        launch_relu_mask_sum16(ctx, g0, c.cout, g1, c.cout, YRef((const float*)nullptr), nullptr, 0, M, c.cout, g.p, c.cout);
         const PlaneSeg in = seg_of(pl[pXin]);
         backward_pconv_bn(this, c, YRef(g.p, (int64_t)c.cout), YRef(pl[rpStemY].p, pl[rpStemY].pstride), &in, 1, s, GT(nullptr), pl[rpdY0]);
         bucket_ready(0, convs[blocks[0].c1].w_off);
@@ -604,6 +677,7 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
                                        grads + head_b_off, act_slope, last.mean(), last.invstd(), buf(ws_red),
                                        g16_flow && out_ch == 1 ? pl[g16A[1]].p : nullptr);
     }
+    int up_records = 0;                           // BatchNorm-backward records a transposed conv's input-gradient kernel left for the layer below
     for (int l = 1; l <= D; ++l) {                // decoders, shallow to deep
         const int k = D - l;
         Shape s{n, h >> (l - 1), w >> (l - 1)};
@@ -612,16 +686,64 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         ConvBN& c2 = convs[IB + 2 + 2 * k + 1];
         UpConv& u = ups[k];
         const PlaneSeg a1 = seg_of(pl[pA1d[l]]);
-        const int rec1 = backward_pconv_bn(this, c2, gt(gA[l], g16_flow && out_ch == 1 && l == 1 ? g16A[1] : -1).ref(),
-                                           yr(decY2[l], y16_flow && l == 1 ? yD2top : -1), &a1, 1, s,
-                                           gt(gB[l], g16_flow ? g16B[l] : -1), pl[pdYa[l]], l == 1 ? head_records : 0, &c1,
+        // (with the transposed convs on the plane kernels the gradient arriving from decoder l - 1's is a bfloat16 tensor, the
+        // BatchNorm-backward sums of c2 came out of that kernel's epilogue, and Y2 is a bfloat16 tensor)
+        const bool up16 = convt_planes && l > 1;
+        const int rec1 = backward_pconv_bn(this, c2, gt(gA[l], up16 || (g16_flow && out_ch == 1 && l == 1) ? g16A[l] : -1).ref(),
+                                           yr(decY2[l], y16_flow && l == 1 ? yD2top : (up16 ? yD2[l] : -1)), &a1, 1, s,
+                                           gt(gB[l], g16_flow ? g16B[l] : -1), pl[pdYa[l]], l == 1 ? head_records : up_records, &c1,
                                            yr(decY1[l], y16_flow ? yD1[l] : -1));
         const PlaneSeg in2[2] = {seg_of(pl[pUp[l]]), seg_of(pl[pSkip[l]])};
-        backward_pconv_bn(this, c1, gt(gB[l], g16_flow ? g16B[l] : -1).ref(), yr(decY1[l], y16_flow ? yD1[l] : -1), in2, 2, s, buf(dconcat[l]), pl[pdYb[l]],
-                          rec1);
+        backward_pconv_bn(this, c1, gt(gB[l], g16_flow ? g16B[l] : -1).ref(), yr(decY1[l], y16_flow ? yD1[l] : -1), in2, 2, s,
+                          convt_planes ? GT(pl[g16cat[l]]) : GT(buf(dconcat[l])), pl[pdYb[l]], rec1);
+        ConvBN& prevBN = (l == D) ? convs[IB + 1] : convs[IB + 2 + 2 * (k - 1) + 1];
+        if (convt_planes) {
+            // ConvTranspose on the plane kernels: dUp = the first C channels of the bfloat16 [up | skip] gradient
+            const PlaneBuf& cat = pl[g16cat[l]];
+            const PlaneSeg dUp{cat.p, cat.pstride, plane_chunks(u.cout)};
+            launch_channel_sum(ctx, YRef(cat.p, cat.pstride), (int64_t)s.N * s.H * s.W, u.cout, buf(ws_red), grads + u.b_off);
+            PWgradArgs wa;                        // dW[tap][cout][cin] = sum_pixels act(prev)[i, j, cin] * dUp[2 i + a, 2 j + b, cout]
+            wa.xop[0] = dUp; wa.nseg = 1; wa.seg_c[0] = u.cout;
+            wa.yop = seg_of(pl[pUpIn[l]]); wa.Cy = u.cin; wa.P = 1;
+            wa.N = sin.N; wa.H = sin.H; wa.W = sin.W; wa.Hx = s.H; wa.Wx = s.W;
+            wa.R = 2; wa.S = 2; wa.pad = 0;
+            wa.dw = grads + u.w_off;
+            wa.tap_stride = (int64_t)u.cin * u.cout;
+            wa.sy = 1; wa.sx = u.cin;
+            wa.algo_flops = 2.0 * sin.N * sin.H * sin.W * 4.0 * u.cin * u.cout;
+            wa.slab = buf(ws_slab);
+            wa.slab_floats = bufs[ws_slab].n;
+            {
+                SideScopeP side(this);
+                launch_pwgrad(ctx, wa);
+                side.end();
+            }
+            PConvArgs a;                          // the input gradient: a 2x2 stride-2 contraction of dUp, bfloat16 out, with the
+            a.x[0] = dUp; a.nseg = 1; a.P = 1;    // BatchNorm-backward sums of the layer below in the epilogue
+            a.N = sin.N; a.H = sin.H; a.W = sin.W; a.Hin = s.H; a.Win = s.W;
+            a.R = 2; a.S = 2; a.pad = 0;
+            a.Cout = u.cin;
+            a.wB = u.wBd;
+            PlaneBuf& dprev = (l == D) ? pl[g16BottA] : pl[g16A[l + 1]];
+            const PlaneBuf& prevY16 = (l == D) ? pl[yB2] : pl[yD2[l + 1]];
+            a.y16 = dprev.p; a.y_pstride = (int)dprev.pstride;
+            a.Hout = sin.H; a.Wout = sin.W;
+            a.algo_flops = 2.0 * sin.N * sin.H * sin.W * 4.0 * u.cin * u.cout;
+            float* ws = buf(ws_red);
+            a.stats = reinterpret_cast<double*>(ws);
+            a.stats_max_records = (int)(bn_stats_ws_floats(u.cin) / ((size_t)u.cin * 4));
+            a.bwd_y16 = prevY16.p;
+            a.bwd_yps = prevY16.pstride;
+            a.bwd_scale = prevBN.scale(); a.bwd_shift = prevBN.shift();
+            a.bwd_mean = prevBN.mean(); a.bwd_invstd = prevBN.invstd();
+            a.bwd_slope = act_slope;
+            launch_pconv(ctx, a);
+            up_records = a.stats_records;
+            bucket_ready(u.w_off, l == 1 ? n_flat : ups[k + 1].w_off);
+            continue;
+        }
         // ConvTranspose: dUp = dconcat[..., 0:C]; the round-1 kernels on float32 tensors
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
-        ConvBN& prevBN = (l == D) ? convs[IB + 1] : convs[IB + 2 + 2 * (k - 1) + 1];
         View dUp{buf(dconcat[l]), 2 * u.cout};
         launch_channel_sum(ctx, dUp, (int64_t)s.N * s.H * s.W, u.cout, buf(ws_red), grads + u.b_off);
         WgradArgs wa;
@@ -661,8 +783,9 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     {                                             // bottleneck
         Shape s{n, h >> D, w >> D};
         const PlaneSeg a1 = seg_of(pl[pA1b]), p4 = seg_of(pl[pPool[D]]);
-        const int rec1 = backward_pconv_bn(this, convs[IB + 1], buf(gBottA), buf(bottY2), &a1, 1, s, gt(gBottB, g16_flow ? g16BottB : -1),
-                                           pl[pdYbottA], 0, &convs[IB], yr(bottY1, y16_flow ? yB1 : -1));
+        const int rec1 = backward_pconv_bn(this, convs[IB + 1], gt(gBottA, convt_planes ? g16BottA : -1).ref(), yr(bottY2, convt_planes ? yB2 : -1), &a1, 1,
+                                           s, gt(gBottB, g16_flow ? g16BottB : -1), pl[pdYbottA], convt_planes ? up_records : 0, &convs[IB],
+                                           yr(bottY1, y16_flow ? yB1 : -1));
         backward_pconv_bn(this, convs[IB], gt(gBottB, g16_flow ? g16BottB : -1).ref(), yr(bottY1, y16_flow ? yB1 : -1), &p4, 1, s,
                           gt(dpool[D], g16_flow ? g16pool[D] : -1), pl[pdYbottB], rec1);
         bucket_ready(convs[IB].w_off, ups[0].w_off);
@@ -672,12 +795,13 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         Shape s{n, h >> (l - 1), w >> (l - 1)};
         ConvBN& c1 = convs[2 * (l - 1)];
         ConvBN& c2 = convs[2 * (l - 1) + 1];
+        const YRef dskip = skip_grad(l, c2.cout);
         const int have = launch_pool_bwd_merge_sums(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), c2.mean(),
-                                                    c2.invstd(), View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(),
+                                                    c2.invstd(), dskip, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(),
                                                     buf(gA[l]), act_slope, buf(ws_red), g16_flow ? pl[g16A[l]].p : nullptr);
         if (!have)
             launch_pool_bwd_merge(ctx, yr(encY2[l], y16_flow ? yE2[l] : -1), s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(),
-                                  View{buf(dconcat[l]) + c2.cout, 2 * c2.cout}, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(), buf(gA[l]), act_slope,
+                                  dskip, gt(dpool[l], g16_flow ? g16pool[l] : -1).ref(), buf(gA[l]), act_slope,
                                   g16_flow ? pl[g16A[l]].p : nullptr);
         const PlaneSeg a1 = seg_of(pl[pA1e[l]]);
         const int rec1 = backward_pconv_bn(this, c2, gt(gA[l], g16_flow ? g16A[l] : -1).ref(), yr(encY2[l], y16_flow ? yE2[l] : -1), &a1, 1, s, gt(gB[l], g16_flow ? g16B[l] : -1),

@@ -40,8 +40,8 @@ void launch_bn_relu_pool_planes(rfi_ctx* ctx, const float* y, int N, int H, int 
 // out = relu(y * scale + shift + shortcut), shortcut = s * s_scale + s_shift (a projection's raw output) or s (s_scale null)
 void launch_bn_add_relu16(rfi_ctx* ctx, const bf16_t* y, int64_t y_ps, const float* scale, const float* shift, const bf16_t* s, int64_t s_ps,
                           const float* s_scale, const float* s_shift, int64_t M, int C, bf16_t* out, int64_t out_ps);
-// dz = (g0 + g1 + g2) * (a > 0): g1 / g2 (a float32 view) / the mask are optional
-void launch_relu_mask_sum16(rfi_ctx* ctx, const bf16_t* g0, int64_t p0, const bf16_t* g1, int64_t p1, View g2, const bf16_t* a, int64_t pa,
+// dz = (g0 + g1 + g2) * (a > 0): g1 / g2 (a float32 or bfloat16 view) / the mask are optional
+void launch_relu_mask_sum16(rfi_ctx* ctx, const bf16_t* g0, int64_t p0, const bf16_t* g1, int64_t p1, YRef g2, const bf16_t* a, int64_t pa,
                             int64_t M, int C, bf16_t* dz, int64_t pz);
 // input gradient of a 3x3 stride-2 pad-1 conv as four 2x2 stride-1 pad-0 contractions of dY, one per parity class
 // c = 2 py + px of the input pixel (written with output stride 2): float32 filters [class][tap t = 2 ty + tx][Cin][K] with
@@ -94,6 +94,9 @@ struct PConvArgs {
                                       // read float32 tensors)
     int Hout = 0, Wout = 0;
     int osy = 1, osx = 1, ooy = 0, oox = 0;
+    int zblocks = 0;                  // > 0 (ConvTranspose2d(k2, s2) as ONE 1x1 contraction with 4 Cz output channels, Cz = 32 zblocks):
+                                      // output channel block cb belongs to filter tap z = cb / zblocks = 2 a + b and lands at pixel
+                                      // (oy osy + ooy + a, ox osx + oox + b), channels 32 (cb % zblocks) ..; bias has Cz entries
     int R = 3, S = 1, pad = 1;
     double* stats = nullptr;          // as ConvArgs::stats
     int stats_max_records = 0;

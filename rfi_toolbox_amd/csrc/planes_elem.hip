@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256) void bn_add_relu16_kernel(const bf16_t* __rest
 }
 // dz = (g0 + g1 + g2) * (a > 0)   (g1, g2, a optional; g2 a float32 view)
 __global__ __launch_bounds__(256) void relu_mask_sum16_kernel(const bf16_t* __restrict__ g0, int64_t p0, const bf16_t* __restrict__ g1, int64_t p1,
-                                                             const float* __restrict__ g2, int64_t p2, const bf16_t* __restrict__ a, int64_t pa,
-                                                             int64_t M, int C, bf16_t* __restrict__ dz, int64_t pz) {
+                                                             const void* __restrict__ g2, int g2_16, int64_t p2, const bf16_t* __restrict__ a,
+                                                             int64_t pa, int64_t M, int C, bf16_t* __restrict__ dz, int64_t pz) {
     const int groups = C / 8;
     const int64_t total = M * groups;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void relu_mask_sum16_kernel(const bf16_t* __re
             for (int e = 0; e < 8; ++e) v[e] += u[e];
         }
         if (g2) {
-            load8(g2 + m * p2 + c0, u);
+            if (g2_16) load8(static_cast<const bf16_t*>(g2) + m * p2 + c0, u);
+            else load8(static_cast<const float*>(g2) + m * p2 + c0, u);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += u[e];
         }
@@ -375,15 +376,15 @@ void launch_bn_add_relu16(rfi_ctx* ctx, const bf16_t* y, int64_t y_ps, const flo
     check_launch("bn_add_relu16");
 }
 
-void launch_relu_mask_sum16(rfi_ctx* ctx, const bf16_t* g0, int64_t p0, const bf16_t* g1, int64_t p1, View g2, const bf16_t* a, int64_t pa,
+void launch_relu_mask_sum16(rfi_ctx* ctx, const bf16_t* g0, int64_t p0, const bf16_t* g1, int64_t p1, YRef g2, const bf16_t* a, int64_t pa,
                             int64_t M, int C, bf16_t* dz, int64_t pz) {
-    RFI_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && p0 % 8 == 0 && (!g1 || p1 % 8 == 0) && (!g2.p || g2.pstride % 4 == 0) && (!a || pa % 8 == 0) &&
+    RFI_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && p0 % 8 == 0 && (!g1 || p1 % 8 == 0) && (!g2.p || g2.stride(C) % (g2.bf16 ? 8 : 4) == 0) && (!a || pa % 8 == 0) &&
                     pz % 8 == 0 && al16(g0) && al16(g1) && al16(g2.p) && al16(a) && al16(dz),
                 "relu_mask_sum16: channels in whole groups of 8, 16-byte aligned rows");
-    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * (4 + (g1 ? 2 : 0) + (g2.p ? 4 : 0) + (a ? 2 : 0)));
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, (double)M * C * (4 + (g1 ? 2 : 0) + (g2.p ? (g2.bf16 ? 2 : 4) : 0) + (a ? 2 : 0)));
     int64_t blocks = cdiv(M * (C / 8), 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(relu_mask_sum16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g0, p0, g1, p1, g2.p, (int64_t)g2.pstride, a, pa,
+    hipLaunchKernelGGL(relu_mask_sum16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g0, p0, g1, p1, g2.p, g2.bf16, g2.stride(C), a, pa,
                        M, C, dz, pz);
     check_launch("relu_mask_sum16");
 }

@@ -377,12 +377,14 @@ int shape_class(const PWgradArgs& a) {
     if (a.R == 3 && a.S == 1 && a.pad == 1) return 0;
     if (a.P == 1 && a.R == 3 && a.S == 2 && a.pad == 1) return 1;
     if (a.P == 1 && a.R == 1 && a.S == 2 && a.pad == 0) return 2;
+    if (a.P == 1 && a.R == 2 && a.S == 2 && a.pad == 0) return 3;      // ConvTranspose2d(k2, s2): Xop = the output gradient
     return -1;
 }
 Plan select_any(rfi_ctx* ctx, PWgradDev& d, int what) {
     switch (shape_class(d.a)) {
         case 1: return select<1, 3, 2>(ctx, d, what);
         case 2: return select<1, 1, 2>(ctx, d, what);
+        case 3: return select<1, 2, 2>(ctx, d, what);
         default: return d.a.P == 3 ? select<3>(ctx, d, what) : select<1>(ctx, d, what);
     }
 }
@@ -415,7 +417,7 @@ size_t pwgrad_slab_floats(const PWgradArgs& a) {
 
 void launch_pwgrad(rfi_ctx* ctx, const PWgradArgs& a) {
     RFI_REQUIRE(a.P == 1 || a.P == 3, "pwgrad: planes must be 1 or 3");
-    RFI_REQUIRE(shape_class(a) >= 0, "pwgrad: 3x3 stride 1 pad 1; bfloat16 flow also 3x3 stride 2 pad 1 and 1x1 stride 2");
+    RFI_REQUIRE(shape_class(a) >= 0, "pwgrad: 3x3 stride 1 pad 1; bfloat16 flow also 3x3 stride 2 pad 1, 1x1 stride 2, 2x2 stride 2 pad 0");
     RFI_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.Cy > 0 && a.seg_c[0] > 0, "pwgrad: empty shape");
     RFI_REQUIRE(std::max(a.yop.nchunks, std::max(a.xop[0].nchunks, a.nseg > 1 ? a.xop[1].nchunks : 0)) * a.P * 2 <= 256,
                 "pwgrad: more than 42 (P = 3) / 128 (P = 1) chunks per operand segment");

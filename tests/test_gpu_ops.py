@@ -429,6 +429,37 @@ def test_stride2_convolutions_on_the_plane_kernels(shape, ksize):
     assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, "wgrad"
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 32), (1, 64, 64, 128, 64), (1, 8, 32, 256, 128), (3, 4, 4, 32, 32), (1, 12, 20, 48, 64),
+                                   (2, 32, 32, 1024, 512)])
+def test_transposed_conv_on_the_plane_kernels(shape):
+    """ConvTranspose2d(k2, s2) in the bfloat16 flow: forward = ONE 1x1 contraction on the input planes whose 4 cout output
+    channels are the four taps, each written to its own pixel of the 2 x 2 block; input gradient = a 2x2 stride-2
+    contraction of dy; weight gradient = the strided pixel reduction with dy as the halo operand.  Against torch on the
+    bf16-ROUNDED operands."""
+    n, h, w, cin, cout = shape
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    g = torch.Generator().manual_seed(17 + hash(shape) % 1000)
+    x = bf(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = bf(torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv_transpose2d(x, wt, b, stride=2)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    c = ctx()
+    dxd, dwd, dbd, ddy = c.to_device(nhwc(x.detach())), c.to_device(wt.detach().numpy()), c.to_device(b.numpy()), c.to_device(nhwc(dy))
+    out = c.empty((n, 2 * h, 2 * w, cout))
+    check(lib.rfi_op_convt2x2(c.handle, IMPL_PBF16, P(dxd), n, h, w, cin, P(dwd), P(dbd), cout, P(out)))
+    want = nhwc(y.detach())
+    assert np.abs(out.numpy() - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-6, "fwd"
+    gx = c.empty((n, h, w, cin))
+    check(lib.rfi_op_convt2x2_dgrad(c.handle, IMPL_PBF16, P(ddy), n, h, w, cout, P(dwd), cin, P(gx)))
+    want = nhwc(x.grad)
+    assert np.abs(gx.numpy() - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-6, "dgrad"
+    gw = c.empty((cin, cout, 2, 2))
+    check(lib.rfi_op_convt2x2_wgrad(c.handle, IMPL_PBF16, P(dxd), P(ddy), n, h, w, cin, cout, P(gw)))
+    assert rel_err(gw.numpy(), wt.grad.numpy()) <= 5e-5, "wgrad"
+
+
 @pytest.mark.parametrize("shape", [(1, 8, 32, 64, 64), (2, 4, 4, 64, 64), (1, 8, 32, 3136, 128), (250, 1, 1, 3136, 128), (1, 8, 32, 256, 1024),
                                    (1, 8, 32, 2048, 512), (1, 8, 32, 64, 32), (3, 5, 7, 32, 96)])
 @pytest.mark.parametrize("xform", [False, True])
