@@ -48,11 +48,11 @@ struct ChanGeom {
     int rblocks;
 };
 
-static ChanGeom chan_geom(int64_t M, int C, int max_rblocks, bool allow_vec = true) {
+static ChanGeom chan_geom(int64_t M, int C, int max_rblocks, bool allow_vec = true, int force_v = 0) {
     ChanGeom g;
-    g.V = (allow_vec && C % 4 == 0) ? 4 : 1;
+    g.V = force_v ? force_v : (allow_vec && C % 4 == 0) ? 4 : 1;
     const int lanes_needed = C / g.V;
-    int cl = (g.V == 4) ? 1 : 4;
+    int cl = (g.V >= 4) ? 1 : 4;
     while (cl < lanes_needed && cl < 64) cl <<= 1;
     g.CL = cl;
     g.RL = kBlock / cl;
@@ -123,15 +123,45 @@ __device__ __forceinline__ void row_lane_reduce(double (&acc)[NQ][V], double* re
 #pragma unroll
         for (int v = 0; v < V; ++v) red[(q * V + v) * kBlock + threadIdx.x] = acc[q][v];
     __syncthreads();
-    if (rl == 0) {
+    // row lanes 0..3 each fold a quarter of the RL entries (four independent chains of LDS reads instead of one serial one:
+    // with 8 channels per lane and 64 row lanes the single chain was longer than the block's whole main loop), then lane 0
+    // adds the four in fixed order
+    const int NF = RL >= 4 ? 4 : 1;
+    if (rl < NF) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                double t = acc[q][v];
-                for (int k = 1; k < RL; ++k) t += red[(q * V + v) * kBlock + k * CL + cl];
-                acc[q][v] = t;
+                double t0 = rl == 0 ? acc[q][v] : 0.0, t1 = 0.0;
+                const double* rp = red + (q * V + v) * kBlock + cl;
+                int k = rl == 0 ? NF : rl;
+                for (; k + NF < RL; k += 2 * NF) {
+                    t0 += rp[k * CL];
+                    t1 += rp[(k + NF) * CL];
+                }
+                if (k < RL) t0 += rp[k * CL];
+                acc[q][v] = t0 + t1;
             }
+    }
+    if (NF > 1) {
+        __syncthreads();
+        if (rl > 0 && rl < NF) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int v = 0; v < V; ++v) red[(q * V + v) * kBlock + threadIdx.x] = acc[q][v];
+        }
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    double t = acc[q][v];
+                    for (int j = 1; j < NF; ++j) t += red[(q * V + v) * kBlock + j * CL + cl];
+                    acc[q][v] = t;
+                }
+        }
     }
 }
 
@@ -277,6 +307,137 @@ __global__ void bn_bwd_reduce_kernel(const void* __restrict__ da, int da16, cons
     }
 }
 
+// ---- the same two passes for the bfloat16 data flow (dA and Y bfloat16, dense / chunk-padded rows; C % 8 == 0): 8 channels per
+// lane -- one 16-byte load per tensor, row and lane, ONE 16-byte store of the bf16 dY row piece -- and the per-channel sums
+// in float32 over 8 rows at a time, then fp64 (the generic kernels above: 8-byte loads, four 2-byte stores and two to five
+// fp64 operations per element, 2.8 - 3.9 TB/s on the 1024 x 1024 x 64 tensors; these: the elementwise kernels' rate)
+__device__ __forceinline__ void ld8h(const unsigned short* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+    v[4] = __builtin_bit_cast(float, t.z << 16); v[5] = __builtin_bit_cast(float, t.z & 0xffff0000u);
+    v[6] = __builtin_bit_cast(float, t.w << 16); v[7] = __builtin_bit_cast(float, t.w & 0xffff0000u);
+}
+__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {      // RNE; NaN stays NaN
+    const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__global__ __launch_bounds__(kBlock) void bn_bwd_reduce16_kernel(const unsigned short* __restrict__ da, const unsigned short* __restrict__ y, int64_t yps, int64_t M,
+                                       int C, int CL, int64_t rows_per_block, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       double* __restrict__ partial, float slope) {
+    __shared__ double red[2 * 8 * kBlock];
+    const int RL = kBlock / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = (blockIdx.y * CL + cl) * 8;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    double acc[2][8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) acc[0][v] = acc[1][v] = 0;
+    if (c < C) {
+        float sc[8], sh[8], mu[8], is[8];
+        ld8f(scale + c, sc); ld8f(shift + c, sh); ld8f(mean + c, mu); ld8f(invstd + c, is);
+        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)RL * 8) {
+            float p1[8], p2[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) p1[v] = p2[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t r = rb + (int64_t)k * RL;
+                if (r < r1) {
+                    float yv[8], dv[8];
+                    ld8h(y + r * yps + c, yv);
+                    ld8h(da + r * C + c, dv);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
+                        p1[v] += dz;
+                        p2[v] += dz * ((yv[v] - mu[v]) * is[v]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                acc[0][v] += (double)p1[v];
+                acc[1][v] += (double)p2[v];
+            }
+        }
+    }
+    row_lane_reduce<8, 2>(acc, red, CL, RL, cl, rl);
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            partial[((int64_t)blockIdx.x * C + c + v) * 2 + 0] = acc[0][v];
+            partial[((int64_t)blockIdx.x * C + c + v) * 2 + 1] = acc[1][v];
+        }
+    }
+}
+// dY as bf16 planes (P = 1); SUMS: partial[rb * C + c] = sum dy (the conv bias gradient; layers without a bias skip it)
+template <bool SUMS>
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply16_kernel(const unsigned short* __restrict__ da, const unsigned short* __restrict__ y, int64_t yps, int64_t M,
+                                      int C, int CL, int64_t rows_per_block, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      const float* __restrict__ gamma, const float* __restrict__ c1, const float* __restrict__ c2,
+                                      double* __restrict__ partial, float slope, unsigned short* __restrict__ planes, int64_t pl_stride) {
+    __shared__ double red[SUMS ? 8 * kBlock : 1];
+    const int RL = kBlock / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = (blockIdx.y * CL + cl) * 8;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    double acc[1][8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) acc[0][v] = 0;
+    if (c < C) {
+        float sc[8], sh[8], mu[8], is[8], g[8], k1[8], k2[8];
+        ld8f(scale + c, sc); ld8f(shift + c, sh); ld8f(mean + c, mu); ld8f(invstd + c, is);
+        ld8f(gamma + c, g); ld8f(c1 + c, k1); ld8f(c2 + c, k2);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) g[v] = g[v] * is[v];
+        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)RL * 8) {
+            float p1[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) p1[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t r = rb + (int64_t)k * RL;
+                if (r < r1) {
+                    float yv[8], dv[8], o[8];
+                    ld8h(y + r * yps + c, yv);
+                    ld8h(da + r * C + c, dv);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
+                        const float xh = (yv[v] - mu[v]) * is[v];
+                        o[v] = g[v] * (dz - k1[v] - xh * k2[v]);
+                        if (SUMS) p1[v] += o[v];
+                    }
+                    *reinterpret_cast<uint4*>(planes + r * pl_stride + c) =
+                        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+                }
+            }
+            if (SUMS) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) acc[0][v] += (double)p1[v];
+            }
+        }
+    }
+    if constexpr (SUMS) {
+        row_lane_reduce<8, 1>(acc, red, CL, RL, cl, rl);
+        if (rl == 0 && c < C) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) partial[(int64_t)blockIdx.x * C + c + v] = acc[0][v];
+        }
+    }
+}
+
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int records, int C,
                                        double count, float* c1, float* c2, float* dgamma,
                                        float* dbeta) {
@@ -354,12 +515,17 @@ __global__ void bn_bwd_apply_kernel(void* __restrict__ da_, int da16, const void
 #pragma unroll
                 for (int v = 0; v < V; ++v) res[v] = o[v];
                 for (int p = 0; p < P; ++p) {
+                    unsigned short hq[V];
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
                         const __bf16 h = (__bf16)res[v];                                  // RNE; NaN stays NaN
-                        q[p * 16 + v] = __builtin_bit_cast(unsigned short, h);
+                        hq[v] = __builtin_bit_cast(unsigned short, h);
                         res[v] -= (float)h;
                     }
+                    if constexpr (V == 4)              // one 8-byte store per piece (c % 4 == 0: aligned)
+                        *reinterpret_cast<uint2*>(q + p * 16) = make_uint2((unsigned)hq[0] | ((unsigned)hq[1] << 16), (unsigned)hq[2] | ((unsigned)hq[3] << 16));
+                    else
+                        q[p * 16] = hq[0];
                 }
             } else {
                 stv<V>(static_cast<float*>(da_) + r * C + c, o);        // (float32 tensors only: the launcher checks)
@@ -1248,7 +1414,18 @@ void launch_bn_bwd_reduce(rfi_ctx* ctx, YRef da, YRef y, int64_t M, int C,
                           const float* invstd, float* partial_ws, float* c1, float* c2,
                           float* dgamma, float* dbeta, float slope) {
     ChanGeom g = geom_rows(M, C);
-    {
+    static const bool no16 = getenv("RFI_NO_BN16") != nullptr;          // A/B runs: the generic kernels for bfloat16 tensors too
+    const bool fast16 = !no16 && da.bf16 && y.bf16 && C % 8 == 0 && da.stride(C) == C && y.stride(C) % 8 == 0 &&
+                        !((reinterpret_cast<uintptr_t>(da.p) | reinterpret_cast<uintptr_t>(y.p) | reinterpret_cast<uintptr_t>(scale) |
+                           reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(invstd)) & 15);
+    if (fast16) {
+        g = chan_geom(M, C, kMaxRowBlocks, true, 8);
+        ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 4);
+        hipLaunchKernelGGL(bn_bwd_reduce16_kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream,
+                           static_cast<const unsigned short*>(da.p), static_cast<const unsigned short*>(y.p), y.stride(C), M, C, g.CL,
+                           g.rows_per_block, scale, shift, mean, invstd, reinterpret_cast<double*>(partial_ws), slope);
+        check_launch("bn_bwd_reduce16");
+    } else {
         RFI_REQUIRE(da.stride(C) == C && (!da.bf16 || g.V == 4), "bn_bwd_reduce: the gradient tensor must be dense (bfloat16: C % 4 == 0)");
         ProfScope ps(ctx, FAM_BN, 0, (double)M * C * ((y.bf16 ? 2 : 4) + (da.bf16 ? 2 : 4)));
         if (g.V == 4)
@@ -1277,6 +1454,35 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
                          int64_t planes_pstride, int planes_P, hipEvent_t done, bool finish_dbias, const float* head_dl,
                          const float* head_w) {
     ChanGeom g = geom_rows(M, C);
+    static const bool no16 = getenv("RFI_NO_BN16") != nullptr;
+    const bool fast16 = !no16 && da_inout.bf16 && y.bf16 && planes_out && planes_P == 1 && !head_dl && C % 8 == 0 && da_inout.stride(C) == C &&
+                        y.stride(C) % 8 == 0 && planes_pstride % 8 == 0 && (finish_dbias || !dbias) &&
+                        !((reinterpret_cast<uintptr_t>(da_inout.p) | reinterpret_cast<uintptr_t>(y.p) | reinterpret_cast<uintptr_t>(planes_out) |
+                           reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(mean) |
+                           reinterpret_cast<uintptr_t>(invstd) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(c1) |
+                           reinterpret_cast<uintptr_t>(c2)) & 15);
+    if (fast16) {
+        g = chan_geom(M, C, kMaxRowBlocks, true, 8);
+        {
+            ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 6);
+            auto launch = [&](auto kernel) {
+                hipExtLaunchKernelGGL(kernel, dim3(g.rblocks, g.cblocks), dim3(kBlock), 0, ctx->stream, nullptr, done, 0,
+                                      static_cast<const unsigned short*>(da_inout.p), static_cast<const unsigned short*>(y.p), y.stride(C), M, C, g.CL,
+                                      g.rows_per_block, scale, shift, mean, invstd, gamma, c1, c2, reinterpret_cast<double*>(partial_ws), slope,
+                                      planes_out, planes_pstride);
+            };
+            if (dbias) launch(bn_bwd_apply16_kernel<true>);
+            else launch(bn_bwd_apply16_kernel<false>);
+            check_launch("bn_bwd_apply16");
+        }
+        if (dbias) {
+            ProfScope ps(ctx, FAM_BN);
+            hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0, ctx->stream,
+                               reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, dbias);
+            check_launch("finish_channel_sum");
+        }
+        return;
+    }
     {
         RFI_REQUIRE(da_inout.stride(C) == C && (!da_inout.bf16 || (planes_out && g.V == 4)),
                     "bn_bwd_apply: a bfloat16 gradient tensor needs the plane output and C % 4 == 0");
