@@ -23,7 +23,7 @@ for d, name in (("stats_serial", "kernel_stats"), ("stats_overlap", "kernel_stat
     if hits:
         shutil.copy(hits[0], os.path.join(dst, f"{tag}_{name}.csv"))
 here = os.path.join(ROOT, "tools")
-for dt, suffix in (("f32", ""), ("bf16", "_bf16"), ("cnn3", "_cnn3"), ("unet1024", "_unet1024_bf16"), ("resnet1024", "_resnet1024_bf16regs"),
+for dt, suffix in (("f32", ""), ("bf16", "_bf16"), ("cnn3", "_cnn3"), ("unet1024", "_unet1024_bf16"), ("resnet1024", "_resnet1024_bf16"),
                    ("maskrcnn", "_maskrcnn")):
     fd, wd, md = (os.path.join(src, f"pmc_{k}_{dt}") for k in ("fetch", "write", "mfma"))
     if os.path.isdir(fd) and os.path.isdir(wd):
