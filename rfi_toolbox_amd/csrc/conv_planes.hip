@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
         // bwd: the layer's raw outputs at this lane's (pixel, 4 channels) positions, fetched before any store of the
         // tile is issued (the wait at their first use then never has to pass one of this tile's stores)
         u32x2 ypre[BWD ? MT : 1][BWD ? NTL : 1][2][2];
-        if constexpr (BWD) if (bwd) {
+        if constexpr (BWD) {
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
@@ -303,48 +303,51 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
         if constexpr (VEC) {
             // Quarter blocks (4 accumulator registers = 8 pixel rows x 32 channels) alternate between the two halves of the
             // scratch: the 16-byte read of quarter qi - 1 is issued in front of quarter qi's LDS writes and its arithmetic and
-            // store behind them, so no LDS round trip is waited for (measured on the 64-channel layers at 1024 x 1024: the
-            // epilogue was 10 k of a tile's 26 k cycles with one exposed round trip per half block)
+            // store behind them, so no LDS round trip is waited for.  Tiles that lie inside the image with all their channels
+            // (every tile of the model shapes) run a copy of the loop WITHOUT bounds tests, and the statistics are accumulated
+            // whether or not the launch wants them: the loop is straight-line code -- with a branch per quarter (full tile?
+            // statistics? backward sums?) the compiler waited for every LDS operation at each join and copied the statistics
+            // registers at every merge; skipping the epilogue altogether (RFI_PCONV_DIAG=4) showed it to be 24 % (512-channel
+            // layers) to 42 % (64-channel layers at 1024 x 1024) of the kernel
             constexpr int NQ = NTL * MT * 4;
             const int pl = lane >> 3, g4 = (lane & 7) * 4;
             f32x4 p1[NTL], p2[NTL];
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) p1[nt] = p2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 rq = {0.f, 0.f, 0.f, 0.f};
+            auto quarters = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                f32x4 rq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int qi = 0; qi <= NQ; ++qi) {
-                if (qi > 0) rq = *reinterpret_cast<const f32x4*>(s_ep + ((qi - 1) & 1) * 288 + pl * 36 + g4);
-                if (qi < NQ) {
-                    const int nt = qi / (MT * 4), mt = (qi / 4) % MT, q = qi & 3;
+                for (int qi = 0; qi <= NQ; ++qi) {
+                    if (qi > 0) rq = *reinterpret_cast<const f32x4*>(s_ep + ((qi - 1) & 1) * 288 + pl * 36 + g4);
+                    if (qi < NQ) {
+                        const int nt = qi / (MT * 4), mt = (qi / 4) % MT, q = qi & 3;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) s_ep[(qi & 1) * 288 + (k + 4 * lh) * 36 + li] = ac[mt][nt][q * 4 + k];
-                }
-                if (qi > 0) {
-                    const int pq = qi - 1, nt = pq / (MT * 4), mt = (pq / 4) % MT, q = pq & 3;
-                    const int co = n0 + (wn * NTL + nt) * 32 + g4;
-                    f32x4 v = rq + bias4[nt];
-                    const int p0 = (wm * MT + mt) * 32 + q * 8;                  // first pixel of the row group (wave-uniform)
-                    const unsigned off = tbase + (unsigned)(p0 / TW) * row_st + (unsigned)(p0 % TW) * col_st + lane_off[nt];
-                    const int oy = ct.oy0 + (p0 + pl) / TW, ox = ct.ox0 + (p0 + pl) % TW;
-                    if (full || (co < a.Cout && oy < a.H && ox < a.W)) {
-                        if constexpr (OM >= 1) {                // the tensor holds bf16 values (RNE; NaN stays NaN)
-                            unsigned short qh[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const __bf16 h = (__bf16)v[e];
-                                qh[e] = __builtin_bit_cast(unsigned short, h);
-                                v[e] = (float)h;
-                            }
-                            if constexpr (OM == 2) {
-                                u32x2 pk;
-                                pk[0] = (unsigned)qh[0] | ((unsigned)qh[1] << 16);
-                                pk[1] = (unsigned)qh[2] | ((unsigned)qh[3] << 16);
-                                *reinterpret_cast<u32x2*>(a.y16 + off) = pk;
-                            }
+                        for (int k = 0; k < 4; ++k) s_ep[(qi & 1) * 288 + (k + 4 * lh) * 36 + li] = ac[mt][nt][q * 4 + k];
+                    }
+                    if (qi > 0) {
+                        const int pq = qi - 1, nt = pq / (MT * 4), mt = (pq / 4) % MT, q = pq & 3;
+                        f32x4 v = rq + bias4[nt];
+                        const int p0 = (wm * MT + mt) * 32 + q * 8;              // first pixel of the row group (wave-uniform)
+                        const unsigned off = tbase + (unsigned)(p0 / TW) * row_st + (unsigned)(p0 % TW) * col_st + lane_off[nt];
+                        bool ok = true;
+                        if constexpr (!FULL) {
+                            const int co = n0 + (wn * NTL + nt) * 32 + g4;
+                            const int oy = ct.oy0 + (p0 + pl) / TW, ox = ct.ox0 + (p0 + pl) % TW;
+                            ok = co < a.Cout && oy < a.H && ox < a.W;
                         }
-                        if constexpr (OM != 2) *reinterpret_cast<f32x4*>(a.y + off) = v;
-                        if (st_out) {
-                            if (BWD && bwd) {
+                        if (FULL || ok) {
+                            if constexpr (OM >= 1) {            // the tensor holds bf16 values (RNE; NaN stays NaN): v_cvt_pk_bf16_f32
+                                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                                const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+                                const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+                                v = f32x4{__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                                          __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+                                if constexpr (OM == 2) *reinterpret_cast<u32x2*>(a.y16 + off) = u32x2{w0, w1};
+                            }
+                            if constexpr (OM != 2) *reinterpret_cast<f32x4*>(a.y + off) = v;
+                            if constexpr (BWD) {
                                 const u32x2 t = ypre[BWD ? mt : 0][BWD ? nt : 0][q >> 1][q & 1];
                                 const f32x4 yv = {__builtin_bit_cast(float, t[0] << 16), __builtin_bit_cast(float, t[0] & 0xffff0000u),
                                                   __builtin_bit_cast(float, t[1] << 16), __builtin_bit_cast(float, t[1] & 0xffff0000u)};
@@ -361,7 +364,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                         }
                     }
                 }
-            }
+            };
+            if (full) quarters(std::true_type{});
+            else quarters(std::false_type{});
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
