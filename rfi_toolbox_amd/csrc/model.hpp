@@ -36,6 +36,8 @@ struct ConvBN {
     bool has_bias = true;               // false: Conv2d(bias=False) in front of a BatchNorm (the bias slot stays 0, no state_dict entry)
     float* ws2d = nullptr;              // stride 2: filters of the 2x2 form on the space-to-depth input [4][cout][4 cin]
     float* wds2d = nullptr;             // ... and their dgrad layout [4'][4 cin][cout]
+    float* ws2d3 = nullptr;             // ... and the 3 x bf16 records of both (a launch without them splits a temporary copy
+    float* wds2d3 = nullptr;            // and drains the stream to free it: six stalls per step)
     bool has_bn = true;                 // false: Conv+bias -> ReLU (SimpleCNN); scale=1, shift=0 stay fixed
     int64_t nbt = 0;                    // num_batches_tracked (host side)
     // device per-channel state: [running_mean | running_var | mean | invstd | scale | shift | c1 | c2]

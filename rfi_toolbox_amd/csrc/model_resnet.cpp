@@ -161,7 +161,9 @@ void rfi_model::build_resnet() {
     }
     // derived filters of the stride-2 convs (2x2 form + its dgrad layout) and identity scale / shift vectors
     size_t wneed = 0;
-    for (auto& c : convs) if (c.stride == 2 && c.R == 3) wneed += 2 * align4((size_t)16 * c.cin * c.cout);
+    for (auto& c : convs)
+        if (c.stride == 2 && c.R == 3)
+            wneed += 2 * align4((size_t)16 * c.cin * c.cout) + align4(weights_x3_floats(4, c.cout, 4 * c.cin)) + align4(weights_x3_floats(4, 4 * c.cin, c.cout));
     const size_t cmax = (size_t)feat << D;
     rs_wpool = static_cast<float*>(ctx->alloc((wneed + 2 * cmax + 16) * sizeof(float)));
     size_t o = 0;
@@ -169,6 +171,8 @@ void rfi_model::build_resnet() {
         if (c.stride == 2 && c.R == 3) {
             c.ws2d = rs_wpool + o; o += align4((size_t)16 * c.cin * c.cout);
             c.wds2d = rs_wpool + o; o += align4((size_t)16 * c.cin * c.cout);
+            c.ws2d3 = rs_wpool + o; o += align4(weights_x3_floats(4, c.cout, 4 * c.cin));
+            c.wds2d3 = rs_wpool + o; o += align4(weights_x3_floats(4, 4 * c.cin, c.cout));
         }
     rs_ones = rs_wpool + o; o += cmax;
     rs_zeros = rs_wpool + o;
@@ -220,6 +224,10 @@ void rfi_model::refresh_resnet_weights() {
         if (c.stride != 2 || c.R != 3) continue;
         launch_w_s2d(ctx, params + c.w_off, c.cout, c.cin, c.ws2d, true);
         launch_weight_to_dgrad(ctx, c.ws2d, 4, c.cout, 4 * c.cin, 1, c.wds2d);
+        if (use_w3()) {
+            launch_weights_to_x3(ctx, c.ws2d, 4, c.cout, 4 * c.cin, c.ws2d3);
+            launch_weights_to_x3(ctx, c.wds2d, 4, 4 * c.cin, c.cout, c.wds2d3);
+        }
     }
 }
 
@@ -334,7 +342,7 @@ View rfi_model::forward_resnet_encoder(View x, int n, int h, int w, bool train) 
         const double f1 = 2.0 * M * 9.0 * b.cin * b.cout, f2 = 2.0 * M * 9.0 * b.cout * b.cout;
         if (b.stride == 2) {
             launch_s2d(ctx, a_in, n, s.H * 2, s.W * 2, b.cin, buf(b.xs));
-            conv_bn(this, c1, View{buf(b.xs), 4 * b.cin}, InXform{}, s, c1.ws2d, nullptr, 2, 1, 4 * b.cin, buf(b.Y1), train, f1);
+            conv_bn(this, c1, View{buf(b.xs), 4 * b.cin}, InXform{}, s, c1.ws2d, c1.ws2d3, 2, 1, 4 * b.cin, buf(b.Y1), train, f1);
             ConvBN& cd = convs[b.cd];             // projection: 1x1 on the (0, 0) slice of the space-to-depth input
             conv_bn(this, cd, View{buf(b.xs), 4 * b.cin}, InXform{}, s, params + cd.w_off, cd.w3, 1, 0, b.cin, buf(b.Yd), train,
                     2.0 * M * b.cin * b.cout);
@@ -407,7 +415,7 @@ void rfi_model::backward_resnet_encoder(const float* x_dev, int n, int h, int w)
                 launch_w_s2d(ctx, grads + c1.w_off, b.cout, b.cin, buf(rs_dW), false);
                 side.end();
             }
-            dgrad(this, dA1, b.cout, c1.wds2d, nullptr, 4 * b.cin, s, 2, 0, dX, f1);               // [M][4 cin]
+            dgrad(this, dA1, b.cout, c1.wds2d, c1.wds2d3, 4 * b.cin, s, 2, 0, dX, f1);             // [M][4 cin]
             // ---- projection branch: BNd on the same dz (recomputed: the first copy now holds dY2), 1x1 conv
             ConvBN& cd = convs[b.cd];
             dz = buf(rs_dzd);
