@@ -482,6 +482,19 @@ int rfi_op_roi_align_ml(rfi_ctx* ctx, const float* const* maps_host, int n, int 
 int rfi_op_roi_align_ml_backward(rfi_ctx* ctx, float* const* dmaps_host, int n, int h0, int w0, int c, float scale0, const float* dout,
                                  const float* rois, const int32_t* level, const int32_t* img_start, int max_rois, int ph, int pw,
                                  int sampling_ratio);
+/* ---- elementwise kernels of the bfloat16 data flow (ResNet-style encoder, BatchNorm backward), for the kernel-level parity
+ *      tests.  bfloat16 tensors are dense [m][c] arrays of uint16 bit patterns, c % 8 == 0, 16-byte aligned.  No counterpart
+ *      in the reference (its tensors are float32): these are the builder's reduced-precision storage forms of
+ *      relu(BN(y) + shortcut) (torchvision-style BasicBlock tail), of the masked sum of gradient terms at a block output,
+ *      and of nn.BatchNorm2d's training-mode backward in front of a (Leaky)ReLU with slope `slope` (1: no activation).
+ *      bn_backward16: dgamma / dbeta / dbias (dbias may be null) are float32 [c]; dy is bfloat16. ---- */
+int rfi_op_bn_add_relu16(rfi_ctx* ctx, const uint16_t* y, const float* scale, const float* shift, const uint16_t* s, const float* s_scale,
+                         const float* s_shift, int64_t m, int c, uint16_t* out);
+int rfi_op_relu_mask_sum16(rfi_ctx* ctx, const uint16_t* g0, const uint16_t* g1, const float* g2_f32, const uint16_t* g2_bf16,
+                           int64_t g2_stride, const uint16_t* a, int64_t m, int c, uint16_t* dz);
+int rfi_op_bn_backward16(rfi_ctx* ctx, const uint16_t* da, const uint16_t* y, int64_t m, int c, const float* gamma, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float slope, uint16_t* dy, float* dgamma,
+                         float* dbeta, float* dbias);
 int rfi_readback_begin(rfi_ctx* ctx, const void* src_dev, size_t bytes);
 int rfi_readback_end(rfi_ctx* ctx, void* dst_host, size_t bytes);
 int rfi_op_fpn_merge(rfi_ctx* ctx, const float* lateral, const float* top, int n, int h, int w, int c, float* out);

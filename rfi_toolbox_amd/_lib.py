@@ -134,6 +134,9 @@ _PROTOS = {
                                 _vp, _vp, _vp, _vp, _vp]),
     "rfi_op_roi_align_ml": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rfi_op_roi_align_ml_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "rfi_op_bn_add_relu16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "rfi_op_relu_mask_sum16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp]),
+    "rfi_op_bn_backward16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "rfi_readback_begin": (_i, [_vp, _vp, _sz]),
     "rfi_readback_end": (_i, [_vp, _vp, _sz]),
     "rfi_op_rpn_loss": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _f, _vp, _pf, _pf]),

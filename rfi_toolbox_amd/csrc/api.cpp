@@ -2133,6 +2133,36 @@ int rfi_op_roi_compact(rfi_ctx* ctx, const int32_t* sel, const int32_t* nsel, co
                            cls, tgt, gt, level, img_start, rois_fg, rois_gt, level_fg, fg_start, counts);
     });
 }
+int rfi_op_bn_add_relu16(rfi_ctx* ctx, const uint16_t* y, const float* scale, const float* shift, const uint16_t* s, const float* s_scale,
+                         const float* s_shift, int64_t m, int c, uint16_t* out) {
+    return guarded([&] {
+        ctx->activate();
+        launch_bn_add_relu16(ctx, y, c, scale, shift, s, c, s_scale, s_shift, m, c, out, c);
+    });
+}
+int rfi_op_relu_mask_sum16(rfi_ctx* ctx, const uint16_t* g0, const uint16_t* g1, const float* g2_f32, const uint16_t* g2_bf16,
+                           int64_t g2_stride, const uint16_t* a, int64_t m, int c, uint16_t* dz) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(!(g2_f32 && g2_bf16), "relu_mask_sum16: one third term at most");
+        const YRef g2 = g2_bf16 ? YRef(g2_bf16, g2_stride) : YRef(g2_f32, g2_f32 ? g2_stride : (int64_t)0);
+        launch_relu_mask_sum16(ctx, g0, c, g1, c, g2, a, c, m, c, dz, c);
+    });
+}
+int rfi_op_bn_backward16(rfi_ctx* ctx, const uint16_t* da, const uint16_t* y, int64_t m, int c, const float* gamma, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float slope, uint16_t* dy, float* dgamma,
+                         float* dbeta, float* dbias) {
+    return guarded([&] {
+        ctx->activate();
+        RFI_REQUIRE(m > 0 && c > 0 && c % 16 == 0, "bn_backward16: channels in whole 16-channel chunks");
+        Scratch s(ctx);
+        float* ws = s.get(std::max(bn_bwd_ws_floats(m, c), channel_sum_ws_floats(m, c)) + 16);
+        float* c12 = s.get((size_t)2 * c);
+        launch_bn_bwd_reduce(ctx, YRef(da, (int64_t)c), YRef(y, (int64_t)c), m, c, scale, shift, mean, invstd, ws, c12, c12 + c, dgamma, dbeta, slope);
+        launch_bn_bwd_apply(ctx, YRef(da, (int64_t)c), YRef(y, (int64_t)c), m, c, scale, shift, mean, invstd, gamma, c12, c12 + c, ws, dbias, slope, dy,
+                            (int64_t)c, 1);
+    });
+}
 int rfi_op_roi_align_ml(rfi_ctx* ctx, const float* const* maps_host, int n, int h0, int w0, int c, float scale0, const float* rois,
                         const int32_t* level, const int32_t* count_dev, int max_rois, int ph, int pw, int sampling_ratio, float* out) {
     return guarded([&] {

@@ -138,3 +138,100 @@ def test_conv3x3_double_tile_kernels_bf16(shape):
         gx = c.empty((n, h, w, cin))
         check(lib.rfi_op_conv3x3_dgrad(c.handle, impl, P(ddy), n, h, w, cout, P(dw), cin, P(gx)))
         assert rel_err(gx.numpy(), nhwc(xin.grad.float())) <= TOL, impl
+
+
+# ------------------------------------------------------------------ elementwise kernels of the bfloat16 data flow
+def _bits(t):          # float32 tensor holding bf16 values -> uint16 bit patterns (numpy)
+    import numpy as np
+    return t.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def _from_bits(a):
+    import numpy as np
+    return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("m,c", [(4096, 64), (1000, 16), (333, 128), (64 * 64 * 3, 32)])
+@pytest.mark.parametrize("projection", [False, True])
+def test_block_tail_bf16(m, c, projection):
+    """relu(BN(y) + shortcut) on bfloat16 tensors: float32 arithmetic (product and sum rounded separately), ONE rounding of
+    the result to bfloat16 -- bit-exact against the same expression in torch."""
+    import numpy as np
+    g = torch.Generator().manual_seed(m + c)
+    y, s = bf(torch.randn(m, c, generator=g)), bf(torch.randn(m, c, generator=g))
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    ssc, ssh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    short = (s * ssc + ssh) if projection else s
+    want = torch.relu((y * sc + sh) + short).to(torch.bfloat16).to(torch.float32)
+    cx = ctx()
+    dy, ds = cx.to_device(_bits(y)), cx.to_device(_bits(s))
+    dsc, dsh, dssc, dssh = (cx.to_device(t.numpy()) for t in (sc, sh, ssc, ssh))
+    out = cx.empty((m, c), np.uint16)
+    check(lib.rfi_op_bn_add_relu16(cx.handle, P(dy), P(dsc), P(dsh), P(ds), P(dssc) if projection else None, P(dssh) if projection else None,
+                                   m, c, P(out)))
+    assert torch.equal(_from_bits(out.numpy()), want)
+
+
+@pytest.mark.parametrize("m,c", [(4096, 64), (777, 16), (64 * 64, 256)])
+@pytest.mark.parametrize("terms", ["g0", "g0+g1", "g0+f32", "g0+g1+bf16", "nomask"])
+def test_masked_gradient_sum_bf16(m, c, terms):
+    """dz = (g0 + g1 + g2) * [a > 0]: the gradient terms that meet at a BasicBlock output (the next block's input gradient, the
+    identity shortcut's, the decoder's skip gradient as a channel slice of a float32 or bfloat16 [up | skip] tensor), summed in
+    float32 in that order and rounded once -- bit-exact against torch."""
+    import numpy as np
+    g = torch.Generator().manual_seed(m * 3 + c)
+    g0, g1, a = (bf(torch.randn(m, c, generator=g)) for _ in range(3))
+    cat = torch.randn(m, 2 * c, generator=g)
+    cat16 = bf(cat)
+    tot = g0.clone()
+    if "g1" in terms:
+        tot = tot + g1
+    if "f32" in terms:
+        tot = tot + cat[:, c:]
+    if "bf16" in terms:
+        tot = tot + cat16[:, c:]
+    want = (tot if terms == "nomask" else torch.where(a > 0, tot, torch.zeros_like(tot))).to(torch.bfloat16).to(torch.float32)
+    cx = ctx()
+    d0, d1, da = cx.to_device(_bits(g0)), cx.to_device(_bits(g1)), cx.to_device(_bits(a))
+    dcat, dcat16 = cx.to_device(cat.numpy()), cx.to_device(_bits(cat16))
+    out = cx.empty((m, c), np.uint16)
+    import ctypes as C
+    f32p = C.c_void_p(dcat.ptr + 4 * c) if "f32" in terms else None
+    b16p = C.c_void_p(dcat16.ptr + 2 * c) if "bf16" in terms else None
+    check(lib.rfi_op_relu_mask_sum16(cx.handle, P(d0), P(d1) if "g1" in terms else None, f32p, b16p, 2 * c,
+                                     None if terms == "nomask" else P(da), m, c, P(out)))
+    assert torch.equal(_from_bits(out.numpy()), want)
+
+
+@pytest.mark.parametrize("m,c", [(64 * 64 * 4, 32), (128 * 128, 64), (3000, 16), (8 * 8 * 64, 512)])
+@pytest.mark.parametrize("slope", [0.0, 1.0, 0.1])
+def test_batchnorm_backward_bf16(m, c, slope):
+    """Training-mode BatchNorm backward in front of a (Leaky)ReLU on bfloat16 tensors (8 channels per lane, float32 partial sums
+    per 8 rows, fp64 across): dgamma / dbeta / the conv-bias gradient and dY against float64 torch on the same bf16 inputs."""
+    import numpy as np
+    g = torch.Generator().manual_seed(m + 7 * c)
+    y, da = bf(torch.randn(m, c, generator=g) * 1.5 + 0.2), bf(torch.randn(m, c, generator=g))
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    y64 = y.double()
+    mean, var = y64.mean(0), y64.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    scale = (gamma.double() * invstd).float()
+    shift = (beta.double() - mean * gamma.double() * invstd).float()
+    mean32, invstd32 = mean.float(), invstd.float()
+    z = y * scale + shift                                   # the forward's own float32 pre-activation decides the mask
+    dz = torch.where(z > 0, da, da * slope).double()
+    xh = ((y - mean32) * invstd32).double()
+    dbeta, dgamma = dz.sum(0), (dz * xh).sum(0)
+    dyw = (gamma * invstd32).double() * (dz - dbeta / m - xh * (dgamma / m))
+    cx = ctx()
+    dda, dyy = cx.to_device(_bits(da)), cx.to_device(_bits(y))
+    dev = {k: cx.to_device(v.numpy()) for k, v in dict(gamma=gamma, scale=scale, shift=shift, mean=mean32, invstd=invstd32).items()}
+    out = cx.empty((m, c), np.uint16)
+    og, ob, obias = cx.empty((c,)), cx.empty((c,)), cx.empty((c,))
+    check(lib.rfi_op_bn_backward16(cx.handle, P(dda), P(dyy), m, c, P(dev["gamma"]), P(dev["scale"]), P(dev["shift"]), P(dev["mean"]),
+                                   P(dev["invstd"]), slope, P(out), P(og), P(ob), P(obias)))
+    got = _from_bits(out.numpy()).double()
+    assert float((got - dyw).abs().max()) <= 2.0 ** -8 * float(dyw.abs().max()) + 1e-6
+    assert rel_err(og.numpy(), dgamma.float().numpy()) <= 2e-5 and rel_err(ob.numpy(), dbeta.float().numpy()) <= 2e-5
+    # the conv bias in front of the BatchNorm: sum of the (rounded) dY, ~0 by construction
+    assert float(np.abs(obias.numpy() - got.sum(0).float().numpy()).max()) <= 1e-3 * float(got.abs().sum(0).max()) + 1e-6
