@@ -228,3 +228,25 @@ def test_benched_combination_width64_bf16_1024():
     assert loss2 == loss
     for k in names:
         assert np.array_equal(m.grad(k), g1[k]), k
+
+
+def test_switching_data_flows_on_one_model():
+    """float32 tensors -> the bfloat16 data flow (its own tensors, filter images and class tables) -> back, at two shapes: the
+    float32 results return bit for bit, and the bfloat16 flow's are the same before and after the round trip."""
+    f = 16
+    st = _perturbed_state(f, 51)
+    m = UNetResNet18(3, 1, f).load_state_dict(st).train()
+    out = {}
+    for n, s in ((2, 64), (1, 128)):
+        x, y, _, _ = _inputs(n, s, 52 + s)
+        for mode in ("float32", "bfloat16", "float32", "bfloat16"):
+            m.set_compute_dtype(mode)
+            loss = m.forward_backward(x, y)
+            g = {k: m.grad(k).copy() for k in ("stem.0.weight", "layer2.0.conv1.weight", "layer3.0.downsample.0.weight", "decoder2.up.weight")}
+            key = (mode, s)
+            if key in out:
+                assert loss == out[key][0], key
+                for k in g:
+                    assert np.array_equal(g[k], out[key][1][k]), (key, k)
+            out[key] = (loss, g)
+        assert out[("float32", s)][0] != out[("bfloat16", s)][0]
