@@ -37,3 +37,14 @@ def test_other_models_are_bitwise_reproducible(model, features, size):
     the U-Net code path: the same bit-identical-gradients property."""
     from race_probe import probe
     assert not probe("float32", 100, features=features, batch=4, size=size, model=model)
+
+
+@pytest.mark.parametrize("kw", [dict(features=32, batch=8, size=64, emulate=2), dict(features=32, batch=2, size=64, emulate=2, model="resnet"),
+                                dict(features=64, batch=1, size=256, model="resnet")])
+def test_bf16_flow_with_transposed_convs_on_planes_is_bitwise_reproducible(kw):
+    """Widths in whole 32-channel blocks: the transposed convs run on the plane kernels too (tap-group contraction, strided
+    weight gradient on the side stream, BatchNorm-backward sums in the 2x2 stride-2 input gradient's epilogue), for the plain
+    U-Net and for the ResNet-encoder model's bfloat16 flow (parity-class input gradients, owned dY planes), alone and with
+    the bucketed gradient exchange emulated."""
+    from race_probe import probe
+    assert not probe("bfloat16", 40, **kw)
