@@ -1456,13 +1456,18 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
     ChanGeom g = geom_rows(M, C);
     static const bool no16 = getenv("RFI_NO_BN16") != nullptr;
     const bool fast16 = !no16 && da_inout.bf16 && y.bf16 && planes_out && planes_P == 1 && !head_dl && C % 8 == 0 && da_inout.stride(C) == C &&
-                        y.stride(C) % 8 == 0 && planes_pstride % 8 == 0 && (finish_dbias || !dbias) &&
+                        y.stride(C) % 8 == 0 && planes_pstride % 8 == 0 &&
                         !((reinterpret_cast<uintptr_t>(da_inout.p) | reinterpret_cast<uintptr_t>(y.p) | reinterpret_cast<uintptr_t>(planes_out) |
                            reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(mean) |
                            reinterpret_cast<uintptr_t>(invstd) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(c1) |
                            reinterpret_cast<uintptr_t>(c2)) & 15);
     if (fast16) {
+        const ChanGeom g4 = g;
         g = chan_geom(M, C, kMaxRowBlocks, true, 8);
+        if (dbias) {          // the row blocks of the generic kernel: the records the batched finisher's table expects (bn_bwd_apply_records)
+            g.rows_per_block = g4.rows_per_block;     // -- and the same partial sums whether the finishing is deferred or not (a step with the
+            g.rblocks = g4.rblocks;                   // gradient exchange finishes at once: bit-identical bias gradients either way)
+        }
         {
             ProfScope ps(ctx, FAM_BN, 0, (double)M * C * 6);
             auto launch = [&](auto kernel) {
@@ -1475,7 +1480,7 @@ void launch_bn_bwd_apply(rfi_ctx* ctx, YRef da_inout, YRef y, int64_t M, int C,
             else launch(bn_bwd_apply16_kernel<false>);
             check_launch("bn_bwd_apply16");
         }
-        if (dbias) {
+        if (dbias && finish_dbias) {
             ProfScope ps(ctx, FAM_BN);
             hipLaunchKernelGGL(finish_channel_sum_kernel, dim3((int)cdiv(C, kFinCh)), dim3(kBlock), 0, ctx->stream,
                                reinterpret_cast<const double*>(partial_ws), g.rblocks, (int64_t)C, C, dbias);

@@ -272,7 +272,7 @@ void rfi_model::prepare(int n, int h, int w) {
                 "forward: H and W must be multiples of 2^depth (" + std::to_string(div) +
                     "), as the reference's pool/up-conv/cat chain requires; got " +
                     std::to_string(h) + "x" + std::to_string(w));
-    if (n == pN && h == pH && w == pW && !bufs.empty()) return;
+    if (n == pN && h == pH && w == pW && !bufs.empty()) return;     // (set_planes() clears pN: the table below depends on the flow)
     ctx->activate();
     const int D = depth;
     if (bufs.empty()) {
@@ -353,7 +353,8 @@ void rfi_model::prepare(int n, int h, int w) {
     }
     bufs[ws_slab].ensure(ctx, slab_need + 16);
     // per-layer regions for the partial sums of the conv-bias gradients + the table of the batched finisher
-    if (arch == 0 && !planesP) {
+    // (the plane flows too: the plain U-Net's and the ResNet-encoder model's, whose encoder convs have no bias)
+    if (arch == 0 || (arch == 2 && planesP)) {
         if (dbias_pool) { ctx->release(dbias_pool); dbias_pool = nullptr; }
         if (dbias_descs) { ctx->release(dbias_descs); dbias_descs = nullptr; }
         size_t need = 0;
@@ -378,6 +379,7 @@ void rfi_model::prepare(int n, int h, int w) {
             int H, W;
             conv_geom((int)ci, H, W);
             const ConvBN& c = convs[ci];
+            if (!c.has_bias) continue;
             hd.push_back(FinishSumDesc{reinterpret_cast<const double*>(dbias_pool + c.dbias_rec_off), bn_bwd_apply_records((int64_t)n * H * W, c.cout),
                                        (int64_t)c.cout, c.cout, grads + c.b_off});
             dbias_max_c = std::max(dbias_max_c, c.cout);

@@ -515,9 +515,12 @@ int backward_pconv_bn(rfi_model* m, ConvBN& c, YRef dA, YRef Y, const PlaneSeg* 
         launch_bn_bwd_reduce(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(), ws, c.c1(), c.c2(),
                              m->grads + c.g_off, m->grads + c.be_off, slope);
     const hipEvent_t dy_done = m->next_fork_event();         // completes with the kernel that writes dY
+    // (dbias_deferred: the partial sums of the conv-bias gradient stay in the layer's own region; the pass finishes every
+    // layer's with ONE batched launch at its end)
+    const bool defer = m->dbias_deferred && c.has_bias;
     launch_bn_bwd_apply(ctx, dA, Y, M, c.cout, c.scale(), c.shift(), c.mean(), c.invstd(),
-                        m->params + c.g_off, c.c1(), c.c2(), ws, c.has_bias ? m->grads + c.b_off : nullptr, slope, dYp.p, dYp.pstride,
-                        m->planesP, dy_done);
+                        m->params + c.g_off, c.c1(), c.c2(), defer ? m->dbias_pool + c.dbias_rec_off : ws,
+                        c.has_bias ? m->grads + c.b_off : nullptr, slope, dYp.p, dYp.pstride, m->planesP, dy_done, !defer);
     PWgradArgs wa;
     wa.xop[0] = in[0];
     if (nseg > 1) wa.xop[1] = in[1];
@@ -664,6 +667,8 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     // a gradient tensor an input-gradient conv writes: bfloat16 tensor pl[hi] in the bf16 flow, else float32 bufs[fi]
     auto gt = [&](int fi, int hi) { return hi >= 0 ? GT(pl[hi]) : GT(buf(fi)); };
     const int64_t M1 = (int64_t)n * h * w;
+    static const bool no_defer = getenv("RFI_NO_DEFER_DBIAS") != nullptr;
+    dbias_deferred = dbias_pool && !no_defer && !ctx->exchange_active();    // (bias gradients must be final before their bucket leaves)
     if (loss_kind == 1)
         launch_focal_bwd(ctx, buf(head_sigmoid ? probs : logits), labels_dev, M1, focal_alpha, focal_gamma, buf(dlogits));
     else
@@ -672,10 +677,11 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
     int head_records = 0;
     {
         ConvBN& last = convs[IB + 2 + 2 * (D - 1) + 1];
+        const bool hdefer = dbias_deferred && head_fin_deferred;
         head_records = launch_head_bwd(ctx, yr(decY2[1], y16_flow ? yD2top : -1), M1, feat, last.scale(), last.shift(), params + head_w_off, out_ch,
-                                       buf(dlogits), buf(gA[1]), buf(ws_red) + bn_bwd_ws_floats(M1, feat), grads + head_w_off,
-                                       grads + head_b_off, act_slope, last.mean(), last.invstd(), buf(ws_red),
-                                       g16_flow && out_ch == 1 ? pl[g16A[1]].p : nullptr);
+                                       buf(dlogits), buf(gA[1]), hdefer ? dbias_pool + head_rec_off : buf(ws_red) + bn_bwd_ws_floats(M1, feat),
+                                       grads + head_w_off, grads + head_b_off, act_slope, last.mean(), last.invstd(), buf(ws_red),
+                                       g16_flow && out_ch == 1 ? pl[g16A[1]].p : nullptr, nullptr, !hdefer);
     }
     int up_records = 0;                           // BatchNorm-backward records a transposed conv's input-gradient kernel left for the layer below
     for (int l = 1; l <= D; ++l) {                // decoders, shallow to deep
@@ -701,7 +707,9 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
             // ConvTranspose on the plane kernels: dUp = the first C channels of the bfloat16 [up | skip] gradient
             const PlaneBuf& cat = pl[g16cat[l]];
             const PlaneSeg dUp{cat.p, cat.pstride, plane_chunks(u.cout)};
-            launch_channel_sum(ctx, YRef(cat.p, cat.pstride), (int64_t)s.N * s.H * s.W, u.cout, buf(ws_red), grads + u.b_off);
+            const bool udefer = dbias_deferred && u.cout % 4 == 0;
+            launch_channel_sum(ctx, YRef(cat.p, cat.pstride), (int64_t)s.N * s.H * s.W, u.cout, udefer ? dbias_pool + u.dbias_rec_off : buf(ws_red),
+                               grads + u.b_off, !udefer);
             PWgradArgs wa;                        // dW[tap][cout][cin] = sum_pixels act(prev)[i, j, cin] * dUp[2 i + a, 2 j + b, cout]
             wa.xop[0] = dUp; wa.nseg = 1; wa.seg_c[0] = u.cout;
             wa.yop = seg_of(pl[pUpIn[l]]); wa.Cy = u.cin; wa.P = 1;
@@ -745,7 +753,11 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
         // ConvTranspose: dUp = dconcat[..., 0:C]; the round-1 kernels on float32 tensors
         const float* prevY = (l == D) ? buf(bottY2) : buf(decY2[l + 1]);
         View dUp{buf(dconcat[l]), 2 * u.cout};
-        launch_channel_sum(ctx, dUp, (int64_t)s.N * s.H * s.W, u.cout, buf(ws_red), grads + u.b_off);
+        {
+            const bool udefer = dbias_deferred && u.cout % 4 == 0;
+            launch_channel_sum(ctx, dUp, (int64_t)s.N * s.H * s.W, u.cout, udefer ? dbias_pool + u.dbias_rec_off : buf(ws_red), grads + u.b_off,
+                               !udefer);
+        }
         WgradArgs wa;
         wa.xop = dUp;
         wa.yop = View{prevY, u.cin};
@@ -812,6 +824,8 @@ void rfi_model::backward_planes(const float* x_dev, const uint8_t* labels_dev, i
                           pl[pdYbE[l]], rec1);
         bucket_ready(c1.w_off, convs[2 * l].w_off);
     }
+    if (dbias_deferred)
+        launch_finish_channel_sums_batched(ctx, static_cast<const FinishSumDesc*>(dbias_descs), dbias_n, dbias_max_c);
     side_join();
     side_bound = 2;
 }
