@@ -430,7 +430,8 @@ void rfi_model::side_rebuild_wd() {
     struct Back { rfi_ctx* c; ~Back() { c->stream = c->main_stream; } } back{ctx};
     launch_weight_to_dgrad_batched(ctx, static_cast<const RelayoutDesc*>(relayout_descs), relayout_n, params,
                                    wd_pool, relayout_bytes, relayout_tiles);
-    refresh_ws_weights(ws_need(), 2);
+    if (planesP) refresh_plane_weights(2);
+    else refresh_ws_weights(ws_need(), 2);
     RFI_CHECK_HIP(hipEventRecord(wd_ready, ctx->side_stream));
     wd_pending = true;
 }
@@ -459,8 +460,12 @@ void rfi_model::refresh_dgrad_weights() {
     // the dgrad layout and its B-operand images are rebuilt on the SIDE stream (idle during the forward pass) under the first
     // convs; backward() waits for them (wait_wd).  RFI_NO_WD_SIDE=1: everything on the main stream, as before
     static const bool no_wd_side = getenv("RFI_NO_WD_SIDE") != nullptr;
-    const bool split = !no_wd_side && ctx->overlap && !ctx->profiling && arch == 0 && !planesP && ws_need() != 0 && ws_pool && ws_P == ws_need() &&
-                       ws_n_fwd > 0 && (!use_w3() || (x3_descs && !x3_reads_wd && x3_for_ws_P == ws_P)) && ctx->stream == ctx->main_stream;
+    // (the plane flows: the forward pass reads the forward-direction images only, nothing but the input-gradient kernels reads
+    // the dgrad layouts -- unless pre-split records of them are in use)
+    const bool split_planes = planesP && wb_pool && wb_n_fwd > 0 && !use_w3() && training;
+    const bool split = !no_wd_side && ctx->overlap && !ctx->profiling && ctx->stream == ctx->main_stream &&
+                       (split_planes || (arch == 0 && !planesP && ws_need() != 0 && ws_pool && ws_P == ws_need() && ws_n_fwd > 0 &&
+                                         (!use_w3() || (x3_descs && !x3_reads_wd && x3_for_ws_P == ws_P))));
     if (split) {
         wd_side_todo = true;                      // (forward() starts it behind the first conv: side_rebuild_wd)
     } else {
@@ -527,7 +532,7 @@ void rfi_model::refresh_dgrad_weights() {
         x3_fresh = true;
     }
     if (arch == 2 && !planesP) refresh_resnet_weights();   // 2x2 forms of the stride-2 filters
-    if (planesP) refresh_plane_weights();                  // B-operand-order filters of the plane kernels
+    if (planesP) refresh_plane_weights(split ? 1 : 0);     // B-operand-order filters of the plane kernels
     wd_dirty = false;
 }
 

@@ -315,7 +315,9 @@ struct rfi_model {
     double wb_bytes = 0;
     void set_planes(int P);           // switches the data flow; frees plane tensors of another P
     void prepare_planes(int n, int h, int w);
-    void refresh_plane_weights();
+    int wb_n_fwd = 0;                 // descriptors of the forward-direction filter images (the table's first entries)
+    double wb_bytes_fwd = 0;
+    void refresh_plane_weights(int which = 0);       // 0 everything; 1 forward-direction images; 2 input-gradient direction (+ class tables)
     void forward_planes(const float* x_dev, int n, int h, int w, bool train_mode);
     void backward_planes(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w);
 

@@ -180,12 +180,14 @@ void rfi_model::prepare_planes(int n, int h, int w) {
 
 // filters of every 3x3 layer in MFMA B-operand order, both directions, rebuilt with the dgrad layouts after each
 // optimiser step by ONE batched launch
-void rfi_model::refresh_plane_weights() {
+void rfi_model::refresh_plane_weights(int which) {
     const int P = planesP, IB = i_bott;
     auto two_seg = [&](size_t ci) { return (int)ci >= IB + 2 && (((int)ci - (IB + 2)) & 1) == 0; };      // decoder conv1: [up | skip]
     auto has_wBd = [&](const ConvBN& c) { return c.R == 3 && c.stride == 1; };      // (the other shapes' input gradients: class tables)
     if (arch == 2 && rpb.empty()) rpb.assign(blocks.size(), ResPlanes());
     if (!wb_pool) {
+        // the table: every forward-direction image first (what the forward pass reads), then the input-gradient direction
+        // (dgrad layouts, parity-class tables) -- the second half can be rebuilt on the side stream under the forward pass
         size_t need = 0, cls_need = 0;
         for (size_t ci = 0; ci < convs.size(); ++ci) {
             const ConvBN& c = convs[ci];
@@ -205,7 +207,7 @@ void rfi_model::refresh_plane_weights() {
         if (cls_need && !rs_cls_pool) rs_cls_pool = static_cast<float*>(ctx->alloc(cls_need * sizeof(float)));
         std::vector<WBDesc> hd;
         size_t o = 0, co = 0;
-        wb_bytes = 0;
+        wb_bytes = wb_bytes_fwd = 0;
         for (size_t ci = 0; ci < convs.size(); ++ci) {
             ConvBN& c = convs[ci];
             const bool two = two_seg(ci);
@@ -214,7 +216,20 @@ void rfi_model::refresh_plane_weights() {
             const size_t ef = wb_elems(taps, c.cout, two ? c.cin / 2 : c.cin_p, two ? c.cin / 2 : 0, P);
             o += ef + 32;
             hd.push_back(WBDesc{params + c.w_off, c.wBf, taps, c.cout, c.cin_p, {two ? c.cin / 2 : c.cin_p, two ? c.cin / 2 : 0}, P});
-            wb_bytes += 2.0 * ef + 4.0 * taps * c.cin_p * c.cout;
+            wb_bytes_fwd += 2.0 * ef + 4.0 * taps * c.cin_p * c.cout;
+        }
+        if (P == 1)
+            for (auto& u : ups) {                 // forward layout [4][cout][cin] = one 1x1 contraction with 4 cout channels
+                u.wBf = wb_pool + o;
+                const size_t ef = wb_elems(1, 4 * u.cout, u.cin, 0, 1);
+                o += ef + 32;
+                hd.push_back(WBDesc{params + u.w_off, u.wBf, 1, 4 * u.cout, u.cin, {u.cin, 0}, 1});
+                wb_bytes_fwd += 2.0 * ef + 16.0 * u.cin * u.cout;
+            }
+        wb_n_fwd = (int)hd.size();
+        wb_bytes = wb_bytes_fwd;
+        for (size_t ci = 0; ci < convs.size(); ++ci) {
+            ConvBN& c = convs[ci];
             if (!has_wBd(c)) continue;
             c.wBd = wb_pool + o;
             const size_t ed = wb_elems(9, c.cin_p, c.cout, 0, P);
@@ -222,6 +237,14 @@ void rfi_model::refresh_plane_weights() {
             hd.push_back(WBDesc{c.wd, c.wBd, 9, c.cin_p, c.cout, {c.cout, 0}, P});
             wb_bytes += 2.0 * ed + 4.0 * 9 * c.cin_p * c.cout;
         }
+        if (P == 1)
+            for (auto& u : ups) {                 // dgrad layout [4][cin][cout]
+                u.wBd = wb_pool + o;
+                const size_t ed = wb_elems(4, u.cin, u.cout, 0, 1);
+                o += ed + 32;
+                hd.push_back(WBDesc{u.wd, u.wBd, 4, u.cin, u.cout, {u.cout, 0}, 1});
+                wb_bytes += 2.0 * ed + 16.0 * u.cin * u.cout;
+            }
         for (size_t bi = 0; bi < blocks.size(); ++bi) {
             const ResBlock& b = blocks[bi];
             if (b.stride != 2) continue;
@@ -237,29 +260,21 @@ void rfi_model::refresh_plane_weights() {
                 wb_bytes += 2.0 * e + 16.0 * b.cin * b.cout * (c == 0 ? 2 : 1);
             }
         }
-        if (P == 1)
-            for (auto& u : ups) {                 // forward layout [4][cout][cin] = one 1x1 contraction with 4 cout channels; dgrad layout [4][cin][cout]
-                u.wBf = wb_pool + o;
-                const size_t ef = wb_elems(1, 4 * u.cout, u.cin, 0, 1);
-                o += ef + 32;
-                hd.push_back(WBDesc{params + u.w_off, u.wBf, 1, 4 * u.cout, u.cin, {u.cin, 0}, 1});
-                u.wBd = wb_pool + o;
-                const size_t ed = wb_elems(4, u.cin, u.cout, 0, 1);
-                o += ed + 32;
-                hd.push_back(WBDesc{u.wd, u.wBd, 4, u.cin, u.cout, {u.cout, 0}, 1});
-                wb_bytes += 2.0 * (ef + ed) + 32.0 * u.cin * u.cout;
-            }
         wb_n = (int)hd.size();
         wb_descs = ctx->alloc(hd.size() * sizeof(WBDesc));
         RFI_CHECK_HIP(hipMemcpyAsync(wb_descs, hd.data(), hd.size() * sizeof(WBDesc), hipMemcpyHostToDevice, ctx->stream));
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));     // hd goes out of scope
     }
-    for (size_t bi = 0; bi < blocks.size(); ++bi) {
-        const ResBlock& b = blocks[bi];
-        if (b.stride == 2)
-            launch_w_s2_classes(ctx, params + convs[b.c1].w_off, params + convs[b.cd].w_off, b.cout, b.cin, rpb[bi].cls);
+    const WBDesc* descs = static_cast<const WBDesc*>(wb_descs);
+    if (which != 2) launch_weights_to_wb(ctx, descs, wb_n_fwd, wb_bytes_fwd);
+    if (which != 1) {
+        for (size_t bi = 0; bi < blocks.size(); ++bi) {
+            const ResBlock& b = blocks[bi];
+            if (b.stride == 2)
+                launch_w_s2_classes(ctx, params + convs[b.c1].w_off, params + convs[b.cd].w_off, b.cout, b.cin, rpb[bi].cls);
+        }
+        if (wb_n > wb_n_fwd) launch_weights_to_wb(ctx, descs + wb_n_fwd, wb_n - wb_n_fwd, wb_bytes - wb_bytes_fwd);
     }
-    launch_weights_to_wb(ctx, static_cast<const WBDesc*>(wb_descs), wb_n, wb_bytes);
 }
 
 namespace {
@@ -336,6 +351,7 @@ void rfi_model::forward_resnet_planes(PlaneSeg& cur, int n, int h, int w, bool t
         run_pconv_bn(this, c, &cur, 1, Shape{n, h, w}, y, train);
         launch_act_split(ctx, View{nullptr, c.cout}, (int64_t)n * h * w, c.cout, bn_xf(c), 1, pl[rpA0].p, pl[rpA0].pstride, pl[rpStemY].p,
                          pl[rpStemY].pstride);
+        side_rebuild_wd();                        // (the input-gradient-direction filter images: side stream, under the forward pass)
     }
     const PlaneBuf* a_in = &pl[rpA0];
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
@@ -384,6 +400,7 @@ void rfi_model::forward_planes(const float* x_dev, int n, int h, int w, bool tra
         ConvBN& c2 = convs[2 * (l - 1) + 1];
         const YT y2 = yt(encY2[l], y16_flow ? yE2[l] : -1);
         double_conv(this, c1, c2, &cur, 1, s, yt(encY1[l], y16_flow ? yE1[l] : -1), pl[pA1e[l]], y2, train_mode);
+        if (l == 1) side_rebuild_wd();            // (the input-gradient-direction filter images: side stream, under the forward pass)
         launch_bn_relu_pool_planes(ctx, y2.f, s.N, s.H, s.W, c2.cout, c2.scale(), c2.shift(), act_slope, P,
                                    pl[pSkip[l]].p, pl[pSkip[l]].pstride, pl[pPool[l]].p, pl[pPool[l]].pstride,
                                    y2.h ? y2.h->p : nullptr, y2.h ? y2.h->pstride : 0);
