@@ -26,6 +26,22 @@ def family(name):
     return "elementwise" if "rfi::" in name else None
 
 
+def short(name):
+    """`void rfi::(anonymous namespace)::conv_ws_kernel<1, 8, 32, 2, 0, false, 3>(rfi::...)` -> `conv_ws_kernel<1, 8, 32, 2, 0, false, 3>`"""
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"rfi::\(anonymous namespace\)::|rfi::", "", name)
+    depth, out = 0, []
+    for ch in name:                      # cut the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out)
+
+
 def fold(d):
     f = (glob.glob(f"{d}/*counter_collection.csv") + glob.glob(f"{d}/*/*counter_collection.csv"))[0]
     tot, n = collections.defaultdict(float), collections.Counter()
@@ -34,6 +50,9 @@ def fold(d):
         if fam:
             tot[fam] += float(r["Counter_Value"])
             n[fam] += 1
+            k = "kernel:" + short(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"])
+            n[k] += 1
     return tot, n
 
 
@@ -44,11 +63,16 @@ def main():
     res = {"note": "bytes per launch; fetch = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction), "
                    "write = WRITE_SIZE x 1024; rocprofv3 --kernel-trace --pmc, separate passes",
            "families": {}}
+    res["kernels"] = {}
     for fam in ft:
         fetch = 2.0 * ft[fam] * 1024 / fn[fam]
         write = wt.get(fam, 0.0) * 1024 / max(wn.get(fam, 1), 1)
-        res["families"][fam] = {"launches_seen": fn[fam], "fetch_bytes_per_launch": round(fetch),
-                                "write_bytes_per_launch": round(write), "hbm_bytes_per_launch": round(fetch + write)}
+        rec = {"launches_seen": fn[fam], "fetch_bytes_per_launch": round(fetch),
+               "write_bytes_per_launch": round(write), "hbm_bytes_per_launch": round(fetch + write)}
+        if fam.startswith("kernel:"):
+            res["kernels"][fam[7:]] = rec
+        else:
+            res["families"][fam] = rec
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
 
