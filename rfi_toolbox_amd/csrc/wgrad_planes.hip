@@ -301,7 +301,11 @@ int tap_groups(const PWgradArgs& a, int nkx) {
     static const int force = getenv("RFI_PWGRAD_TG") ? atoi(getenv("RFI_PWGRAD_TG")) : 0;     // A/B runs: 1 or 3
     if (force == 1 || force == 3) return force;
     const int chunks = (int)cdiv(plane_chunks(a.Cy), 2 * BYB) * (int)cdiv(nkx, 2 * BXB);
-    return chunks >= 16 ? 3 : 1;
+    // ... and few pixels: with many (the 256 x 256 maps of a 1024 x 1024 sample) the slabs are a small share and staging every tile
+    // three times makes the kernel LDS-DMA bound (resnet1024: 560 TFLOP/s with tap groups, -2.5 % step time without them there; measured
+    // thresholds 8 k / 32 k / none: 12.72 / 12.83 / 13.04 ms per step there, 3.561 / 3.573 / 3.583 ms on the U-Net at 64 x 128 x 128)
+    static const int64_t max_px = getenv("RFI_PWGRAD_TG_PIXELS") ? atoll(getenv("RFI_PWGRAD_TG_PIXELS")) : 8192;
+    return chunks >= 16 && (int64_t)a.N * a.H * a.W <= max_px ? 3 : 1;
 }
 template <int R, int S, int BYB, int BXB, int TH, int TW>
 Plan plan_cfg(const PWgradArgs& a, int nkx) {
