@@ -20,8 +20,8 @@ for d, name in (("stats_serial", "kernel_stats"), ("stats_overlap", "kernel_stat
                 ("stats_serial_cnn3", "kernel_stats_cnn3"), ("stats_serial_unet1024", "kernel_stats_unet1024"),
                 ("stats_serial_resnet1024", "kernel_stats_resnet1024"), ("stats_serial_maskrcnn", "kernel_stats_maskrcnn")):
     hits = glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True)
-    if hits:
-        shutil.copy(hits[0], os.path.join(dst, f"{tag}_{name}.csv"))
+    if hits:                       # (gpurun merges every call's files into the same tree: the newest run's table)
+        shutil.copy(max(hits, key=os.path.getmtime), os.path.join(dst, f"{tag}_{name}.csv"))
 here = os.path.join(ROOT, "tools")
 for dt, suffix in (("f32", ""), ("bf16", "_bf16"), ("cnn3", "_cnn3"), ("unet1024", "_unet1024_bf16"), ("resnet1024", "_resnet1024_bf16"),
                    ("maskrcnn", "_maskrcnn")):
