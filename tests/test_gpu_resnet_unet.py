@@ -250,3 +250,31 @@ def test_switching_data_flows_on_one_model():
                     assert np.array_equal(g[k], out[key][1][k]), (key, k)
             out[key] = (loss, g)
         assert out[("float32", s)][0] != out[("bfloat16", s)][0]
+
+
+@pytest.mark.parametrize("f,n,h,w", [(16, 3, 96, 160), (32, 2, 48, 208)])
+def test_bf16_flow_on_non_square_ragged_shapes(f, n, h, w):
+    """Maps that are not multiples of the kernels' 8 x 32 / 16 x 16 / 8 x 8 tiles at some level (ragged tiles in the strided
+    plane contractions, the parity-class input gradients and the tap-group transposed conv; width 32: the transposed convs
+    on planes too): loss against the same-arithmetic oracle, gradients closer to it than float32 arithmetic is."""
+    st = _perturbed_state(f, 61)
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(n, h, w, 3, generator=g)
+    y = (torch.rand(n, h, w, generator=g) > 0.85).to(torch.uint8)
+    xo, yo = unet_ref.nhwc_to_nchw(x), y.float().unsqueeze(1)
+    _, _, g32, _ = rref.loss_and_grads(st, xo, yo)
+    with unet_ref.bf16_operands(round_outputs=True):
+        lb, _, gb, _ = rref.loss_and_grads(st, xo, yo)
+    m = UNetResNet18(3, 1, f).load_state_dict(st).train().set_compute_dtype("bfloat16")
+    assert m.forward_backward(x, y) == pytest.approx(float(lb), rel=3e-3)
+    ratios = []
+    for k, gg in gb.items():
+        if k.endswith((".0.bias", ".3.bias")) and "conv" in k or k == "final_conv.bias":
+            continue
+        gg = gg.numpy().ravel()
+        nrm = np.linalg.norm(gg) + 1e-30
+        rel_same = np.linalg.norm(m.grad(k).ravel() - gg) / nrm
+        rel_arith = np.linalg.norm(g32[k].numpy().ravel() - gg) / nrm
+        assert rel_same <= max(1.1 * rel_arith, 1e-2), (k, rel_same, rel_arith)
+        ratios.append(rel_same / max(rel_arith, 1e-9))
+    assert np.median(ratios) <= 0.8, np.median(ratios)
