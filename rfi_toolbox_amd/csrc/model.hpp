@@ -223,6 +223,7 @@ struct rfi_model {
     int stem_kp() const { return (49 * in_ch + 15) / 16 * 16; }      // K of the K-packed 7x7 stem
     int fL[4] = {-1, -1, -1, -1}, fM[4] = {-1, -1, -1, -1}, fP[4] = {-1, -1, -1, -1}, fdM[4] = {-1, -1, -1, -1}, fdP[4] = {-1, -1, -1, -1};
     int bG[6] = {-1, -1, -1, -1, -1, -1};
+    int bT[4][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};   // dY3 / dY2 / dY1 / dYd of a Bottleneck, by block index mod 3: what the side stream's weight gradients read
     bool frozen_dirty = true;         // frozen BatchNorm buffers changed: scale / shift must be recomputed
     void build_backbone();
     void prepare_backbone(int n, int h, int w);

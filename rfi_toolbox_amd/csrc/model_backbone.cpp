@@ -176,6 +176,7 @@ void rfi_model::prepare_backbone(int n, int h, int w) {
         for (int i = 0; i < 4; ++i) { fL[i] = new_buf(); fM[i] = new_buf(); fP[i] = new_buf(); fdM[i] = new_buf(); fdP[i] = new_buf(); }
         fP6 = new_buf(); fdP6 = new_buf();
         for (int i = 0; i < 6; ++i) bG[i] = new_buf();
+        for (int r = 0; r < 4; ++r) for (int p = 0; p < 3; ++p) bT[r][p] = new_buf();
         bdW = new_buf(); bS = new_buf(); bCol = new_buf(); bWp = new_buf();
         x_stage = new_buf(); x_stage2 = new_buf(); x_pad = new_buf(); out_stage = new_buf();
         ws_red = new_buf(); ws_slab = new_buf(); lab_stage = new_buf(); logits = new_buf(); dlogits = new_buf();
@@ -206,6 +207,7 @@ void rfi_model::prepare_backbone(int n, int h, int w) {
     bufs[fP6].ensure(ctx, px(6) * F);
     bufs[fdP6].ensure(ctx, px(6) * F);
     for (int i = 0; i < 6; ++i) bufs[bG[i]].ensure(ctx, gmax);
+    for (int r = 0; r < 4; ++r) for (int p = 0; p < 3; ++p) bufs[bT[r][p]].ensure(ctx, gmax);
     bufs[bS].ensure(ctx, gmax);
     bufs[bCol].ensure(ctx, px(1) * stem_kp());
     bufs[bWp].ensure(ctx, (size_t)feat * stem_kp() + 16);
@@ -290,6 +292,16 @@ void conv(rfi_model* m, View in, InXform xf, Sh s, int Hin, int Win, const float
     a.bf16x3 = m->compute_x3;
     launch_conv(m->ctx, a);
 }
+// RAII: launches between construction and end() go to the side stream (model.cpp, side_begin / side_end)
+struct SideScopeB {
+    rfi_model* m;
+    bool ended = false;
+    explicit SideScopeB(rfi_model* model) : m(model) { m->side_begin(); }
+    void end() { m->side_end(); ended = true; }
+    ~SideScopeB() { if (!ended) m->ctx->stream = m->ctx->main_stream; }
+};
+
+// (the caller decides the stream: backward_backbone puts the weight gradients on the side stream)
 void wgrad(rfi_model* m, View x, InXform xf_x, const float* dY, int cy, int cx, Sh s, int Hx, int Wx, int R, int S, int pad, float* dw) {
     const int64_t M = (int64_t)s.N * s.H * s.W;
     if (R == 1 && S == 1 && Hx == s.H && Wx == s.W && s.W < 32 && M % 32 == 0) {       // (as in conv())
@@ -383,6 +395,9 @@ void rfi_model::forward_backbone(const float* x_dev, int n, int h, int w) {
 // dP2..dP6 sit in fdP[0..3] / fdP6 (rfi_backbone_backward copies them there)
 void rfi_model::backward_backbone(const float* x_dev, int n, int h, int w) {
     refresh_dgrad_weights();
+    static const int bound_env = getenv("RFI_BB_SIDE_BOUND") ? atoi(getenv("RFI_BB_SIDE_BOUND")) : 2;     // (1..5: A/B runs; measured 31.8 / 32.2 / 32.9 ms per
+                                                                                                    // step of the detector at bound 2 / bound 5 / no side stream)
+    side_bound = std::min(5, std::max(1, bound_env));
     const int F = out_ch;
     int last[4], bi = -1;
     for (int s = 0; s < 4; ++s) { bi += kBlocksPerStage[s]; last[s] = bi; }
@@ -395,7 +410,7 @@ void rfi_model::backward_backbone(const float* x_dev, int n, int h, int w) {
         const int64_t M = (int64_t)s.N * s.H * s.W;
         ConvBN& cl = convs[fpn_layer[i]];
         launch_channel_sum(ctx, View{buf(fdP[i]), F}, M, F, ws, grads + cl.b_off);
-        wgrad(this, View{buf(fM[i]), F}, InXform{}, buf(fdP[i]), F, F, s, s.H, s.W, 3, 1, 1, grads + cl.w_off);
+        { SideScopeB side(this); wgrad(this, View{buf(fM[i]), F}, InXform{}, buf(fdP[i]), F, F, s, s.H, s.W, 3, 1, 1, grads + cl.w_off); side.end(); }
         conv(this, View{buf(fdP[i]), F}, InXform{}, s, s.H, s.W, cl.wd, cl.wd3, nullptr, F, F, 3, 1, 1, buf(fdM[i]));
         if (i > 0) {                                // + the share of M_{i-1} = L_{i-1} + up(M_i)
             launch_fpn_merge_bwd_top(ctx, buf(fdM[i - 1]), n, h >> (i + 1), w >> (i + 1), F, buf(bG[0]));
@@ -404,7 +419,7 @@ void rfi_model::backward_backbone(const float* x_dev, int n, int h, int w) {
         const BBlock& k = bb[last[i]];
         ConvBN& ci = convs[fpn_inner[i]];
         launch_channel_sum(ctx, View{buf(fdM[i]), F}, M, F, ws, grads + ci.b_off);
-        wgrad(this, View{buf(k.A), k.cout}, InXform{}, buf(fdM[i]), F, k.cout, s, s.H, s.W, 1, 1, 0, grads + ci.w_off);
+        { SideScopeB side(this); wgrad(this, View{buf(k.A), k.cout}, InXform{}, buf(fdM[i]), F, k.cout, s, s.H, s.W, 1, 1, 0, grads + ci.w_off); side.end(); }
         conv(this, View{buf(fdM[i]), F}, InXform{}, s, s.H, s.W, ci.wd, ci.wd3, nullptr, F, k.cout, 1, 1, 0, dC[i]);
     }
     // ---- body, last block first.  gout: gradient w.r.t. the block output A
@@ -420,43 +435,54 @@ void rfi_model::backward_backbone(const float* x_dev, int n, int h, int w) {
         const Sh si{n, h >> k.lvl_in, w >> k.lvl_in}, so{n, h >> k.lvl, w >> k.lvl};
         const int64_t Mo = (int64_t)so.N * so.H * so.W, Mi = (int64_t)si.N * si.H * si.W;
         const float* a_in = b == 0 ? buf(bP0) : buf(bb[b - 1].A);
-        float* t0 = dC[3];                          // scratch (dC[3] is consumed; dC[0..2] stay until their stage boundary)
+        // The weight gradients run on the side stream next to this chain (its masks, affine backward passes, space-to-depth
+        // forms and shortcut adds are memory-bound).  What they read -- dY3, dY2, dY1, dYd -- lives in buffers of its own by
+        // block index mod 3: block b - 3 rewrites them, and with a run-ahead bound of up to 5 side launches the main stream has
+        // waited for every weight gradient of block b by then (a block issues at least three: after block b - 2's last,
+        // launch i + 8 counted from block b's first, it has waited for launch i + 3 or later)
+        const int par = b % 3;
+        float* t3 = buf(bT[0][par]);                // dz -> dY3            [Mo][cout]
+        float* dA2 = buf(bT[1][par]);               // dA2 -> dY2           [Mo][width]
+        float* dA1 = buf(bT[2][par]);               // dA1 -> dY1           [Mi][width]
+        float* td = buf(bT[3][par]);                // dz -> dYd            [Mo][cout]
         // dz = gout * [A > 0] -> dY3 = dz * scale3
-        launch_relu_mask(ctx, View{gout, k.cout}, View{}, View{buf(k.A), k.cout}, View{}, Mo, k.cout, t0);
-        affine_bwd(this, c3, t0, buf(k.Y3), Mo, 1.0f);
-        wgrad(this, View{buf(k.Y2), k.width}, act_of(c2), t0, k.cout, k.width, so, so.H, so.W, 1, 1, 0, grads + c3.w_off);
-        float* dA2 = gother;                                              // (gother is free until the end of the block)
-        conv(this, View{t0, k.cout}, InXform{}, so, so.H, so.W, c3.wd, c3.wd3, nullptr, k.cout, k.width, 1, 1, 0, dA2);
+        launch_relu_mask(ctx, View{gout, k.cout}, View{}, View{buf(k.A), k.cout}, View{}, Mo, k.cout, t3);
+        affine_bwd(this, c3, t3, buf(k.Y3), Mo, 1.0f);
+        { SideScopeB side(this); wgrad(this, View{buf(k.Y2), k.width}, act_of(c2), t3, k.cout, k.width, so, so.H, so.W, 1, 1, 0, grads + c3.w_off); side.end(); }
+        conv(this, View{t3, k.cout}, InXform{}, so, so.H, so.W, c3.wd, c3.wd3, nullptr, k.cout, k.width, 1, 1, 0, dA2);
         affine_bwd(this, c2, dA2, buf(k.Y2), Mo, 0.0f);                   // -> dY2
-        float* dA1 = t0;                                                  // [Mi][width]
         if (k.stride == 2) {
-            wgrad(this, View{buf(k.xs1), 4 * k.width}, InXform{k.sc4, k.sh4, 1, 0.0f}, dA2, k.width, 4 * k.width, so, so.H, so.W, 2, 1, 1,
-                  buf(bdW));
-            launch_w_s2d(ctx, grads + c2.w_off, c2.cout, c2.cin, buf(bdW), false);
+            {
+                SideScopeB side(this);              // (the 2x2-form gradient goes back to the 3x3 layout behind its slab reduction)
+                wgrad(this, View{buf(k.xs1), 4 * k.width}, InXform{k.sc4, k.sh4, 1, 0.0f}, dA2, k.width, 4 * k.width, so, so.H, so.W, 2, 1, 1,
+                      buf(bdW));
+                launch_w_s2d(ctx, grads + c2.w_off, c2.cout, c2.cin, buf(bdW), false);
+                side.end();
+            }
             float* dXs = buf(bS);                   // scratch [Mo][4 width]
             conv(this, View{dA2, k.width}, InXform{}, so, so.H, so.W, c2.wds2d, nullptr, nullptr, k.width, 4 * k.width, 2, 1, 0, dXs);
             launch_d2s_add(ctx, dXs, nullptr, View{}, n, si.H, si.W, k.width, dA1);
         } else {
-            wgrad(this, View{buf(k.Y1), k.width}, act_of(c1), dA2, k.width, k.width, so, so.H, so.W, 3, 1, 1, grads + c2.w_off);
+            { SideScopeB side(this); wgrad(this, View{buf(k.Y1), k.width}, act_of(c1), dA2, k.width, k.width, so, so.H, so.W, 3, 1, 1, grads + c2.w_off); side.end(); }
             conv(this, View{dA2, k.width}, InXform{}, so, so.H, so.W, c2.wd, c2.wd3, nullptr, k.width, k.width, 3, 1, 1, dA1);
         }
         affine_bwd(this, c1, dA1, buf(k.Y1), Mi, 0.0f);                   // -> dY1
-        wgrad(this, View{a_in, k.cin}, InXform{}, dA1, k.width, k.cin, si, si.H, si.W, 1, 1, 0, grads + c1.w_off);
-        float* dX = gother;                                               // [Mi][cin]  (dA2 is dead)
+        { SideScopeB side(this); wgrad(this, View{a_in, k.cin}, InXform{}, dA1, k.width, k.cin, si, si.H, si.W, 1, 1, 0, grads + c1.w_off); side.end(); }
+        float* dX = gother;                                               // [Mi][cin]
         conv(this, View{dA1, k.width}, InXform{}, si, si.H, si.W, c1.wd, c1.wd3, nullptr, k.width, k.cin, 1, 1, 0, dX);
         if (k.cd >= 0) {
             ConvBN& cd = convs[k.cd];
-            launch_relu_mask(ctx, View{gout, k.cout}, View{}, View{buf(k.A), k.cout}, View{}, Mo, k.cout, t0);
-            affine_bwd(this, cd, t0, buf(k.Yd), Mo, 1.0f);                // -> dYd
+            launch_relu_mask(ctx, View{gout, k.cout}, View{}, View{buf(k.A), k.cout}, View{}, Mo, k.cout, td);
+            affine_bwd(this, cd, td, buf(k.Yd), Mo, 1.0f);                // -> dYd
             if (k.stride == 2) {
-                wgrad(this, View{buf(k.xsA), 4 * k.cin}, InXform{}, t0, k.cout, k.cin, so, so.H, so.W, 1, 1, 0, grads + cd.w_off);
+                { SideScopeB side(this); wgrad(this, View{buf(k.xsA), 4 * k.cin}, InXform{}, td, k.cout, k.cin, so, so.H, so.W, 1, 1, 0, grads + cd.w_off); side.end(); }
                 float* dS = buf(bS);
-                conv(this, View{t0, k.cout}, InXform{}, so, so.H, so.W, cd.wd, cd.wd3, nullptr, k.cout, k.cin, 1, 1, 0, dS);
+                conv(this, View{td, k.cout}, InXform{}, so, so.H, so.W, cd.wd, cd.wd3, nullptr, k.cout, k.cin, 1, 1, 0, dS);
                 launch_subsample2_bwd_add(ctx, dS, n, si.H, si.W, k.cin, dX);      // the projection saw x[:, ::2, ::2]
             } else {
-                wgrad(this, View{a_in, k.cin}, InXform{}, t0, k.cout, k.cin, so, so.H, so.W, 1, 1, 0, grads + cd.w_off);
+                { SideScopeB side(this); wgrad(this, View{a_in, k.cin}, InXform{}, td, k.cout, k.cin, so, so.H, so.W, 1, 1, 0, grads + cd.w_off); side.end(); }
                 float* dS = buf(bS);
-                conv(this, View{t0, k.cout}, InXform{}, so, so.H, so.W, cd.wd, cd.wd3, nullptr, k.cout, k.cin, 1, 1, 0, dS);
+                conv(this, View{td, k.cout}, InXform{}, so, so.H, so.W, cd.wd, cd.wd3, nullptr, k.cout, k.cin, 1, 1, 0, dS);
                 launch_add_inplace(ctx, dX, dS, Mi * k.cin);
             }
         } else {                                    // identity shortcut: + gout * [A > 0]
@@ -475,7 +501,12 @@ void rfi_model::backward_backbone(const float* x_dev, int n, int h, int w) {
         affine_bwd(this, c, dA0, buf(bY0), (int64_t)n * H2 * W2, 0.0f);
         (void)x_dev;                                  // (its K-packed copy from the forward pass is the operand)
         const int Kp = stem_kp();
-        wgrad(this, View{buf(bCol), Kp}, InXform{}, dA0, c.cout, Kp, Sh{n, H2, W2}, H2, W2, 1, 1, 0, buf(bWp));
-        launch_w_pack(ctx, grads + c.w_off, 49, c.cout, in_ch, Kp, buf(bWp), false);
+        {
+            SideScopeB side(this);
+            wgrad(this, View{buf(bCol), Kp}, InXform{}, dA0, c.cout, Kp, Sh{n, H2, W2}, H2, W2, 1, 1, 0, buf(bWp));
+            launch_w_pack(ctx, grads + c.w_off, 49, c.cout, in_ch, Kp, buf(bWp), false);
+            side.end();
+        }
     }
+    side_join();
 }
