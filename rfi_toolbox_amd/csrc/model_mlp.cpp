@@ -170,6 +170,7 @@ void rfi_model::forward_mlp(const float* x_dev, int n) {
 // dlogits are the caller's (rfi_model_backward_dlogits): this head has no loss of its own
 void rfi_model::backward_mlp(const float* x_dev, int n) {
     RFI_REQUIRE(ext_dlogits, "BoxHead: the loss lives outside the model (rfi_op_fastrcnn_loss + rfi_model_backward_dlogits)");
+    side_bound = 0;
     const int L = depth;
     const Lay s = layout_of(n);
     const int64_t M = n;
@@ -196,7 +197,12 @@ void rfi_model::backward_mlp(const float* x_dev, int n) {
         wa.slab_floats = bufs[ws_slab].n;
         wa.bf16 = compute_bf16;
         wa.bf16x3 = compute_x3;
-        launch_wgrad(ctx, wa);
+        {   // side stream: every layer owns its gradient tensor mkG[i], nothing the weight gradient reads is rewritten in this pass
+            struct Back { rfi_ctx* c; ~Back() { c->stream = c->main_stream; } } back{ctx};
+            side_begin();
+            launch_wgrad(ctx, wa);
+            side_end();
+        }
         ConvArgs a;
         a.x = View{dA, c.cout};
         a.N = s.N; a.H = s.H; a.W = s.W; a.Hin = s.H; a.Win = s.W;
@@ -211,4 +217,5 @@ void rfi_model::backward_mlp(const float* x_dev, int n) {
         a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
     }
+    side_join();
 }
