@@ -23,6 +23,8 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 
 from .._lib import DEVICE, HOST, check, lib
@@ -79,6 +81,8 @@ def _paste(prob, box, h, w):
     out[iy1:iy2, ix1:ix2] = v > 0.5
     return out
 
+
+_RPN_ALL_LATE = os.environ.get("RFI_RPN_ALL_LATE") is not None     # A/B runs: every level's RPN training pass behind the proposals
 
 class MaskRCNN:
     def __init__(self, num_classes=2, in_channels=3, base_width=64, fpn_channels=256, representation_size=1024, *, device=None,
@@ -325,9 +329,26 @@ class MaskRCNN:
                                           5, b.aoff.ctypes.data_as(C.c_void_p), b.p_lab, b.p_tgt, P(b.n_sampled)))
         # ---- backbone, RPN head on every level
         check(lib.rfi_backbone_forward(self.backbone._h, P(b.x_in), DEVICE, n, h, w, b.pf, DEVICE))
-        for lvl in range(5):
+
+        def rpn_backward(lvl):
+            """Loss (global normaliser on the device) and backward pass of the shared head at one level; its activations of this
+            level must be the ones the head holds."""
+            _, hl, wl, _ = b.shapes[lvl]
+            check(lib.rfi_op_rpn_loss_devcount(H, P(b.rpn_out[lvl]), n * hl * wl, 4, P(b.rpn_lab[lvl]), P(b.rpn_tgt[lvl]), P(b.n_sampled),
+                                               1.0 / 9, P(b.rpn_dout[lvl]), P(b.rpn_ws[lvl]), C.c_void_p(b.rpn_loss2.ptr + 8 * lvl)))
+            check(lib.rfi_model_backward_dlogits(self.rpn._h, P(b.feats[lvl]), DEVICE, P(b.rpn_dout[lvl]), DEVICE, n, hl, wl))
+            self.rpn.accumulate_gradients("add")
+            check(lib.rfi_model_input_grad(self.rpn._h, P(b.dfe[lvl]), DEVICE))          # the first term of d loss / d P_l
+
+        # The head keeps the activations of ONE pass.  Level 0 (three quarters of the head's work) trains at once, while its
+        # activations are there -- its targets were sampled above; the other levels' passes come back after the proposals,
+        # behind the read-back of the RoI counts (their forward passes are repeated then: a sixteenth of level 0's each)
+        self.rpn.accumulate_gradients("begin")
+        for lvl in (0, 1, 2, 3, 4):
             _, hl, wl, _ = b.shapes[lvl]
             check(lib.rfi_model_forward_nhwc(self.rpn._h, P(b.feats[lvl]), DEVICE, n, hl, wl, P(b.rpn_out[lvl]), DEVICE))
+            if lvl == 0 and not _RPN_ALL_LATE:
+                rpn_backward(0)
         # ---- proposals: top pre_nms per level -> decode + clip -> per-level NMS -> best post_nms + ground truth
         K = self.pre_nms
         for lvl in range(5):
@@ -350,18 +371,12 @@ class MaskRCNN:
                                      P(b.gt_labels), G, P(b.gt_base), t1, t2, t3, P(b.rois), P(b.box_lab), P(b.box_tgt), P(b.roi_gt),
                                      P(b.roi_lvl), P(b.img_start), P(b.rois_m), P(b.rois_g), P(b.lvl_m), P(b.fg_start), P(b.counts)))
         check(lib.rfi_readback_begin(H, P(b.counts), 8))         # (R, Rf) come down while the RPN head's backward passes run
-        # ---- the RPN head's own training work: loss level by level (global normaliser on the device), one shared head
-        self.rpn.accumulate_gradients("begin")
-        for lvl in (4, 0, 1, 2, 3):                              # (level 4 first: its forward pass was the last one above)
+        # ---- the rest of the RPN head's own training work (level 4 first: its forward pass was the last one above)
+        for lvl in ((4, 0, 1, 2, 3) if _RPN_ALL_LATE else (4, 1, 2, 3)):
             _, hl, wl, _ = b.shapes[lvl]
-            check(lib.rfi_op_rpn_loss_devcount(H, P(b.rpn_out[lvl]), n * hl * wl, 4, P(b.rpn_lab[lvl]), P(b.rpn_tgt[lvl]), P(b.n_sampled),
-                                               1.0 / 9, P(b.rpn_dout[lvl]), P(b.rpn_ws[lvl]), C.c_void_p(b.rpn_loss2.ptr + 8 * lvl)))
-            # (forward again: the head keeps the activations of ONE pass, and later passes overwrote this level's)
             if lvl != 4:
                 check(lib.rfi_model_forward_nhwc(self.rpn._h, P(b.feats[lvl]), DEVICE, n, hl, wl, P(b.rpn_out[lvl]), DEVICE))
-            check(lib.rfi_model_backward_dlogits(self.rpn._h, P(b.feats[lvl]), DEVICE, P(b.rpn_dout[lvl]), DEVICE, n, hl, wl))
-            self.rpn.accumulate_gradients("add")
-            check(lib.rfi_model_input_grad(self.rpn._h, P(b.dfe[lvl]), DEVICE))          # the first term of d loss / d P_l
+            rpn_backward(lvl)
         self.rpn.accumulate_gradients("end")
         cnt2 = (C.c_int32 * 2)()
         check(lib.rfi_readback_end(H, cnt2, 8))
