@@ -181,13 +181,17 @@ def test_assembled_step_is_bitwise_reproducible():
     det = MaskRCNN(2, 3, 16, 64, 128, seed=7)
     det.keep_trace = True
     x, targets = _batch(np.random.default_rng(1), n=4)
+    watch = [e[0] for e in det.backbone._entries if e[0].endswith("weight") and ("conv" in e[0] or "downsample.0" in e[0] or "blocks" in e[0])][::5]
     runs = []
     for _ in range(4):
         det.sample_step = 11
         losses = det.train_step(x, targets, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)
-        runs.append((losses, dict(det.last_trace["grad_norms"]), det.last_trace["rois"].copy()))
-    for losses, norms, rois in runs[1:]:
+        # (the backbone's weight gradients run on the side stream next to its main chain: whole tensors, not only their norm)
+        grads = {k: det.backbone.grad(k).copy() for k in watch}
+        runs.append((losses, dict(det.last_trace["grad_norms"]), det.last_trace["rois"].copy(), grads))
+    for losses, norms, rois, grads in runs[1:]:
         assert losses == runs[0][0] and norms == runs[0][1] and np.array_equal(rois, runs[0][2])
+        assert all(np.array_equal(grads[k], runs[0][3][k]) for k in watch)
 
 
 def test_data_parallel_step_on_a_rank_without_foreground():
