@@ -10,6 +10,10 @@ segmentation_models_pytorch, so the class is builder-defined:
 with ``BasicBlock`` the published ResNet-18 block (conv3x3 - BN - ReLU - conv3x3 - BN, identity or Conv1x1(stride 2)
 + BN shortcut, ReLU).  ``state_dict`` keys are those ``torch.nn`` gives that module tree (oracle/resnet_unet_ref.py
 holds it as plain ``torch.nn`` modules).  The optimisation step is the U-Net's (scripts/train_model.py:120-151).
+
+``set_compute_dtype("bfloat16")`` selects the bfloat16 data flow (csrc/model_planes.cpp: every tensor between kernels in HBM
+as bfloat16, the stride-2 3x3 / 1x1 layers as strided plane contractions, their input gradient by parity classes) when
+``init_features % 16 == 0``; other widths keep float32 tensors and round the operands at staging.
 """
 from __future__ import annotations
 

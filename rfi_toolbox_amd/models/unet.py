@@ -162,7 +162,9 @@ class HipSegmenter:
         (exact fmaf chain).  ``"bfloat16"``: activations stored in HBM as bf16, bf16 MFMA operands, float32
         accumulate, float32 BatchNorm / loss / optimiser -- a builder-chosen reduced-precision mode, NOT the reference's
         arithmetic (its CPU path, the parity target, is float32; on a GPU it autocasts to float16 with a GradScaler,
-        train_model.py:131,144); the 3x3 layers run on the plane kernels (LDS-DMA staged operands).  ``"float32_planes"``: the default arithmetic on pre-split plane tensors (same kernels as
+        train_model.py:131,144); every contraction runs on the plane kernels (LDS-DMA staged operands; the transposed convs
+        too at widths in whole 32-channel blocks); ``UNetResNet18`` has this data flow at widths in whole 16-channel chunks
+        and falls back to ``"bfloat16_regs"`` at others, as the models without a plane flow do.  ``"float32_planes"``: the default arithmetic on pre-split plane tensors (same kernels as
         bfloat16, three pieces per value).  ``"bfloat16_regs"``: round 1's bf16 mode (float32 storage, operands
         rounded in registers)."""
         code = {"float32": 2, "fp32": 2, "f32": 2, "float32_3xbf16": 2, "float32_mfma": 0, "f32mfma": 0,
