@@ -408,8 +408,8 @@ int rfi_model_input_grad(rfi_model* m, float* dx, int dx_mem) {
         RFI_REQUIRE(m->pN > 0 && dx, "input_grad: no backward pass has run");
         m->ctx->activate();
         const size_t cnt = (size_t)m->pN * m->pH * m->pW * m->in_ch;
-        RFI_CHECK_HIP(hipMemcpyAsync(dx, m->buf(m->mkGx), cnt * sizeof(float),
-                                     dx_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
+        if (dx_mem == RFI_DEVICE) launch_copy_d2d(m->ctx, dx, m->buf(m->mkGx), cnt * sizeof(float));
+        else RFI_CHECK_HIP(hipMemcpyAsync(dx, m->buf(m->mkGx), cnt * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
         if (dx_mem != RFI_DEVICE || getenv("RFI_SYNC_ALWAYS")) RFI_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));   // (sync_if_host below)
     });
 }
@@ -697,6 +697,11 @@ int rfi_model_set_head_sigmoid(rfi_model* m, int enabled) {
 
 namespace {
 
+// a copy on the model's stream: between two device buffers as a kernel (launch_copy_d2d), else hipMemcpyAsync
+void copy_on_stream(rfi_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (kind == hipMemcpyDeviceToDevice) launch_copy_d2d(ctx, dst, src, bytes);
+    else RFI_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+}
 const float* stage_input(rfi_model* m, const float* x, int x_mem, int n, int h, int w, bool nchw) {
     const size_t cnt = (size_t)n * h * w * m->in_ch;
     const float* dev = x;
@@ -732,9 +737,7 @@ void emit_logits(rfi_model* m, float* out, int out_mem, int n, int h, int w, boo
         launch_nhwc_to_nchw(m->ctx, src, n, m->out_ch, h, w, m->buf(m->out_stage));
         src = m->buf(m->out_stage);
     }
-    RFI_CHECK_HIP(hipMemcpyAsync(out, src, cnt * sizeof(float),
-                                 out_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                                 m->ctx->stream));
+    copy_on_stream(m->ctx, out, src, cnt * sizeof(float), out_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
     sync_if_host(m, out_mem);
 }
 float read_scalar(rfi_model* m, const float* dev) {
@@ -853,8 +856,8 @@ int rfi_model_backward_dlogits(rfi_model* m, const float* x, int x_mem, const fl
         m->ctx->activate();
         const float* xd = stage_input(m, x, x_mem, n, h, w, false);
         const size_t cnt = (size_t)n * h * w * m->out_scale * m->out_scale * m->out_ch;
-        RFI_CHECK_HIP(hipMemcpyAsync(m->buf(m->dlogits), dlogits, cnt * sizeof(float),
-                                     dlogits_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->ctx->stream));
+        copy_on_stream(m->ctx, m->buf(m->dlogits), dlogits, cnt * sizeof(float),
+                       dlogits_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
         struct Flag { rfi_model* m; ~Flag() { m->ext_dlogits = false; } } flag{m};
         m->ext_dlogits = true;
         m->backward(xd, nullptr, n, h, w);
@@ -872,8 +875,8 @@ int rfi_backbone_forward(rfi_model* m, const float* x, int x_mem, int n, int h, 
             if (!feats[i]) continue;
             const int lvl = i + 2;
             const size_t cnt = (size_t)n * (h >> lvl) * (w >> lvl) * m->out_ch;
-            RFI_CHECK_HIP(hipMemcpyAsync(feats[i], m->buf(i < 4 ? m->fP[i] : m->fP6), cnt * sizeof(float),
-                                         feats_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
+            copy_on_stream(m->ctx, feats[i], m->buf(i < 4 ? m->fP[i] : m->fP6), cnt * sizeof(float),
+                           feats_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
         }
         sync_if_host(m, x_mem, feats_mem);
     });
@@ -889,8 +892,8 @@ int rfi_backbone_backward(rfi_model* m, const float* x, int x_mem, int n, int h,
             const size_t cnt = (size_t)n * (h >> lvl) * (w >> lvl) * m->out_ch;
             float* dst = m->buf(i < 4 ? m->fdP[i] : m->fdP6);
             if (dfeats[i])
-                RFI_CHECK_HIP(hipMemcpyAsync(dst, dfeats[i], cnt * sizeof(float),
-                                             dfeats_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->ctx->stream));
+                copy_on_stream(m->ctx, dst, dfeats[i], cnt * sizeof(float),
+                               dfeats_mem == RFI_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
             else
                 RFI_CHECK_HIP(hipMemsetAsync(dst, 0, cnt * sizeof(float), m->ctx->stream));
         }
@@ -951,7 +954,7 @@ int rfi_model_grad_accumulate(rfi_model* m, int phase) {
         if (!m->grad_acc) m->grad_acc = static_cast<float*>(m->ctx->alloc(bytes));
         if (phase == 0) RFI_CHECK_HIP(hipMemsetAsync(m->grad_acc, 0, bytes, m->ctx->stream));
         else if (phase == 1) launch_add_inplace(m->ctx, m->grad_acc, m->grads, (int64_t)m->n_flat);
-        else RFI_CHECK_HIP(hipMemcpyAsync(m->grads, m->grad_acc, bytes, hipMemcpyDeviceToDevice, m->ctx->stream));
+        else launch_copy_d2d(m->ctx, m->grads, m->grad_acc, bytes);
     });
 }
 int rfi_model_grad_buffer(rfi_model* m, float** dptr, int64_t* n_floats) {

@@ -415,6 +415,8 @@ void launch_bn_add_relu(rfi_ctx* ctx, const float* y, const float* scale, const 
                         const float* s_scale, const float* s_shift, int64_t M, int C, MutView out, MutView out2);
 void launch_relu_mask(rfi_ctx* ctx, View da, View da2, View a, View base, int64_t M, int C, float* dz);   // (da + da2) * (a > 0) + base
 void launch_add_inplace(rfi_ctx* ctx, float* x, const float* y, int64_t n);
+// device-to-device copy as a kernel on the context's stream (hipMemcpyAsync's blit path idles the queue ~55 us per copy)
+void launch_copy_d2d(rfi_ctx* ctx, void* dst, const void* src, size_t bytes);
 // 3x3 stride-2 filters [9][Cout][Cin] <-> their 2x2 form on the space-to-depth input [4][Cout][4 Cin]
 void launch_w_s2d(rfi_ctx* ctx, float* w3, int Cout, int Cin, float* w2, bool to_s2d);
 

@@ -384,7 +384,7 @@ void rfi_model::forward_backbone(const float* x_dev, int n, int h, int w) {
         const Sh s{n, h >> (i + 2), w >> (i + 2)};
         ConvBN& ci = convs[fpn_inner[i]];
         conv(this, View{buf(k.A), k.cout}, InXform{}, s, s.H, s.W, params + ci.w_off, ci.w3, params + ci.b_off, k.cout, F, 1, 1, 0, buf(fL[i]));
-        if (i == 3) RFI_CHECK_HIP(hipMemcpyAsync(buf(fM[i]), buf(fL[i]), (size_t)s.N * s.H * s.W * F * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        if (i == 3) launch_copy_d2d(ctx, buf(fM[i]), buf(fL[i]), (size_t)s.N * s.H * s.W * F * sizeof(float));
         else launch_fpn_merge_fwd(ctx, buf(fL[i]), buf(fM[i + 1]), s.N, s.H, s.W, F, buf(fM[i]));
         ConvBN& cl = convs[fpn_layer[i]];
         conv(this, View{buf(fM[i]), F}, InXform{}, s, s.H, s.W, params + cl.w_off, cl.w3, params + cl.b_off, F, F, 3, 1, 1, buf(fP[i]));
@@ -427,7 +427,7 @@ void rfi_model::backward_backbone(const float* x_dev, int n, int h, int w) {
     float* gother = buf(bG[1]);
     {
         const BBlock& k = bb.back();
-        RFI_CHECK_HIP(hipMemcpyAsync(gout, dC[3], (size_t)n * (h >> 5) * (w >> 5) * k.cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        launch_copy_d2d(ctx, gout, dC[3], (size_t)n * (h >> 5) * (w >> 5) * k.cout * sizeof(float));
     }
     for (int b = (int)bb.size() - 1; b >= 0; --b) {
         BBlock& k = bb[b];

@@ -99,6 +99,12 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
         *reinterpret_cast<f32x4*>(dz + i * 4) = g;
     }
 }
+__global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void copy1_kernel(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ x, const float* __restrict__ y, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
@@ -331,6 +337,23 @@ void launch_relu_mask(rfi_ctx* ctx, View da, View da2, View a, View base, int64_
     hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_of(M * C / 4)), dim3(256), 0, ctx->stream, da.p, da.pstride, da2.p, da2.pstride,
                        a.p, a.pstride, base.p, base.pstride, M, C, dz);
     check_launch("relu_mask");
+}
+// A device-to-device copy as an ordinary kernel on the context's stream: hipMemcpyAsync(DeviceToDevice) goes through the
+// runtime's blit path, which left the queue idle for ~55 us in front of every copy (rocprofv3 trace of the detector's step:
+// 50 copies, 2.8 of 28 ms); a kernel follows its predecessor like any other launch
+void launch_copy_d2d(rfi_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    ProfScope ps(ctx, FAM_ELEMWISE, 0, 2.0 * bytes);
+    const bool v16 = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 15) == 0;
+    if (v16) {
+        const int64_t n = (int64_t)(bytes / 16);
+        hipLaunchKernelGGL(copy16_kernel, dim3(grid_of(n)), dim3(256), 0, ctx->stream, static_cast<uint4*>(dst), static_cast<const uint4*>(src), n);
+    } else {
+        const int64_t n = (int64_t)bytes;
+        hipLaunchKernelGGL(copy1_kernel, dim3(grid_of(n)), dim3(256), 0, ctx->stream, static_cast<unsigned char*>(dst),
+                           static_cast<const unsigned char*>(src), n);
+    }
+    check_launch("copy_d2d");
 }
 void launch_add_inplace(rfi_ctx* ctx, float* x, const float* y, int64_t n) {
     RFI_REQUIRE(n % 4 == 0, "add_inplace: n % 4 == 0");
