@@ -222,6 +222,7 @@ struct rfi_model {
     int bY0 = -1, bP0 = -1, bArg = -1, bdW = -1, bS = -1, bCol = -1, bWp = -1, fP6 = -1, fdP6 = -1;
     int stem_kp() const { return (49 * in_ch + 15) / 16 * 16; }      // K of the K-packed 7x7 stem
     int fL[4] = {-1, -1, -1, -1}, fM[4] = {-1, -1, -1, -1}, fP[4] = {-1, -1, -1, -1}, fdM[4] = {-1, -1, -1, -1}, fdP[4] = {-1, -1, -1, -1};
+    float* bb_stem_w3 = nullptr;      // 3 x bf16 records of the K-packed stem filters (rebuilt with them every step)
     int bG[6] = {-1, -1, -1, -1, -1, -1};
     int bT[4][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};   // dY3 / dY2 / dY1 / dYd of a Bottleneck, by block index mod 3: what the side stream's weight gradients read
     bool frozen_dirty = true;         // frozen BatchNorm buffers changed: scale / shift must be recomputed

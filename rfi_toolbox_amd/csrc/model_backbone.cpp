@@ -127,8 +127,13 @@ void rfi_model::build_backbone() {
     // 2x2 forms of the stride-2 3x3 filters, 4x tiled affine coefficients of their inputs, identity vectors
     const size_t cmax = (size_t)32 * w0;
     size_t need = 2 * cmax + 16;
+    // (+ the 3 x bf16 records of those forms and of the K-packed stem filters: a launch without them splits a temporary copy and
+    // drains the stream to free it -- eight stalls per step, 0.2 to several ms each in the rocprofv3 timeline of the detector)
     for (auto& k : bb)
-        if (k.stride == 2) need += 2 * align4((size_t)16 * k.width * k.width) + 2 * align4((size_t)4 * k.width);
+        if (k.stride == 2)
+            need += 2 * align4((size_t)16 * k.width * k.width) + 2 * align4((size_t)4 * k.width) +
+                    align4(weights_x3_floats(4, k.width, 4 * k.width)) + align4(weights_x3_floats(4, 4 * k.width, k.width));
+    need += align4(weights_x3_floats(1, w0, stem_kp())) + 16;
     rs_wpool = static_cast<float*>(ctx->alloc(need * sizeof(float)));
     size_t o = 0;
     rs_ones = rs_wpool + o; o += cmax;
@@ -140,7 +145,10 @@ void rfi_model::build_backbone() {
             c.wds2d = rs_wpool + o; o += align4((size_t)16 * k.width * k.width);
             k.sc4 = rs_wpool + o; o += align4((size_t)4 * k.width);
             k.sh4 = rs_wpool + o; o += align4((size_t)4 * k.width);
+            c.ws2d3 = rs_wpool + o; o += align4(weights_x3_floats(4, k.width, 4 * k.width));
+            c.wds2d3 = rs_wpool + o; o += align4(weights_x3_floats(4, 4 * k.width, k.width));
         }
+    bb_stem_w3 = rs_wpool + o; o += align4(weights_x3_floats(1, w0, stem_kp()));
     {
         std::vector<float> h(2 * cmax, 0.0f);
         for (size_t i = 0; i < cmax; ++i) h[i] = 1.0f;
@@ -260,6 +268,10 @@ void rfi_model::refresh_backbone() {
             ConvBN& c = convs[k.c2];
             launch_w_s2d(ctx, params + c.w_off, c.cout, c.cin, c.ws2d, true);
             launch_weight_to_dgrad(ctx, c.ws2d, 4, c.cout, 4 * c.cin, 1, c.wds2d);
+            if (use_w3()) {
+                launch_weights_to_x3(ctx, c.ws2d, 4, c.cout, 4 * c.cin, c.ws2d3);
+                launch_weights_to_x3(ctx, c.wds2d, 4, 4 * c.cin, c.cout, c.wds2d3);
+            }
         }
 }
 
@@ -341,7 +353,8 @@ void rfi_model::forward_backbone(const float* x_dev, int n, int h, int w) {
         const int Kp = stem_kp();
         launch_im2col(ctx, x_dev, n, h, w, in_ch, 7, 2, 3, h / 2, w / 2, Kp, buf(bCol));
         launch_w_pack(ctx, params + c.w_off, 49, c.cout, in_ch, Kp, buf(bWp), true);
-        conv(this, View{buf(bCol), Kp}, InXform{}, Sh{n, h / 2, w / 2}, h / 2, w / 2, buf(bWp), nullptr, nullptr, Kp, c.cout, 1, 1, 0, buf(bY0));
+        if (use_w3()) launch_weights_to_x3(ctx, buf(bWp), 1, c.cout, Kp, bb_stem_w3);
+        conv(this, View{buf(bCol), Kp}, InXform{}, Sh{n, h / 2, w / 2}, h / 2, w / 2, buf(bWp), bb_stem_w3, nullptr, Kp, c.cout, 1, 1, 0, buf(bY0));
         launch_maxpool3_fwd(ctx, buf(bY0), n, h / 2, w / 2, c.cout, c.scale(), c.shift(), buf(bP0), reinterpret_cast<unsigned*>(buf(bArg)));
     }
     const float* a_in = buf(bP0);
@@ -351,7 +364,7 @@ void rfi_model::forward_backbone(const float* x_dev, int n, int h, int w) {
         conv(this, View{a_in, k.cin}, InXform{}, si, si.H, si.W, params + c1.w_off, c1.w3, nullptr, k.cin, k.width, 1, 1, 0, buf(k.Y1));
         if (k.stride == 2) {
             launch_s2d(ctx, buf(k.Y1), n, si.H, si.W, k.width, buf(k.xs1));
-            conv(this, View{buf(k.xs1), 4 * k.width}, InXform{k.sc4, k.sh4, 1, 0.0f}, so, so.H, so.W, c2.ws2d, nullptr, nullptr, 4 * k.width,
+            conv(this, View{buf(k.xs1), 4 * k.width}, InXform{k.sc4, k.sh4, 1, 0.0f}, so, so.H, so.W, c2.ws2d, c2.ws2d3, nullptr, 4 * k.width,
                  k.width, 2, 1, 1, buf(k.Y2));
         } else {
             conv(this, View{buf(k.Y1), k.width}, act_of(c1), so, so.H, so.W, params + c2.w_off, c2.w3, nullptr, k.width, k.width, 3, 1, 1,
@@ -460,7 +473,7 @@ void rfi_model::backward_backbone(const float* x_dev, int n, int h, int w) {
                 side.end();
             }
             float* dXs = buf(bS);                   // scratch [Mo][4 width]
-            conv(this, View{dA2, k.width}, InXform{}, so, so.H, so.W, c2.wds2d, nullptr, nullptr, k.width, 4 * k.width, 2, 1, 0, dXs);
+            conv(this, View{dA2, k.width}, InXform{}, so, so.H, so.W, c2.wds2d, c2.wds2d3, nullptr, k.width, 4 * k.width, 2, 1, 0, dXs);
             launch_d2s_add(ctx, dXs, nullptr, View{}, n, si.H, si.W, k.width, dA1);
         } else {
             { SideScopeB side(this); wgrad(this, View{buf(k.Y1), k.width}, act_of(c1), dA2, k.width, k.width, so, so.H, so.W, 3, 1, 1, grads + c2.w_off); side.end(); }
