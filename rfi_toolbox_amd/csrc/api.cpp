@@ -617,6 +617,7 @@ int rfi_model_store_entry(rfi_model* m, const char* name, void* host, size_t byt
 int rfi_model_store_grad(rfi_model* m, const char* name, void* host, size_t bytes) {
     return guarded([&] {
         m->ctx->activate();
+        m->join_pending_side();
         store_from_flat(m, m->grads, find_entry(m, name), host, bytes);
     });
 }
@@ -950,6 +951,7 @@ int rfi_model_grad_accumulate(rfi_model* m, int phase) {
     return guarded([&] {
         RFI_REQUIRE(phase >= 0 && phase <= 2, "grad_accumulate: phase 0 (begin), 1 (add the current gradients), 2 (end: sum -> gradients)");
         m->ctx->activate();
+        m->join_pending_side();
         const size_t bytes = m->n_flat * sizeof(float);
         if (!m->grad_acc) m->grad_acc = static_cast<float*>(m->ctx->alloc(bytes));
         if (phase == 0) RFI_CHECK_HIP(hipMemsetAsync(m->grad_acc, 0, bytes, m->ctx->stream));
@@ -959,6 +961,8 @@ int rfi_model_grad_accumulate(rfi_model* m, int phase) {
 }
 int rfi_model_grad_buffer(rfi_model* m, float** dptr, int64_t* n_floats) {
     return guarded([&] {
+        m->ctx->activate();
+        m->join_pending_side();                   // (the caller is about to read or reduce the gradients)
         *dptr = m->grads;
         *n_floats = (int64_t)m->n_flat;
     });
@@ -1203,6 +1207,10 @@ void comm_bucket_allreduce(rfi_ctx* ctx, float* dptr, int64_t count) {
 }  // namespace rfi
 extern "C" {
 int rfi_model_allreduce_grads(rfi_model* m) {
+    {
+        const int rc = guarded([&] { m->ctx->activate(); m->join_pending_side(); });
+        if (rc) return rc;
+    }
     if (m->ctx->comm_emulate > 1)          // rfi_comm_emulate: the explicit exchange of the split API is emulated like the buckets
         return guarded([&] {
             m->ctx->activate();

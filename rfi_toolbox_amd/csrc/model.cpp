@@ -59,6 +59,7 @@ rfi_model::~rfi_model() {
     if (d_sums) ctx->release(d_sums);
     if (d_scalars) ctx->release(d_scalars);
     if (wd_ready) (void)hipEventDestroy(wd_ready);
+    if (lazy_ev) (void)hipEventDestroy(lazy_ev);
     for (hipEvent_t e : skip_done) if (e) (void)hipEventDestroy(e);
 }
 
@@ -247,6 +248,7 @@ void rfi_model::reset_channel_state() {
 // ------------------------------------------------------------------------------------ prepare
 void rfi_model::prepare(int n, int h, int w) {
     RFI_REQUIRE(n > 0 && h > 0 && w > 0, "forward: empty batch or image");
+    join_pending_side();                          // (the last pass's weight gradients still read this model's tensors)
     if (ctx->stream != ctx->main_stream) {      // a side-stream launch threw last time: rejoin first
         ctx->stream = ctx->main_stream;
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->side_stream));
@@ -822,6 +824,20 @@ void rfi_model::side_end() {
         RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->side_done[(side_seq - side_bound) % ring], 0));
     ++side_seq;
 }
+void rfi_model::side_join_lazy() {
+    static const bool off = getenv("RFI_NO_LAZY_JOIN") != nullptr;          // A/B runs: join at the end of the pass
+    if (off || (exchange_in_backward && ctx->exchange_active())) return side_join();      // (a bucket may leave right behind this pass)
+    if (!ctx->overlap || side_seq == 0) return;
+    if (!lazy_ev) RFI_CHECK_HIP(hipEventCreateWithFlags(&lazy_ev, hipEventDisableTiming));
+    RFI_CHECK_HIP(hipEventRecord(lazy_ev, ctx->side_stream));
+    lazy_pending = true;
+    side_seq = 0;
+}
+void rfi_model::join_pending_side() {
+    if (!lazy_pending) return;
+    RFI_CHECK_HIP(hipStreamWaitEvent(ctx->main_stream, lazy_ev, 0));
+    lazy_pending = false;
+}
 void rfi_model::side_join() {
     if (!ctx->overlap || side_seq == 0) return;
     const int ring = (int)ctx->side_done.size();
@@ -1009,6 +1025,7 @@ void rfi_model::flush_deferred_wgrads() {
 }
 
 void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, int h, int w) {
+    join_pending_side();
     if (arch == 6) {
         backward_mlp(x_dev, n);
         bucket_ready(0, n_flat);
@@ -1194,6 +1211,7 @@ void rfi_model::backward(const float* x_dev, const uint8_t* labels_dev, int n, i
 
 // ------------------------------------------------------------------------------------ optimiser
 void rfi_model::apply(const rfi_hyper& hp, float grad_scale) {
+    join_pending_side();
     double* ws = reinterpret_cast<double*>(buf(ws_red));
     launch_sumsq(ctx, grads, (int64_t)n_flat, ws, d_sums + 4);
     adam_step += 1;

@@ -331,6 +331,13 @@ struct rfi_model {
     void side_begin_after(hipEvent_t producer_done);   // side stream waits for that producer kernel only (null: as side_begin)
     void side_end();                  // marks the side launch; bounds the main stream's run-ahead
     void side_join();                 // main stream waits for all side work
+    // a head model inside a larger step (the detector's box / mask heads): nothing the caller does next needs this model's WEIGHT
+    // gradients, so the pass ends without waiting for them; whoever touches the gradients, the buffers or the weights next
+    // (apply, all-reduce, accumulate, store_grad, the next forward / backward pass) joins first
+    hipEvent_t lazy_ev = nullptr;
+    bool lazy_pending = false;
+    void side_join_lazy();
+    void join_pending_side();
     // weight gradients parked for a later point of the backward pass (model.cpp, wgrad_on_side)
     struct DeferredWgrad { rfi::WgradArgs a; hipEvent_t after; int to; };
     std::vector<DeferredWgrad> deferred;

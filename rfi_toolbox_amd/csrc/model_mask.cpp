@@ -382,5 +382,5 @@ void rfi_model::backward_mask(const float* x_dev, const uint8_t* labels_dev, int
         ConvArgs a = conv3x3_args(this, View{dA, C}, InXform{}, c.wd, c.wd3, nullptr, i == 0 ? buf(mkGx) : buf(mkG[i - 1]), C, n, h, w);
         launch_conv(ctx, a);
     }
-    side_join();
+    side_join_lazy();                 // (a head inside the detector's step: the caller goes on with the input gradient)
 }

@@ -217,5 +217,5 @@ void rfi_model::backward_mlp(const float* x_dev, int n) {
         a.bf16x3 = compute_x3;
         launch_conv(ctx, a);
     }
-    side_join();
+    side_join_lazy();                 // (the caller goes on with the input gradient; the weight gradients are needed at the optimiser step)
 }
