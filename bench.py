@@ -564,8 +564,8 @@ def cpu_baseline_maskrcnn(size, gpu_batch, seconds_cap=25.0):
 def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
     """BASELINE configs[3]: one training step of the assembled detector per `step` (backbone, RPN on five levels with its
     losses, proposals, RoI sampling, RoIAlign, box head + Fast R-CNN losses, mask head + mask loss, every backward pass, clip
-    + Adam of the four parameter sets).  Tensors live in HBM; the box bookkeeping between the stages runs on the host and IS
-    inside the timed region."""
+    + Adam of the four parameter sets).  Tensors AND the box bookkeeping between the stages (top-k, samplers, proposal
+    selection, RoI lists) live in HBM; the host reads two RoI counts per step."""
     import torch
 
     from rfi_toolbox_amd.models import MaskRCNN
@@ -643,8 +643,9 @@ def run_maskrcnn(args, ctx, D, rank, local_rank, world, n_ranks_seen):
                     "tflops_whole_step": round(step_flops / (ms_per_step * 1e-3) / 1e12, 3),
                     "kernel_ms_per_step_serial": round(kernel_ms, 3),
                     "host_bookkeeping_ms_per_step": round(max(ms_per_step - kernel_ms, 0.0), 3),
-                    "note": "the box bookkeeping between the stages (top-k, sampling, level sort; RPN outputs and labels cross "
-                            "PCIe) runs on the host inside the timed region: ms_per_step - kernel_ms_per_step_serial is its share",
+                    "note": "the box bookkeeping between the stages (top-k, samplers, proposal selection, RoI lists) runs on the "
+                            "device; host_bookkeeping = max(0, ms_per_step - kernel_ms_per_step_serial), where the serial sum "
+                            "counts the side-stream weight gradients one after the other",
                     "final_losses": {k: round(float(v), 5) for k, v in losses.items()}},
            "families": per_family(fam, P)}
     if world == 1 and not args.no_cpu_baseline:

@@ -2,6 +2,7 @@
 # Everything under profiles/<TAG>_* comes from this script, run on the GPU box:
 #   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r3'           # the headline workload (float32 + bf16 companion)
 #   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r3 extra'     # cnn3, unet1024, resnet1024, maskrcnn: stats + PMC passes
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r3 extra "maskrcnn"'     # ... of the named workloads only
 # then `python tools/collect_profiles.py r3` here folds gpurun_out/<TAG>/ into profiles/.
 # Bench lines of every workload / arithmetic, rocprofv3 kernel statistics (serial and with the weight-gradient
 # overlap), and the PMC passes (HBM traffic, matrix-pipe busy cycles) -- counters in their own runs, --kernel-trace
@@ -10,6 +11,7 @@ set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r3}
 PART=${2:-main}
+WLS=${3:-cnn3 unet1024 resnet1024 maskrcnn}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 export TMPDIR=/tmp
@@ -44,7 +46,7 @@ if [ "$PART" = main ]; then
   pmc3 f32 --dtype f32
   pmc3 bf16 --dtype bf16
 else
-  for wl in cnn3 unet1024 resnet1024 maskrcnn; do
+  for wl in $WLS; do
     $T 400 $B --workload $wl > "$O/bench_$wl.json" 2>> "$O/bench.err"
     RFI_NO_OVERLAP=1 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_serial_$wl" -- $B $P --workload $wl > "$O/stats_serial_$wl.log" 2>&1
     pmc3 $wl --workload $wl
