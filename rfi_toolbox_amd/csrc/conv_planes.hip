@@ -314,8 +314,56 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
             f32x4 p1[NTL], p2[NTL];
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) p1[nt] = p2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto quarters = [&](auto full_tag) {
+            // quarter pq's 8 pixel rows x 4 channels of this lane (rq: its accumulator values, transposed): bias, rounding, the
+            // 8- / 16-byte row store, statistics (or the BatchNorm-backward sums)
+            auto finish_quarter = [&](auto full_tag, int pq, f32x4 rq) {
                 constexpr bool FULL = decltype(full_tag)::value;
+                const int nt = pq / (MT * 4), mt = (pq / 4) % MT, q = pq & 3;
+                f32x4 v = rq + bias4[nt];
+                const int p0 = (wm * MT + mt) * 32 + q * 8;              // first pixel of the row group (wave-uniform)
+                const unsigned off = tbase + (unsigned)(p0 / TW) * row_st + (unsigned)(p0 % TW) * col_st + lane_off[nt];
+                bool ok = true;
+                if constexpr (!FULL) {
+                    const int co = n0 + (wn * NTL + nt) * 32 + g4;
+                    const int oy = ct.oy0 + (p0 + pl) / TW, ox = ct.ox0 + (p0 + pl) % TW;
+                    ok = co < a.Cout && oy < a.H && ox < a.W;
+                }
+                if (FULL || ok) {
+                    if constexpr (OM >= 1) {            // the tensor holds bf16 values (RNE; NaN stays NaN): v_cvt_pk_bf16_f32
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+                        const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+                        v = f32x4{__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                                  __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+#ifdef RFI_DIAG_STAMPS
+                        if (d.diag & 8) asm volatile("" :: "v"(w0), "v"(w1));      // (timing experiment: the epilogue without its stores)
+                        else
+#endif
+                        if constexpr (OM == 2) *reinterpret_cast<u32x2*>(a.y16 + off) = u32x2{w0, w1};
+                    }
+                    if constexpr (OM != 2) *reinterpret_cast<f32x4*>(a.y + off) = v;
+                    if constexpr (BWD) {
+                        const u32x2 t = ypre[BWD ? mt : 0][BWD ? nt : 0][q >> 1][q & 1];
+                        const f32x4 yv = {__builtin_bit_cast(float, t[0] << 16), __builtin_bit_cast(float, t[0] & 0xffff0000u),
+                                          __builtin_bit_cast(float, t[1] << 16), __builtin_bit_cast(float, t[1] & 0xffff0000u)};
+                        const f32x4 z = yv * bsc[BWD ? nt : 0] + bsh[BWD ? nt : 0], xh = (yv - bmu[BWD ? nt : 0]) * bis[BWD ? nt : 0];
+                        f32x4 dz;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.0f ? v[e] : v[e] * a.bwd_slope;
+                        p1[nt] += dz;
+                        p2[nt] += dz * xh;
+                    } else {
+                        p1[nt] += v;
+                        p2[nt] += v * v;
+                    }
+                }
+            };
+            // (Measured and not kept, round 4: the same loop for full tiles as a hand-counted software pipeline two quarters deep
+            // -- inline-asm ds_read_b128 / ds_write_b32 with lgkmcnt(5) instead of the compiler's lgkmcnt(0) per quarter.  Cycle
+            // stamps: epilogue 8.1 k -> 7.0 k cycles per 64-channel tile, the co-resident workgroup's MFMA phase 1.64 k -> 1.68 k
+            // per item; kernel and step time +-0.)
+            auto quarters = [&](auto full_tag) {
                 f32x4 rq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int qi = 0; qi <= NQ; ++qi) {
@@ -325,44 +373,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) s_ep[(qi & 1) * 288 + (k + 4 * lh) * 36 + li] = ac[mt][nt][q * 4 + k];
                     }
-                    if (qi > 0) {
-                        const int pq = qi - 1, nt = pq / (MT * 4), mt = (pq / 4) % MT, q = pq & 3;
-                        f32x4 v = rq + bias4[nt];
-                        const int p0 = (wm * MT + mt) * 32 + q * 8;              // first pixel of the row group (wave-uniform)
-                        const unsigned off = tbase + (unsigned)(p0 / TW) * row_st + (unsigned)(p0 % TW) * col_st + lane_off[nt];
-                        bool ok = true;
-                        if constexpr (!FULL) {
-                            const int co = n0 + (wn * NTL + nt) * 32 + g4;
-                            const int oy = ct.oy0 + (p0 + pl) / TW, ox = ct.ox0 + (p0 + pl) % TW;
-                            ok = co < a.Cout && oy < a.H && ox < a.W;
-                        }
-                        if (FULL || ok) {
-                            if constexpr (OM >= 1) {            // the tensor holds bf16 values (RNE; NaN stays NaN): v_cvt_pk_bf16_f32
-                                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                                const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
-                                const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
-                                v = f32x4{__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
-                                          __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
-                                if constexpr (OM == 2) *reinterpret_cast<u32x2*>(a.y16 + off) = u32x2{w0, w1};
-                            }
-                            if constexpr (OM != 2) *reinterpret_cast<f32x4*>(a.y + off) = v;
-                            if constexpr (BWD) {
-                                const u32x2 t = ypre[BWD ? mt : 0][BWD ? nt : 0][q >> 1][q & 1];
-                                const f32x4 yv = {__builtin_bit_cast(float, t[0] << 16), __builtin_bit_cast(float, t[0] & 0xffff0000u),
-                                                  __builtin_bit_cast(float, t[1] << 16), __builtin_bit_cast(float, t[1] & 0xffff0000u)};
-                                const f32x4 z = yv * bsc[BWD ? nt : 0] + bsh[BWD ? nt : 0], xh = (yv - bmu[BWD ? nt : 0]) * bis[BWD ? nt : 0];
-                                f32x4 dz;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.0f ? v[e] : v[e] * a.bwd_slope;
-                                p1[nt] += dz;
-                                p2[nt] += dz * xh;
-                            } else {
-                                p1[nt] += v;
-                                p2[nt] += v * v;
-                            }
-                        }
-                    }
+                    if (qi > 0) finish_quarter(full_tag, qi - 1, rq);
                 }
             };
             if (full) quarters(std::true_type{});
@@ -464,14 +475,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                     if (g < gcount) {
                         const bool last = kc == d.nkc - 1 && g == gcount - 1;
                         const bool wrap = g + 1 >= gcount;                  // the next item starts a new chunk (needs its filters)
+                        RFI_T(t0);
                         if (!last) {
                             issue_A(wrap ? tl[0] : tl[G > 1 ? g + 1 < G ? g + 1 : 0 : 0], wrap ? kc + 1 : kc, (item + 1) & 1);
+#ifdef RFI_DIAG_STAMPS
+                            if (wrap && !(d.diag & 2)) issue_B(kc + 1, (kc + 1) & 1);      // (timing experiment: no filter DMA after the first chunk)
+#else
                             if (wrap) issue_B(kc + 1, (kc + 1) & 1);
+#endif
                         }
+                        RFI_T(t1);
                         if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RFI_DIAG_STAMPS
+                        else if (wrap && !(d.diag & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::A_ITEMS + C::B_ITEMS) : "memory");
+#else
                         else if (wrap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::A_ITEMS + C::B_ITEMS) : "memory");
+#endif
                         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::A_ITEMS) : "memory");
+                        RFI_T(t2);
                         __builtin_amdgcn_s_barrier();                       // every wave's pieces of THIS item have landed
+                        RFI_T(t3);
                         {
                             const unsigned aoff = (unsigned)(item & 1) * C::A_BYTES, boff = (unsigned)(kc & 1) * C::B_BYTES;
                             u32x4 afr[2][MT], bfr[2][NTL];
@@ -521,14 +544,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void pconv_kernel(PConvDev d) {
                             tap_step(std::integral_constant<int, 6>{}); tap_step(std::integral_constant<int, 7>{});
                             tap_step(std::integral_constant<int, 8>{});
                         }
+                        RFI_T(t4);
                         __builtin_amdgcn_s_barrier();       // every wave is done reading this item's buffers (all reads were waited for)
+                        RFI_T(t5);
+#ifdef RFI_DIAG_STAMPS
+                        RFI_ACC(0, t0, t1); RFI_ACC(1, t1, t2); RFI_ACC(2, t2, t3); RFI_ACC(3, t3, t4); RFI_ACC(4, t4, t5);
+                        ++nitem_;
+#endif
                         ++item;
                     }
                 }
             }
+            RFI_T(te0);
             epilogue_group(g0, tl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+#ifdef RFI_DIAG_STAMPS
+            { RFI_T(te1); RFI_ACC(5, te0, te1); }
+#endif
         }
     } else
     for (int g0 = 0; g0 < my_tiles; g0 += G) {
@@ -696,8 +729,9 @@ void launch_cfg(rfi_ctx* ctx, PConvDev& d) {
         RFI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) sm[i] += (double)hs[w * 8 + i];
-        std::fprintf(stderr, "[stamps] pconv P%d tile %dx%d grid %dx%d items/wave %.1f tiles/wg %.1f | cycles per item: issue %.0f "
-                     "vmwait %.0f bar1 %.0f mfma %.0f bar2 %.0f | epilogue per group %.0f\n", P, TH, TW, GX, ychunks, sm[6] / nw,
+        std::fprintf(stderr, "[stamps] pconv %dx%dx%d k%d->%d r%ds%d%s%s P%d tile %dx%d grid %dx%d items/wave %.1f tiles/wg %.1f | cycles per item: issue %.0f "
+                     "vmwait %.0f bar1 %.0f mfma %.0f bar2 %.0f | epilogue per group %.0f\n", a.N, a.H, a.W, d.nkc * 16, a.Cout, R, S, DB ? " db" : "",
+                     BWD ? " bwd" : "", P, TH, TW, GX, ychunks, sm[6] / nw,
                      sm[7] / nw, sm[0] / sm[6], sm[1] / sm[6], sm[2] / sm[6], sm[3] / sm[6], sm[4] / sm[6], sm[5] / (sm[7] / G));
         RFI_CHECK_HIP(hipFree(d.stamps));
         d.stamps = nullptr;

@@ -12,6 +12,7 @@
 // and the producers split 128 x 16 values per item (2 float4 per thread).  Everything is double-buffered ([A0 | A1 | B0 |
 // B1] = 2 x 14 + 2 x 24 KiB), one barrier per item.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -320,7 +321,8 @@ void launch_gw(rfi_ctx* ctx, GwDev& d) {
     using C = GwCfg<NB>;
     const int ntiles = (int)cdiv(d.M, TM);
     const int ycols = (int)cdiv(d.ncb, NB);
-    const int gmax = std::max(8, 256 / ycols);
+    static const int wgs = getenv("RFI_GW_WGS") ? atoi(getenv("RFI_GW_WGS")) : 256;
+    const int gmax = std::max(8, wgs / ycols);
     const int tx = (int)cdiv(ntiles, 8);
     const int per = (int)cdiv(tx, std::max(1, gmax / 8));
     int GX = 8 * (int)cdiv(tx, per);
