@@ -83,7 +83,7 @@ def test_bench_supervisor_falls_back_when_a_rank_stalls_after_init():
     import time
     t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "8"],
-                       env=_clean_env(RFI_BENCH_STALL_RANK="5", RFI_BENCH_STALL_PHASE="control_plane", RFI_BENCH_PHASE_TIMEOUT="5"),
+                       env=_clean_env(RFI_BENCH_STALL_RANK="5", RFI_BENCH_STALL_PHASE="control_plane", RFI_BENCH_PHASE_TIMEOUT="12"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert time.time() - t0 < 60
@@ -125,7 +125,7 @@ def test_bench_under_torch_distributed_run():
 
 
 def test_bench_under_torch_distributed_run_falls_back_when_a_rank_stalls():
-    r = _torchrun(2, _free_port(), RFI_BENCH_STALL_RANK="1", RFI_BENCH_STALL_PHASE="control_plane", RFI_BENCH_PHASE_TIMEOUT="5")
+    r = _torchrun(2, _free_port(), RFI_BENCH_STALL_RANK="1", RFI_BENCH_STALL_PHASE="control_plane", RFI_BENCH_PHASE_TIMEOUT="12")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["fallback"] == "unbucketed", r.stdout
