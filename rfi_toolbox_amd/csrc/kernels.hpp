@@ -135,6 +135,7 @@ struct WgradArgs {
 size_t wgrad_slab_floats(const WgradArgs& a, int impl);
 bool wgrad_ws_eligible(const WgradArgs& a);      // wgrad_ws.hip: the wave-specialised kernel (float32 tensors, 3 x bf16 or bf16 operands)
 void launch_wgrad_ws(rfi_ctx* ctx, const WgradArgs& a);
+size_t wgrad_ws_slab_floats(const WgradArgs& a);  // slab workspace of the shapes only wgrad_ws covers (R = 2 / stride 2), else 0
 bool wgrad_stem_eligible(const WgradArgs& a);    // wgrad_stem.hip: the first conv of a network (Cx = 4 padded, Cy 32 / 64)
 void launch_wgrad_stem(rfi_ctx* ctx, const WgradArgs& a);
 void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a, int impl = IMPL_AUTO);

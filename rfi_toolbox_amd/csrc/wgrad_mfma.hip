@@ -444,6 +444,7 @@ size_t wgrad_slab_floats(const WgradArgs& a, int impl) {
         return std::max(need, pwgrad_slab_floats_f32(a));
     if (impl == IMPL_MFMA_BF16 || impl == IMPL_MFMA_BF16X3) impl = IMPL_MFMA;
     if (impl != IMPL_DIRECT && wgrad_split_eligible(a)) need = std::max(need, wgrad_split_slab_floats(a));
+    if (impl != IMPL_DIRECT) need = std::max(need, wgrad_ws_slab_floats(a));      // (the transposed conv's shape: its own plan)
     if (impl != IMPL_DIRECT && wgrad_mfma_eligible(a)) {
         const Plan p = dispatch(nullptr, a, SEL_PLAN, 256);
         // plan with the largest CU count we may meet so the workspace always suffices
@@ -484,7 +485,7 @@ void launch_wgrad(rfi_ctx* ctx, const WgradArgs& a_in, int impl) {
         launch_wgrad_stem(ctx, a);    // Cx = 4: (tap, channel) packed into the GEMM's N (wgrad_stem.hip)
         return;
     }
-    if (!no_ws && (a.bf16x3 || a.bf16) && wgrad_ws_eligible(a) && wgrad_split_eligible(a)) {
+    if (!no_ws && (a.bf16x3 || a.bf16) && wgrad_ws_eligible(a) && (wgrad_split_eligible(a) || (a.R == 2 && a.S == 2))) {
         launch_wgrad_ws(ctx, a);      // (its slab plan -- 256 workgroups -- fits inside wgrad_split's, which sized the workspace)
         return;
     }

@@ -10,6 +10,14 @@
 // (consumers) run nothing but ds_read_b64_tr_b16 + MFMA on tile k -- wgrad_split.hip staged synchronously and relied on
 // a second workgroup per CU to fill the gaps (matrix pipe busy 0.57).  One workgroup per CU also means HALF the partial
 // slabs (256 workgroups instead of 512), i.e. half the bytes reduce_slabs has to move.
+//
+// [r4] Two more template parameters.  ST: the stride of the convolution -- ST = 2 with R = 2 / pad 0 is the weight gradient
+// of the k2 / s2 TRANSPOSED conv (Xop = the gradient on the 2H x 2W grid, Yop = the layer's input on the H x W grid: tap
+// (r, s) pairs Yop pixel (y, x) with Xop pixel (2y + r, 2x + s); the staged Xop tile is the 2TH x 2TW block under the Yop
+// tile, no halo).  PWV: the number of producer waves.  A staged element of a ONE-tap contraction (R = 1, or R = 2 / ST = 2:
+// nothing is shared between taps) feeds few MFMAs, so those shapes are bound by the producers' split, and a producer wave
+// issues one vector instruction per ~14 cycles beside an MFMA wave -- latency, not issue bandwidth: with PWV = 8 every SIMD
+// hosts two producer waves (768 threads, 168 registers) and the split of a tile takes about half as long.
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -31,25 +39,30 @@ struct WWsDev {
     unsigned long long* stamps;       // RFI_DIAG_STAMPS build: per-wave cycle sums
 };
 
-template <int R, int BYB, int BXB, int TH, int TW, int P>
+template <int R, int BYB, int BXB, int TH, int TW, int P, int ST = 1, int PWV = 4>
 struct WWCfg {
     static constexpr int NTAP = R * R;
     static constexpr int BM = TH * TW;
-    static constexpr int HH = TH + R - 1, HW = TW + R - 1, HP = HH * HW;
+    static constexpr int NPT = 64 * PWV;                       // producer threads
+    static constexpr int HH = ST * (TH - 1) + R, HW = ST * (TW - 1) + R, HP = HH * HW;
     static constexpr int BLOCKS = BYB * BXB;
     static constexpr int WP = 4 / BLOCKS;                       // consumer waves that share one channel block (split the k-steps)
     static constexpr int KS = BM / 16, KS_W = KS / WP;
     static constexpr int ROW = P * 64;                          // bytes per pixel of a 32-channel block image: P planes x 32 channels
     static constexpr int YQ = BYB * 8, XQ = BXB * 8;            // float4 groups per pixel
-    static constexpr int Y_ITEMS = (BM * YQ + 255) / 256, X_ITEMS = (HP * XQ + 255) / 256;
+    static constexpr int Y_ITEMS = (BM * YQ + NPT - 1) / NPT, X_ITEMS = (HP * XQ + NPT - 1) / NPT;
     static constexpr int Y_BYTES = BYB * BM * ROW, X_BYTES = BXB * HP * ROW;
     static constexpr int STAGE = Y_BYTES + X_BYTES;
     static constexpr int TC = (NTAP % 3 == 0) ? 3 : NTAP;
     static constexpr int RED_BYTES = (WP > 1) ? BLOCKS * TC * 4096 : 0;
-    static constexpr int LDS_BYTES = 2 * STAGE > RED_BYTES ? 2 * STAGE : RED_BYTES;
+    static constexpr int TR_FLOATS = 32 * 33;                   // per consumer wave: the transposing slab store's scratch
+    static constexpr int EPI_BYTES = RED_BYTES + 4 * TR_FLOATS * 4;
+    static constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
     static_assert(BLOCKS == 1 || BLOCKS == 2 || BLOCKS == 4, "1, 2 or 4 channel blocks");
     static_assert(BM % 16 == 0 && KS % WP == 0 && TW % 4 == 0, "tile must split into k-steps of 16 pixels");
-    static_assert(256 % YQ == 0 && 256 % XQ == 0, "a producer thread keeps one channel group for all its items");
+    static_assert(NPT % YQ == 0 && NPT % XQ == 0, "a producer thread keeps one channel group for all its items");
+    static_assert(PWV == 4 || PWV == 8 || PWV == 12, "4 consumer waves + 4, 8 or 12 producer waves");
+    static_assert(ST == 1 || (ST == 2 && R == 2), "stride 2: the transposed conv's 2x2 taps");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -71,9 +84,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // XM: the load transforms -- 1 Xop = relu(x * scale + shift), Yop plain (the 3x3 layers of the U-Net: compile-time, no
 // tests); 2 whatever the arguments say (either operand, any activation, or none)
-template <int R, int BYB, int BXB, int TH, int TW, int P, int XM>
-__global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
-    using C = WWCfg<R, BYB, BXB, TH, TW, P>;
+template <int R, int BYB, int BXB, int TH, int TW, int P, int XM, int ST = 1, int PWV = 4>
+__global__ __launch_bounds__(256 + 64 * PWV) void wgrad_ws_kernel(WWsDev d) {
+    using C = WWCfg<R, BYB, BXB, TH, TW, P, ST, PWV>;
     const WgradArgs& a = d.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef RFI_DIAG_STAMPS
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
         // relative to its first pixel, LDS addresses) is computed once; a tile costs one scalar base and one add per item
         // (interior tiles) or the bounds tests (edge tiles); the transforms are written per element, unfused and unpacked.
         const int ptid = tid - 256;
-        constexpr int YSTEP = 256 / C::YQ, XSTEP = 256 / C::XQ;      // pixels between a thread's consecutive items
+        constexpr int YSTEP = C::NPT / C::YQ, XSTEP = C::NPT / C::XQ;      // pixels between a thread's consecutive items
         const int yq = ptid % C::YQ, xq = ptid % C::XQ;
         const int ypix0 = ptid / C::YQ, xpix0 = ptid / C::XQ;
         const int cyq = cy0 + yq * 4, cxq = cx0 + xq * 4;
@@ -132,13 +145,23 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
         // LDS byte address of this thread's 4 channels of item 0 (item it: + it * STEP * ROW, an immediate)
         const int y_lds = (yq >> 3) * (C::BM * C::ROW) + (yq & 7) * 8 + ypix0 * C::ROW;
         const int x_lds = (xq >> 3) * (C::HP * C::ROW) + (xq & 7) * 8 + xpix0 * C::ROW;
-        u32x4 yreg[C::Y_ITEMS], xreg[C::X_ITEMS];
-        unsigned yvalid = ~0u, xvalid = ~0u;             // per-item "inside the image" bits of the tile in the registers
-        bool yfull = true, xin = true;                   // ... all set (wave-uniform)
-        auto load_tile = [&](int tile) {
+        struct TileRegs {
+            u32x4 yreg[C::Y_ITEMS], xreg[C::X_ITEMS];
+            unsigned yvalid = ~0u, xvalid = ~0u;         // per-item "inside the image" bits of the tile in the registers
+            bool yfull = true, xin = true;               // ... all set (wave-uniform)
+        };
+        // PWV > 4 (the one-tap shapes: a tile is ~1 us of work, less than a load's round trip): TWO tiles in flight, in two
+        // register sets (tile t in set t & 1)
+        constexpr bool PF2 = PWV > 4;
+        TileRegs tr0, tr1;
+        auto load_tile = [&](int tile, TileRegs& tr) {
+            u32x4 (&yreg)[C::Y_ITEMS] = tr.yreg;
+            u32x4 (&xreg)[C::X_ITEMS] = tr.xreg;
+            unsigned &yvalid = tr.yvalid, &xvalid = tr.xvalid;
+            bool &yfull = tr.yfull, &xin = tr.xin;
             const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
             const int oy0 = ty_i * TH, ox0 = tx_i * TW;
-            const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+            const int iy0 = oy0 * ST - a.pad, ix0 = ox0 * ST - a.pad;
             const unsigned ybase = (unsigned)(((n * a.H + oy0) * a.W + ox0) * a.yop.pstride) * 4u;
             const unsigned xbase = (unsigned)(((n * a.Hx + iy0) * a.Wx + ix0) * a.xop.pstride) * 4u;     // (may be "negative")
             yfull = oy0 + TH <= a.H && ox0 + TW <= a.W;
@@ -204,7 +227,11 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
             }
             return v;
         };
-        auto store_tile = [&](int buf) {
+        auto store_tile = [&](int buf, const TileRegs& tr) {
+            const u32x4 (&yreg)[C::Y_ITEMS] = tr.yreg;
+            const u32x4 (&xreg)[C::X_ITEMS] = tr.xreg;
+            const unsigned yvalid = tr.yvalid, xvalid = tr.xvalid;
+            const bool xin = tr.xin;
             unsigned char* const sY = smem + buf * C::STAGE + y_lds;
             unsigned char* const sX = smem + buf * C::STAGE + C::Y_BYTES + x_lds;
             const bool do_y = XM == 2 && a.xf_y.scale != nullptr, do_x = XM == 1 || (XM == 2 && a.xf_x.scale != nullptr);
@@ -229,13 +256,13 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
                 }
             }
         };
-        load_tile(split);
-        // k = -1 is the prologue (tile 0); every later iteration stages tile k + 1 while the consumers multiply tile k
-        for (int k = -1; k < my_tiles; ++k) {
+        // phase k = -1 is the prologue (tile 0); every later phase stages tile k + 1 while the consumers multiply tile k
+        auto phase = [&](int k, TileRegs& tr) {
             WS_T(t0);
             if (k + 1 < my_tiles) {
-                store_tile((k + 1) & 1);                 // (waits for the loads of tile k + 1, issued an iteration ago)
-                if (k + 2 < my_tiles) load_tile(split + (k + 2) * d.nsplit);
+                store_tile((k + 1) & 1, tr);             // (waits for the loads of tile k + 1, issued one or two phases ago)
+                constexpr int AHEAD = PF2 ? 3 : 2;
+                if (k + AHEAD < my_tiles) load_tile(split + (k + AHEAD) * d.nsplit, tr);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             WS_T(t1);
@@ -243,10 +270,20 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
             WS_T(t2);
             WS_ACC(0, t0, t1);
             WS_ACC(1, t1, t2);
+        };
+        load_tile(split, tr0);
+        if constexpr (PF2) {
+            if (my_tiles > 1) load_tile(split + d.nsplit, tr1);
+            for (int k = -1; k < my_tiles; k += 2) {     // (my_tiles + 1 phases, as many barriers as the consumers pass)
+                phase(k, tr0);
+                if (k + 1 < my_tiles) phase(k + 1, tr1);
+            }
+        } else {
+            for (int k = -1; k < my_tiles; ++k) phase(k, tr0);
         }
 #ifdef RFI_DIAG_STAMPS
-        if (d.stamps && lane == 0) {
-            unsigned long long* o = d.stamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        if (d.stamps && lane == 0 && (PWV == 4 || (wave >= 8 && wave < 12))) {       // (eight records per workgroup: with more producer waves, waves 8-11)
+            unsigned long long* o = d.stamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (PWV == 4 ? wave : wave - 4)) * 8;
             o[0] = st_[0]; o[1] = st_[1]; o[2] = (unsigned long long)my_tiles;
         }
 #endif
@@ -260,7 +297,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
         const int ll = lane & 15, q = ll >> 2, pc = ll & 3, gq = lane >> 4;
         const int lane_off = (gq & 1) * 32 + pc * 8;                  // bytes inside a plane row
         const int kh = gq >> 1;
-        auto xpix = [&](int t) { return (t / TW) * C::HW + (t % TW); };          // halo pixel of tile pixel t (tap 0)
+        auto xpix = [&](int t) { return ST * ((t / TW) * C::HW + (t % TW)); };   // halo pixel of tile pixel t (tap 0)
         f32x16 acc[C::NTAP];
 #pragma unroll
         for (int t = 0; t < C::NTAP; ++t)
@@ -354,7 +391,29 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WWsDev d) {
         }
         WS_T(tp3);
         // ---- the workgroup's partial slab: rows (reg) = cy, cols (lane & 31) = cx
-        if (ps == 0) {
+        if (ps == 0 && a.sy == 1 && a.sx != 1) {
+            // cy is the contiguous index of dW (the transposed conv's [tap][cout][cin]): the accumulators hold cx along the
+            // lanes, so a direct store scatters 64 four-byte words over 64 lines (cycle stamps: 20 k cycles, a quarter of
+            // the kernel).  Each wave transposes its 32 x 32 block through a scratch of its own BEHIND the reduction area
+            // (the staging buffers are free: every wave is past the loop's last barrier) and stores 128-byte rows.
+            float* slab = a.slab + (size_t)split * d.slab_stride;
+            const int li = lane & 31, lh = lane >> 5;
+            float* const scr = reinterpret_cast<float*>(smem + C::RED_BYTES) + wave * C::TR_FLOATS;
+            const int cy = cy0 + by * 32 + li;
+#pragma unroll
+            for (int tap = 0; tap < C::NTAP; ++tap) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[li * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[tap][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: its LDS accesses complete in order)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int cxl = 2 * j + lh, cx = cx0 + bx * 32 + cxl;
+                    const float v = scr[cxl * 33 + li];
+                    if (cy < a.Cy && cx < a.Cx) slab[(int64_t)tap * a.tap_stride + (int64_t)cy + (int64_t)cx * a.sx] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else if (ps == 0) {
             float* slab = a.slab + (size_t)split * d.slab_stride;
             const int li = lane & 31, lh = lane >> 5;
             const int cx = cx0 + bx * 32 + li;
@@ -393,9 +452,9 @@ Plan plan_cfg(const WgradArgs& a) {
     return Plan{nsplit, (int64_t)R * R * a.tap_stride};
 }
 
-template <int R, int BYB, int BXB, int TH, int TW, int P, int XM>
+template <int R, int BYB, int BXB, int TH, int TW, int P, int XM, int ST = 1, int PWV = 4>
 void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
-    using C = WWCfg<R, BYB, BXB, TH, TW, P>;
+    using C = WWCfg<R, BYB, BXB, TH, TW, P, ST, PWV>;
     const Plan p = plan_cfg<R, BYB, BXB, TH, TW>(a);
     RFI_REQUIRE(a.slab && a.slab_floats >= (size_t)p.nsplit * p.slab_stride, "wgrad_ws: slab workspace too small");
     WWsDev d{a, p.nsplit, p.slab_stride, (unsigned)((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride * 4),
@@ -404,14 +463,14 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
     const size_t lds = C::LDS_BYTES;
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<R, BYB, BXB, TH, TW, P, XM>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<R, BYB, BXB, TH, TW, P, XM, ST, PWV>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
     {
         const double flops = a.algo_flops >= 0 ? a.algo_flops : 2.0 * a.N * a.H * a.W * (double)a.Cy * a.Cx * R * R;
         std::string label;
         if (ctx->profiling)
-            label = "wgrad_ws R" + std::to_string(R) + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
+            label = "wgrad_ws R" + std::to_string(R) + (ST == 2 ? "s2" : "") + " N" + std::to_string(a.N) + " " + std::to_string(a.H) + "x" +
                     std::to_string(a.W) + " cx" + std::to_string(a.Cx) + " cy" + std::to_string(a.Cy) + " split" +
                     std::to_string(p.nsplit) + (P == 3 ? " 3xbf16" : " bf16");
         const double bytes = 4.0 * ((double)a.N * a.Hx * a.Wx * a.Cx + (double)a.N * a.H * a.W * a.Cy + (double)R * R * a.Cx * a.Cy);
@@ -421,7 +480,7 @@ void launch_cfg(rfi_ctx* ctx, const WgradArgs& a) {
         RFI_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d.stamps), nw * 64));
         RFI_CHECK_HIP(hipMemsetAsync(d.stamps, 0, nw * 64, ctx->stream));
 #endif
-        hipLaunchKernelGGL((wgrad_ws_kernel<R, BYB, BXB, TH, TW, P, XM>), grid, dim3(512), lds, ctx->stream, d);
+        hipLaunchKernelGGL((wgrad_ws_kernel<R, BYB, BXB, TH, TW, P, XM, ST, PWV>), grid, dim3(256 + C::NPT), lds, ctx->stream, d);
         check_launch("wgrad_ws");
 #ifdef RFI_DIAG_STAMPS
         std::vector<unsigned long long> hs(nw * 8);
@@ -458,12 +517,43 @@ void select(rfi_ctx* ctx, const WgradArgs& a) {
         else launch_cfg<R, BYB_, BXB_, TH_, TW_, 3, 2>(ctx, a);                     \
         return;                                                                     \
     } while (0)
+    if constexpr (R == 1) {
+        // one tap: producer-bound (header) -- eight producer waves where both operands have 64-channel tiles
+        static const int pwv = getenv("RFI_WGRAD_PWV") ? atoi(getenv("RFI_WGRAD_PWV")) : 8;
+        if (y2 && x2 && pwv == 8) {
+            if (p1) launch_cfg<1, 2, 2, 8, 8, 1, 2, 1, 8>(ctx, a);
+            else launch_cfg<1, 2, 2, 8, 8, 3, 2, 1, 8>(ctx, a);
+            return;
+        }
+    }
     if (y2 && x2) RFI_WW(2, 2, 8, 8);
     if (y2) RFI_WW(2, 1, 8, 8);
     if (x2) RFI_WW(1, 2, 8, 8);
     if (a.W >= 16) RFI_WW(1, 1, 8, 16);
     RFI_WW(1, 1, 16, 8);
 #undef RFI_WW
+}
+
+// the transposed conv's weight gradient (R = 2, stride 2, pad 0): Yop tiles of 4 x 8 pixels against the 8 x 16 Xop pixels
+// under them, 64 x 64 channels (a 32-channel Xop: 8 x 8 Yop pixels), eight producer waves
+void select_t2(rfi_ctx* ctx, const WgradArgs& a, Plan* plan_only) {
+    const bool p1 = a.bf16 && !a.bf16x3;
+    const bool y2 = a.Cy > 32, x2 = a.Cx > 32;
+    static const int pwv = getenv("RFI_WGRAD_T2_PWV") ? atoi(getenv("RFI_WGRAD_T2_PWV")) : 8;     // (A/B: 4, 8 or 12 producer waves)
+#define RFI_WT(BYB_, BXB_, TH_, TW_)                                                       \
+    do {                                                                                   \
+        if (plan_only) { *plan_only = plan_cfg<2, BYB_, BXB_, TH_, TW_>(a); return; }      \
+        if (p1) launch_cfg<2, BYB_, BXB_, TH_, TW_, 1, 2, 2, 8>(ctx, a);                   \
+        else if (pwv == 12) launch_cfg<2, BYB_, BXB_, TH_, TW_, 3, 2, 2, 12>(ctx, a);      \
+        else if (pwv == 4) launch_cfg<2, BYB_, BXB_, TH_, TW_, 3, 2, 2, 4>(ctx, a);        \
+        else launch_cfg<2, BYB_, BXB_, TH_, TW_, 3, 2, 2, 8>(ctx, a);                      \
+        return;                                                                            \
+    } while (0)
+    if (y2 && x2) RFI_WT(2, 2, 4, 8);
+    if (y2) RFI_WT(2, 1, 8, 8);
+    if (x2) RFI_WT(1, 2, 4, 8);
+    RFI_WT(1, 1, 8, 8);
+#undef RFI_WT
 }
 
 }  // namespace
@@ -475,12 +565,24 @@ bool wgrad_ws_eligible(const WgradArgs& a) {
     // (tile bases + an item's relative offset are formed in 32 bits; NOWHERE in the kernel needs bases in (-2^24, 0x7f000000))
     if ((int64_t)a.N * a.Hx * a.Wx * a.xop.pstride * 4 >= 0x7f000000ll || (int64_t)a.N * a.H * a.W * a.yop.pstride * 4 >= 0x7f000000ll) return false;
     if (((int64_t)a.Wx + 1) * a.xop.pstride * 4 >= (1 << 24)) return false;
+    if (a.R == 2 && a.S == 2 && a.pad == 0) {             // the transposed conv's weight gradient (select_t2)
+        static const bool no_t2 = getenv("RFI_NO_WGRAD_T2") != nullptr;
+        return !no_t2 && a.Hx == 2 * a.H && a.Wx == 2 * a.W;
+    }
     if (a.S != 1) return false;
     return (a.R == 3 && a.pad == 1) || (a.R == 2 && a.pad == 1) || (a.R == 1 && a.pad == 0);
+}
+// slab workspace of the shapes no other kernel's plan covers (launch_wgrad sizes the others by wgrad_split's plan)
+size_t wgrad_ws_slab_floats(const WgradArgs& a) {
+    if (!(a.R == 2 && a.S == 2) || !wgrad_ws_eligible(a)) return 0;
+    Plan p{0, 0};
+    select_t2(nullptr, a, &p);
+    return (size_t)p.nsplit * p.slab_stride;
 }
 void launch_wgrad_ws(rfi_ctx* ctx, const WgradArgs& a) {
     RFI_REQUIRE(wgrad_ws_eligible(a) && (a.bf16 || a.bf16x3), "wgrad_ws: shape or arithmetic not eligible");
     if (a.R == 3) select<3>(ctx, a);
+    else if (a.R == 2 && a.S == 2) select_t2(ctx, a, nullptr);
     else if (a.R == 2) select<2>(ctx, a);
     else select<1>(ctx, a);
 }

@@ -96,7 +96,8 @@ def test_conv3x3_wgrad_with_load_transform():
 
 
 CONVT_SHAPES = [(2, 8, 8, 64, 32), (1, 4, 4, 16, 8), (2, 16, 16, 128, 64), (1, 32, 32, 64, 32), (2, 2, 2, 8, 4),
-                (1, 6, 10, 12, 20), (3, 5, 7, 48, 96), (64, 8, 8, 512, 256), (1, 3, 3, 32, 16)]
+                (1, 6, 10, 12, 20), (3, 5, 7, 48, 96), (64, 8, 8, 512, 256), (1, 3, 3, 32, 16),
+                (2, 9, 12, 32, 64), (1, 7, 9, 64, 64), (2, 5, 6, 16, 32)]     # (every tile form of the stride-2 weight-gradient kernel, ragged)
 
 
 @pytest.mark.parametrize("shape", CONVT_SHAPES)
