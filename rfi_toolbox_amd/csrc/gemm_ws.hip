@@ -11,6 +11,11 @@
 // pixels against NB = 8 blocks of 32 channels (consumer wave = 32 pixels x 256 channels, 48 MFMAs per 16-channel item)
 // and the producers split 128 x 16 values per item (2 float4 per thread).  Everything is double-buffered ([A0 | A1 | B0 |
 // B1] = 2 x 14 + 2 x 24 KiB), one barrier per item.
+//
+// [r4] PWV: the number of producer waves.  These contractions are bound by the producers' split (a producer wave issues one
+// vector instruction per ~14 cycles beside an MFMA wave: latency, not issue bandwidth), so where the consumers' registers
+// leave room (NB <= 4: 64 accumulator registers) every SIMD hosts TWO producer waves (PWV = 8, 768 threads, <= 168
+// registers): one float4 per producer thread and item instead of two.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -46,19 +51,22 @@ constexpr int ROWB = 112;             // bytes per pixel in LDS: [h 32 B | m 32 
 constexpr int TM = 128;               // pixels per tile
 constexpr int A_BYTES = TM * ROWB;
 
-template <int NB>
+template <int NB, int PWV = 4>
 struct GwCfg {
     static constexpr int NPIECE = 3 * NB;
     static constexpr int B_BYTES = NPIECE * 1024;
-    static constexpr int B_ITEMS = (NPIECE + 3) / 4;
+    static constexpr int B_ITEMS = (NPIECE + PWV - 1) / PWV;
+    static constexpr int A_ITEMS = 8 / PWV;                          // float4 per producer thread and item (128 pixels x 4 groups)
+    static_assert(PWV == 4 || PWV == 8, "4 or 8 producer waves");
     static constexpr int B_OFF = 2 * A_BYTES;
     static constexpr int LDS_BYTES = B_OFF + 2 * B_BYTES;
 };
 
 // XF: 0 none, 1 relu(x * scale + shift), 2 x * scale + shift followed by max(v, v * slope)
-template <int NB, int XF>
-__global__ __launch_bounds__(512) void gemm_ws_kernel(GwDev d) {
-    using C = GwCfg<NB>;
+template <int NB, int XF, int PWV = 4>
+__global__ __launch_bounds__(256 + 64 * PWV) void gemm_ws_kernel(GwDev d) {
+    using C = GwCfg<NB, PWV>;
+    constexpr int AI = C::A_ITEMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,19 +101,19 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GwDev d) {
         const int ptid = tid - 256, pw = wave - 4;
         const unsigned q4b = (unsigned)(ptid & 3) * 16u;
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, (int)d.x_bytes, 0x00020000);
-        unsigned voff[2], vmsk[2];
+        unsigned voff[AI], vmsk[AI];
         auto setup_tile = [&](int m0) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < AI; ++it) {
                 const int m = m0 + (ptid >> 2) + it * 64;
                 const bool ok = m < d.M;
                 voff[it] = ok ? in_pixel(m) * 4u + q4b : 0x80000000u;
                 vmsk[it] = ok ? 0xffffffffu : 0u;
             }
         };
-        u32x4 raw[2];
+        u32x4 raw[AI];
         f32x4 screg = {1.f, 1.f, 1.f, 1.f}, shreg = {0.f, 0.f, 0.f, 0.f};
-        unsigned pl[2][6];
+        unsigned pl[AI][6];
         // chunk jc of a tile: tap jc / nkc_tap, channels 16 (jc % nkc_tap) ...; the tap's pixel offset and the channel
         // offset are wave-uniform: they ride in the scalar offset of the buffer load
         auto issue_loads = [&](int jc) {
@@ -117,11 +125,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GwDev d) {
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int it = 0; it < 2; ++it) raw[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff[it], soff, 0);
+            for (int it = 0; it < AI; ++it) raw[it] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff[it], soff, 0);
         };
         auto split_all = [&]() {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < AI; ++it) {
                 f32x4 v = __builtin_bit_cast(f32x4, raw[it]);
                 if constexpr (XF != 0) {
 #pragma unroll
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GwDev d) {
         auto write_all = [&](int buf) {
             unsigned char* const sA = smem + buf * A_BYTES + (ptid >> 2) * ROWB + (ptid & 3) * 8;
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < AI; ++it) {
                 unsigned char* row = sA + it * 64 * ROWB;
                 *reinterpret_cast<u32x2*>(row) = u32x2{pl[it][0], pl[it][1]};
                 *reinterpret_cast<u32x2*>(row + 32) = u32x2{pl[it][2], pl[it][3]};
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GwDev d) {
             unsigned char* const sB = smem + C::B_OFF + buf * C::B_BYTES;
 #pragma unroll
             for (int i = 0; i < C::B_ITEMS; ++i) {
-                const int p = pw + 4 * i;
+                const int p = pw + PWV * i;
                 if (p < C::NPIECE) {
                     const int nb = p / 3, plane = p - nb * 3;
                     const int cb = cb0 + nb < d.ncb ? cb0 + nb : d.ncb - 1;       // (a block beyond the last: products never stored)
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GwDev d) {
                 }
                 issue_loads(lch);                        // (the very last item is re-read once: harmless)
                 __builtin_amdgcn_sched_barrier(0);
-                wait_vmcnt<2>();                         // all but the two halo loads: the DMA pieces have landed
+                wait_vmcnt<AI>();                        // all but the item's own loads: the DMA pieces have landed
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             wg_barrier();
@@ -316,9 +324,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GwDev d) {
     }
 }
 
-template <int NB, int XF>
+template <int NB, int XF, int PWV = 4>
 void launch_gw(rfi_ctx* ctx, GwDev& d) {
-    using C = GwCfg<NB>;
+    using C = GwCfg<NB, PWV>;
     const int ntiles = (int)cdiv(d.M, TM);
     const int ycols = (int)cdiv(d.ncb, NB);
     static const int wgs = getenv("RFI_GW_WGS") ? atoi(getenv("RFI_GW_WGS")) : 256;
@@ -329,10 +337,10 @@ void launch_gw(rfi_ctx* ctx, GwDev& d) {
     if (ntiles < 8) GX = ntiles;
     static PerDeviceOnce attr_once;
     attr_once.run(ctx->device, [&] {
-        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws_kernel<NB, XF>),
+        RFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws_kernel<NB, XF, PWV>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     });
-    hipLaunchKernelGGL((gemm_ws_kernel<NB, XF>), dim3(GX, ycols), dim3(512), C::LDS_BYTES, ctx->stream, d);
+    hipLaunchKernelGGL((gemm_ws_kernel<NB, XF, PWV>), dim3(GX, ycols), dim3(256 + 64 * PWV), C::LDS_BYTES, ctx->stream, d);
     check_launch("gemm_ws");
 }
 
@@ -383,6 +391,10 @@ void launch_gemm_ws(rfi_ctx* ctx, ConvArgs& a, const bf16_t* wB3) {
     const int xf = !a.xf.scale ? 0 : (a.xf.relu == 1 || (a.xf.relu == 2 && a.xf.slope == 0.0f)) ? 1 : 2;
     // 8 blocks per workgroup where the grid still covers the chip, else 4 (2 for a 64-channel output)
     const bool wide = d.ncb > 4 && cdiv(d.M, TM) * cdiv(d.ncb, 8) >= 192;
+    static const bool pwv8 = !(getenv("RFI_GW_PWV") && atoi(getenv("RFI_GW_PWV")) == 4);      // (A/B: RFI_GW_PWV=4)
+    // (measured and not kept: 64-channel column groups with eight producer waves where 128-channel ones leave half the CUs
+    // without a workgroup -- the 8 x 8 maps: the kernel alone 59 -> 53 us, the step +0.7 %: the idle CUs are where the side
+    // stream's weight gradient runs)
     if (wide) {
         if (xf == 0) launch_gw<8, 0>(ctx, d);
         else if (xf == 1) launch_gw<8, 1>(ctx, d);
@@ -391,6 +403,10 @@ void launch_gemm_ws(rfi_ctx* ctx, ConvArgs& a, const bf16_t* wB3) {
         if (xf == 0) launch_gw<2, 0>(ctx, d);
         else if (xf == 1) launch_gw<2, 1>(ctx, d);
         else launch_gw<2, 2>(ctx, d);
+    } else if (pwv8) {
+        if (xf == 0) launch_gw<4, 0, 8>(ctx, d);
+        else if (xf == 1) launch_gw<4, 1, 8>(ctx, d);
+        else launch_gw<4, 2, 8>(ctx, d);
     } else {
         if (xf == 0) launch_gw<4, 0>(ctx, d);
         else if (xf == 1) launch_gw<4, 1>(ctx, d);
