@@ -284,16 +284,30 @@ __global__ void bn_bwd_reduce_kernel(const void* __restrict__ da, int da16, cons
     if (c < C) {
         float sc[V], sh[V], mu[V], is[V];
         ldv<V>(scale + c, sc); ldv<V>(shift + c, sh); ldv<V>(mean + c, mu); ldv<V>(invstd + c, is);
-        for (int64_t r = r0 + rl; r < r1; r += RL) {
-            float yv[V], dv[V];
-            ldy<V>(y, y16, r * yps + c, yv);
-            ldy<V>(da, da16, r * C + c, dv);
+        // four rows per trip: the eight loads issue before the first sum (one row per trip left two 16-byte loads in flight
+        // per lane: 4 TB/s on the 128 x 128 levels); the rows are summed in the same order as before -- bit-identical records
+        constexpr int U = 4;
+        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)U * RL) {
+            float yv[U][V], dv[U][V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
-                const float xh = (yv[v] - mu[v]) * is[v];
-                acc[0][v] += (double)dz;
-                acc[1][v] += (double)dz * (double)xh;
+            for (int k = 0; k < U; ++k) {
+                const int64_t r = rb + (int64_t)k * RL;
+                if (r < r1) {
+                    ldy<V>(y, y16, r * yps + c, yv[k]);
+                    ldy<V>(da, da16, r * C + c, dv[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (rb + (int64_t)k * RL < r1) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const float dz = dact_f(yv[k][v] * sc[v] + sh[v], dv[k][v], slope);
+                        const float xh = (yv[k][v] - mu[v]) * is[v];
+                        acc[0][v] += (double)dz;
+                        acc[1][v] += (double)dz * (double)xh;
+                    }
+                }
             }
         }
     }
@@ -492,16 +506,31 @@ __global__ void bn_bwd_apply_kernel(void* __restrict__ da_, int da16, const void
         float hw[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) hw[v] = head_dl ? head_w[c + v] : 0.0f;
-        for (int64_t r = r0 + rl; r < r1; r += RL) {
-            float yv[V], dv[V], o[V];
-            ldy<V>(y, y16, r * yps + c, yv);
-            if (head_dl) {
-                const float d = head_dl[r];
+        // four rows per trip, loads first (as bn_bwd_reduce_kernel; same order of the sums)
+        constexpr int U = 4;
+        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)U * RL) {
+          float yu[U][V], du[U][V];
 #pragma unroll
-                for (int v = 0; v < V; ++v) dv[v] = d * hw[v];
-            } else {
-                ldy<V>(da_, da16, r * C + c, dv);
-            }
+          for (int k = 0; k < U; ++k) {
+              const int64_t r = rb + (int64_t)k * RL;
+              if (r < r1) {
+                  ldy<V>(y, y16, r * yps + c, yu[k]);
+                  if (head_dl) {
+                      const float d = head_dl[r];
+#pragma unroll
+                      for (int v = 0; v < V; ++v) du[k][v] = d * hw[v];
+                  } else {
+                      ldy<V>(da_, da16, r * C + c, du[k]);
+                  }
+              }
+          }
+#pragma unroll
+          for (int k = 0; k < U; ++k) {
+            const int64_t r = rb + (int64_t)k * RL;
+            if (r >= r1) break;
+            float yv[V], dv[V], o[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { yv[v] = yu[k][v]; dv[v] = du[k][v]; }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const float dz = dact_f(yv[v] * sc[v] + sh[v], dv[v], slope);
@@ -530,6 +559,7 @@ __global__ void bn_bwd_apply_kernel(void* __restrict__ da_, int da16, const void
             } else {
                 stv<V>(static_cast<float*>(da_) + r * C + c, o);        // (float32 tensors only: the launcher checks)
             }
+          }
         }
     }
     row_lane_reduce<V, 1>(acc, red, CL, RL, cl, rl);
