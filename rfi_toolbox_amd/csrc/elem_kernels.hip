@@ -612,13 +612,21 @@ __global__ void channel_sum_kernel(const void* __restrict__ v_, int v16, int pst
     double acc[1][V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[0][v] = 0;
-    if (c < C)
-        for (int64_t r = r0 + rl; r < r1; r += RL) {
-            float x[V];
-            ldy<V>(v_, v16, r * pstride + c, x);
+    if (c < C) {
+        constexpr int U = 8;          // eight rows per trip, loads first (one load in flight per lane: 3.2 TB/s); same order of the sums
+        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)U * RL) {
+            float x[U][V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[0][v] += (double)x[v];
+            for (int k = 0; k < U; ++k)
+                if (rb + (int64_t)k * RL < r1) ldy<V>(v_, v16, (rb + (int64_t)k * RL) * pstride + c, x[k]);
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (rb + (int64_t)k * RL < r1) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[0][v] += (double)x[k][v];
+                }
         }
+    }
     row_lane_reduce<V, 1>(acc, red, CL, RL, cl, rl);
     if (rl == 0 && c < C) {
 #pragma unroll
@@ -1099,11 +1107,26 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const void* __restric
             float sc[4], sh[4], wv[4], mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
             ldv<4>(scale + c, sc); ldv<4>(shift + c, sh); ldv<4>(w + (int64_t)o * C + c, wv);
             if (bn_records) { ldv<4>(mean + c, mu); ldv<4>(invstd + c, is); }
-            for (int64_t r = r0 + rl; r < r1; r += RL) {
-                const float d = dl[r * Cout + o];
+            constexpr int U = 4;      // four rows per trip, loads first (same order of the sums)
+            for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)U * RL) {
+              float du[U], yu[U][4], gu[U][4];
+#pragma unroll
+              for (int k = 0; k < U; ++k) {
+                  const int64_t r = rb + (int64_t)k * RL;
+                  if (r < r1) {
+                      du[k] = dl[r * Cout + o];
+                      ldy<4>(y, y16, r * yps + c, yu[k]);
+                      if (o != 0) ldv<4>(da + r * C + c, gu[k]);
+                  }
+              }
+#pragma unroll
+              for (int k = 0; k < U; ++k) {
+                const int64_t r = rb + (int64_t)k * RL;
+                if (r >= r1) break;
+                const float d = du[k];
                 float yv[4], g[4];
-                ldy<4>(y, y16, r * yps + c, yv);
-                if (o != 0) ldv<4>(da + r * C + c, g);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { yv[v] = yu[k][v]; g[v] = gu[k][v]; }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const float z = yv[v] * sc[v] + sh[v];
@@ -1123,6 +1146,7 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const void* __restric
                     }
                 }
                 sb += (double)d;
+              }
             }
         }
 #pragma unroll
