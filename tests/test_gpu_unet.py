@@ -177,7 +177,10 @@ def test_unet_bigger_golden(golden_dir):
             np.testing.assert_allclose(sd[k].numpy(), g[f"state1/{k}"], rtol=0, atol=2.5e-4, err_msg=k)
 
 
-@pytest.mark.parametrize("f,n,size", [(32, 4, 128), (16, 2, 64)])
+@pytest.mark.parametrize("f,n,size", [(32, 4, 128), (16, 2, 64),
+                                      # the 32-channel input-gradient convs with the BatchNorm-backward sums in their epilogue:
+                                      # ragged 8 x 32 tiles (48 = 32 + 16) and the 16 x 16 tile
+                                      (32, 2, 48), (32, 4, 16)])
 def test_flagship_width_vs_oracle(f, n, size):
     """UNet(3,1,32) batch 4 @128x128 (BASELINE config 1 shape): logits, loss, gradient norm,
     gradients and post-step eval logits against the CPU oracle on seeded inputs.
