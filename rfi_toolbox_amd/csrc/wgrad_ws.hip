@@ -17,7 +17,7 @@
 // tile, no halo).  PWV: the number of producer waves.  A staged element of a ONE-tap contraction (R = 1, or R = 2 / ST = 2:
 // nothing is shared between taps) feeds few MFMAs, so those shapes are bound by the producers' split, and a producer wave
 // issues one vector instruction per ~14 cycles beside an MFMA wave -- latency, not issue bandwidth: with PWV = 8 every SIMD
-// hosts two producer waves (768 threads, 168 registers) and the split of a tile takes about half as long.
+// hosts two producer waves (768 threads, 168 registers) and the split of a tile takes about two thirds as long.
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -150,10 +150,9 @@ __global__ __launch_bounds__(256 + 64 * PWV) void wgrad_ws_kernel(WWsDev d) {
             unsigned yvalid = ~0u, xvalid = ~0u;         // per-item "inside the image" bits of the tile in the registers
             bool yfull = true, xin = true;               // ... all set (wave-uniform)
         };
-        // PWV > 4 (the one-tap shapes: a tile is ~1 us of work, less than a load's round trip): TWO tiles in flight, in two
-        // register sets (tile t in set t & 1)
-        constexpr bool PF2 = PWV > 4;
-        TileRegs tr0, tr1;
+        // (a second tile of loads in flight, in a second register set, was measured for the one-tap shapes: +-0 -- the producers
+        // do not wait for their loads -- and taken out again)
+        TileRegs tr0;
         auto load_tile = [&](int tile, TileRegs& tr) {
             u32x4 (&yreg)[C::Y_ITEMS] = tr.yreg;
             u32x4 (&xreg)[C::X_ITEMS] = tr.xreg;
@@ -260,9 +259,8 @@ __global__ __launch_bounds__(256 + 64 * PWV) void wgrad_ws_kernel(WWsDev d) {
         auto phase = [&](int k, TileRegs& tr) {
             WS_T(t0);
             if (k + 1 < my_tiles) {
-                store_tile((k + 1) & 1, tr);             // (waits for the loads of tile k + 1, issued one or two phases ago)
-                constexpr int AHEAD = PF2 ? 3 : 2;
-                if (k + AHEAD < my_tiles) load_tile(split + (k + AHEAD) * d.nsplit, tr);
+                store_tile((k + 1) & 1, tr);             // (waits for the loads of tile k + 1, issued a phase ago)
+                if (k + 2 < my_tiles) load_tile(split + (k + 2) * d.nsplit, tr);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             WS_T(t1);
@@ -272,15 +270,7 @@ __global__ __launch_bounds__(256 + 64 * PWV) void wgrad_ws_kernel(WWsDev d) {
             WS_ACC(1, t1, t2);
         };
         load_tile(split, tr0);
-        if constexpr (PF2) {
-            if (my_tiles > 1) load_tile(split + d.nsplit, tr1);
-            for (int k = -1; k < my_tiles; k += 2) {     // (my_tiles + 1 phases, as many barriers as the consumers pass)
-                phase(k, tr0);
-                if (k + 1 < my_tiles) phase(k + 1, tr1);
-            }
-        } else {
-            for (int k = -1; k < my_tiles; ++k) phase(k, tr0);
-        }
+        for (int k = -1; k < my_tiles; ++k) phase(k, tr0);     // (my_tiles + 1 phases, as many barriers as the consumers pass)
 #ifdef RFI_DIAG_STAMPS
         if (d.stamps && lane == 0 && (PWV == 4 || (wave >= 8 && wave < 12))) {       // (eight records per workgroup: with more producer waves, waves 8-11)
             unsigned long long* o = d.stamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (PWV == 4 ? wave : wave - 4)) * 8;
