@@ -130,3 +130,19 @@ def test_bench_under_torch_distributed_run_falls_back_when_a_rank_stalls():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["fallback"] == "unbucketed", r.stdout
     assert "another rank's supervisor ended the attempt" in r.stderr or "rank 0 has been in the phase" in r.stderr
+
+
+def test_bench_supervisor_attempt_limit_runs_from_the_end_of_the_imports():
+    """No phase bound is hit (defaults: 45-200 s) but the attempt's own limit is: rank 2 hangs after the rendezvous, the limit
+    of 8 s -- counted from the moment every child has finished its imports, however long those took -- ends the attempt and
+    the fresh unbucketed set finishes inside RFI_BENCH_TOTAL_TIMEOUT."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "4"],
+                       env=_clean_env(RFI_BENCH_STALL_RANK="2", RFI_BENCH_STALL_PHASE="control_plane", RFI_BENCH_LAUNCH_TIMEOUT="8",
+                                      RFI_BENCH_TOTAL_TIMEOUT="120"), capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 100
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["fallback"] == "unbucketed", r.stdout
+    assert "after the imports" in r.stderr and "attempt 1 (bucketed exchange) failed" in r.stderr, r.stderr[-1500:]
